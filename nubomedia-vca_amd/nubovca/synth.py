@@ -1,0 +1,247 @@
+"""Synthetic inputs for the Haar hot path: a seeded stump cascade written in
+OpenCV's old-format XML (the reference hard-codes
+/usr/share/opencv/haarcascades/haarcascade_frontalface_alt.xml,
+FACE/kmsfacedetect.cpp:40, which is not available offline) and seeded frames.
+
+The cascade has the *shape* of haarcascade_frontalface_alt (20x20 window,
+22 stages, 2135 stumps, first stages 3/16/21) and is constructed so that
+  * i.i.d. noise windows are rejected with ~50 % probability per stage
+    (the per-stage false-alarm rate haartraining aims for), and
+  * windows resembling TEMPLATE (a 20x20 face-like pattern) pass every stage.
+It is a workload generator, not a face model.
+"""
+import numpy as np
+
+FRONTALFACE_ALT_STAGES = [3, 16, 21, 39, 33, 44, 50, 51, 56, 71, 80, 103, 111, 102,
+                          135, 137, 140, 160, 177, 182, 211, 213]
+WIN = 20
+
+
+def template(win=WIN):
+    """20x20 face-like luminance pattern, float64 in [0,255]."""
+    y, x = np.mgrid[0:win, 0:win].astype(np.float64)
+    s = win / 20.0
+
+    def blob(cx, cy, sx, sy, amp):
+        return amp * np.exp(-(((x - cx * s) / (sx * s)) ** 2 + ((y - cy * s) / (sy * s)) ** 2))
+
+    t = np.full((win, win), 150.0)
+    t += blob(9.5, 9.5, 9, 11, 40)           # bright face oval
+    t += blob(5.5, 7.0, 2.2, 1.4, -95)       # left eye
+    t += blob(13.5, 7.0, 2.2, 1.4, -95)      # right eye
+    t += blob(5.5, 4.6, 2.8, 0.9, -45)       # brows
+    t += blob(13.5, 4.6, 2.8, 0.9, -45)
+    t += blob(9.5, 10.0, 1.3, 3.0, 45)       # nose bridge
+    t += blob(9.5, 15.2, 3.4, 1.2, -80)      # mouth
+    t += blob(9.5, 0.5, 9, 2.0, -60)         # hair line
+    return np.clip(t, 0, 255)
+
+
+def _rand_feature(rng, win):
+    """One Haar-like feature inside the [1, win-1) interior.
+    Returns list of (x, y, w, h, weight) with rect[0] the whole support."""
+    lo, hi = 1, win - 1
+    kind = rng.integers(0, 5)
+    for _ in range(100):
+        if kind == 0:      # x2
+            w, h = rng.integers(1, 9), rng.integers(1, 17)
+            W, H = 2 * w, h
+        elif kind == 1:    # y2
+            w, h = rng.integers(1, 17), rng.integers(1, 9)
+            W, H = w, 2 * h
+        elif kind == 2:    # x3
+            w, h = rng.integers(1, 6), rng.integers(1, 17)
+            W, H = 3 * w, h
+        elif kind == 3:    # y3
+            w, h = rng.integers(1, 17), rng.integers(1, 6)
+            W, H = w, 3 * h
+        else:              # x2_y2
+            w, h = rng.integers(1, 9), rng.integers(1, 9)
+            W, H = 2 * w, 2 * h
+        if W * H < 8 or W > hi - lo or H > hi - lo:
+            continue
+        x = rng.integers(lo, hi - W + 1)
+        y = rng.integers(lo, hi - H + 1)
+        if kind == 0:
+            return [(x, y, W, H, -1.0), (x + w, y, w, h, 2.0)]
+        if kind == 1:
+            return [(x, y, W, H, -1.0), (x, y + h, w, h, 2.0)]
+        if kind == 2:
+            return [(x, y, W, H, -1.0), (x + w, y, w, h, 3.0)]
+        if kind == 3:
+            return [(x, y, W, H, -1.0), (x, y + h, w, h, 3.0)]
+        return [(x, y, W, H, -1.0), (x, y, w, h, 2.0), (x + w, y + h, w, h, 2.0)]
+    raise RuntimeError("feature sampling failed")
+
+
+def _pixel_coeffs(feat, win):
+    """Per-pixel coefficient image of a feature at scale 1 with OpenCV's weight
+    normalisation (rect0 weight recomputed so the feature is zero-mean)."""
+    inv_area = 1.0 / ((win - 2) * (win - 2))
+    c = np.zeros((win, win))
+    w = [r[4] * inv_area for r in feat]
+    w[0] = -sum(w[k] * feat[k][2] * feat[k][3] for k in range(1, len(feat))) / (feat[0][2] * feat[0][3])
+    for k, (x, y, rw, rh, _) in enumerate(feat):
+        c[y:y + rh, x:x + rw] += w[k]
+    return c
+
+
+def _norm_values(coefs, windows):
+    """Normalised feature values v = sum(c*img)/std(img[1:-1,1:-1]) for a stack of
+    windows [N,win,win] and coefficient images [F,win,win] -> [N,F]."""
+    inner = windows[:, 1:-1, 1:-1].reshape(len(windows), -1)
+    std = inner.std(axis=1)
+    std = np.where(std > 0, std, 1.0)
+    vals = windows.reshape(len(windows), -1) @ coefs.reshape(len(coefs), -1).T
+    return vals / std[:, None]
+
+
+def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open_stages=4,
+                 agree_lo=0.52, agree_hi=0.60):
+    """Returns a dict describing a stump cascade (see cascade_to_xml).
+
+    Every stump separates TEMPLATE's normalised feature value v_T from zero
+    (threshold 0.4*v_T, |v_T| >= 1.5 noise sigmas).  The first `open_stages`
+    stages get the stage threshold that passes ~pass_rate of noise windows (the
+    bulk of the work on any frame, as with a trained cascade); later stages
+    additionally demand that agree_lo..agree_hi of the vote weight sides with
+    the template, which makes the cascade specific.
+    """
+    stages = list(FRONTALFACE_ALT_STAGES if stages is None else stages)
+    rng = np.random.default_rng(seed)
+    T = template(win)
+    negs = rng.integers(0, 256, size=(n_mc, win, win)).astype(np.float64)
+    Tn = T[None]
+    out_stages = []
+    for si, ncls in enumerate(stages):
+        feats, thr, lv, rv = [], [], [], []
+        coefs = []
+        while len(feats) < ncls:
+            f = _rand_feature(rng, win)
+            c = _pixel_coeffs(f, win)
+            vT = _norm_values(c[None], Tn)[0, 0]
+            sf = np.sqrt((c ** 2).sum())             # std of v on unit-variance noise
+            if abs(vT) < 1.5 * sf:
+                continue                             # not discriminative for the template
+            t = 0.4 * vT
+            a = rng.uniform(0.4, 1.0)
+            feats.append(f); coefs.append(c); thr.append(t)
+            if vT >= t:      # template on the "right" (>= t) side
+                lv.append(-a); rv.append(a)
+            else:
+                lv.append(a); rv.append(-a)
+        coefs = np.stack(coefs)
+        v = _norm_values(coefs, negs)
+        votes = np.where(v >= np.array(thr)[None], np.array(rv)[None], np.array(lv)[None]).sum(axis=1)
+        # achievable vote sums are discrete: take the cut whose noise pass rate is closest
+        cand = np.unique(votes)
+        rates = np.array([(votes >= cnd).mean() for cnd in cand])
+        st_thr = cand[np.argmin(np.abs(rates - pass_rate))] - 1e-3
+        s_T = sum(abs(a) for a in rv)
+        if si >= open_stages:
+            frac = agree_lo + (agree_hi - agree_lo) * min(1.0, (si - open_stages) / 6.0)
+            st_thr = max(st_thr, s_T * (2 * frac - 1))
+        st_thr = min(st_thr, 0.6 * s_T)              # the template keeps a wide margin
+        out_stages.append(dict(features=feats, thresholds=thr, left=lv, right=rv,
+                               stage_threshold=float(st_thr)))
+    return dict(name="synthetic_frontalface", size=(win, win), stages=out_stages)
+
+
+def _f(v):
+    return "%.9g" % float(np.float32(v))
+
+
+def cascade_to_xml(casc):
+    """Old-format OpenCV Haar cascade XML (type_id opencv-haar-classifier)."""
+    L = ['<?xml version="1.0"?>', "<opencv_storage>",
+         '<%s type_id="opencv-haar-classifier">' % casc["name"],
+         "  <size>%d %d</size>" % casc["size"], "  <stages>"]
+    for si, st in enumerate(casc["stages"]):
+        L += ["    <_>", "      <!-- stage %d -->" % si, "      <trees>"]
+        for j, feat in enumerate(st["features"]):
+            L += ["        <_>", "          <!-- tree %d -->" % j, "          <_>",
+                  "            <!-- root node -->", "            <feature>", "              <rects>"]
+            for (x, y, w, h, wt) in feat:
+                L.append("                <_>%d %d %d %d %d.</_>" % (x, y, w, h, int(wt)))
+            L += ["              </rects>", "              <tilted>0</tilted></feature>",
+                  "            <threshold>%s</threshold>" % _f(st["thresholds"][j]),
+                  "            <left_val>%s</left_val>" % _f(st["left"][j]),
+                  "            <right_val>%s</right_val></_></_>" % _f(st["right"][j])]
+        L += ["      </trees>", "      <stage_threshold>%s</stage_threshold>" % _f(st["stage_threshold"]),
+              "      <parent>%d</parent>" % (si - 1), "      <next>-1</next></_>"]
+    L += ["  </stages></%s>" % casc["name"], "</opencv_storage>", ""]
+    return "\n".join(L)
+
+
+def synthetic_cascade_xml(seed=2016, stages=None):
+    return cascade_to_xml(make_cascade(seed=seed, stages=stages))
+
+
+# ------------------------------------------------------------------ frames
+def _resize_bilinear_f(img, size):
+    h, w = img.shape
+    ys = (np.arange(size) + 0.5) * h / size - 0.5
+    xs = (np.arange(size) + 0.5) * w / size - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, h - 1); y1 = np.clip(y0 + 1, 0, h - 1)
+    x0 = np.clip(np.floor(xs).astype(int), 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
+    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None]; fx = np.clip(xs - np.floor(xs), 0, 1)[None, :]
+    a = img[y0][:, x0]; b = img[y0][:, x1]; c = img[y1][:, x0]; d = img[y1][:, x1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_gray(W, H, seed, kind="noise", faces=()):
+    """Seeded luminance field, uint8 [H,W].
+    kind: 'noise' uniform u8; 'natural' 1/f multi-octave noise; 'gradient' smooth ramp +
+    mild noise; 'flat'.
+    faces: iterable of (x, y, size): TEMPLATE pasted at that box."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        g = rng.integers(0, 256, size=(H, W)).astype(np.float64)
+    elif kind == "gradient":
+        yy, xx = np.mgrid[0:H, 0:W]
+        g = 40 + 170.0 * (0.6 * xx / max(W - 1, 1) + 0.4 * yy / max(H - 1, 1)) + rng.normal(0, 3.0, size=(H, W))
+    elif kind == "natural":
+        # 1/f-like field: equal-amplitude octaves of bilinearly upsampled value noise, so that
+        # Haar responses do not vanish at large window scales the way they do on white noise
+        g = np.zeros((H, W))
+        cell, n_oct = 2, 0
+        while cell <= max(W, H):
+            gh, gw = H // cell + 3, W // cell + 3
+            grid = rng.uniform(-1, 1, size=(gh, gw))
+            ys = np.arange(H) / cell; xs = np.arange(W) / cell
+            y0 = ys.astype(int); x0 = xs.astype(int)
+            fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+            top = grid[y0][:, x0] * (1 - fx) + grid[y0][:, x0 + 1] * fx
+            bot = grid[y0 + 1][:, x0] * (1 - fx) + grid[y0 + 1][:, x0 + 1] * fx
+            g += top * (1 - fy) + bot * fy
+            cell *= 2; n_oct += 1
+        g += rng.uniform(-1, 1, size=(H, W))
+        g = 128 + g * (100.0 / np.sqrt(n_oct + 1))
+    elif kind == "flat":
+        g = np.full((H, W), 128.0)
+    else:
+        raise ValueError(kind)
+    T = template()
+    for (x, y, size) in faces:
+        patch = _resize_bilinear_f(T, int(size)) + rng.normal(0, 2.0, size=(int(size), int(size)))
+        g[y:y + size, x:x + size] = patch[:max(0, min(size, H - y)), :max(0, min(size, W - x))]
+    return np.clip(np.rint(g), 0, 255).astype(np.uint8)
+
+
+def make_bgr(W, H, seed, kind="noise", faces=(), channels=3):
+    """BGR (or BGRA) frame whose BGR2GRAY is close to make_gray's field."""
+    g = make_gray(W, H, seed, kind, faces)
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    out = np.empty((H, W, channels), np.uint8)
+    jitter = rng.integers(-6, 7, size=(H, W, 2))
+    out[..., 0] = np.clip(g.astype(np.int32) + jitter[..., 0], 0, 255)
+    out[..., 1] = g
+    out[..., 2] = np.clip(g.astype(np.int32) + jitter[..., 1], 0, 255)
+    if channels == 4:
+        out[..., 3] = 255
+    return out
+
+
+def frame_seed(stream_id, frame_idx):
+    """seed = 0xC0FFEE + stream_id*1000 + frame_idx."""
+    return 0xC0FFEE + stream_id * 1000 + frame_idx

@@ -1,0 +1,91 @@
+"""Pins the CPU oracle's imgproc restatement against closed-form known answers
+(SURVEY.md 8c / Appendix A.1-A.4).  The reference holds no fixtures for this
+path, so these hand-derived cases are the only anchors ("parity unpinned")."""
+import numpy as np
+import orc
+
+
+def test_gray_primaries():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]], np.uint8)
+    assert orc.bgr2gray(px).tolist() == [[29, 150, 76, 255, 0]]
+
+
+def test_gray_formula_random_and_bgra():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8)
+    exp = ((img[..., 0].astype(np.int64) * 1868 + img[..., 1].astype(np.int64) * 9617
+            + img[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(orc.bgr2gray(img), exp)
+    assert np.array_equal(orc.bgr2gray(img[..., :3]), exp)
+
+
+def test_resize_identity_and_constant():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(31, 45), dtype=np.uint8)
+    assert np.array_equal(orc.resize_linear(img, 45, 31), img)
+    c = np.full((40, 60, 3), 77, np.uint8)
+    assert np.all(orc.resize_linear(c, 13, 9) == 77)
+
+
+def test_resize_half_is_area_average():
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(20, 32), dtype=np.uint8).astype(np.int32)
+    exp = (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(orc.resize_linear(img.astype(np.uint8), 16, 10), exp.astype(np.uint8))
+
+
+def test_resize_integer_ratio_samples_two_taps():
+    # scale 4: fx = (dx+0.5)*4-0.5 = 4dx+1.5 -> sx = 4dx+1, fx=.5 -> mean of taps 4dx+1, 4dx+2
+    src = np.zeros((8, 16), np.uint8)
+    src[:, 1::4] = 100
+    src[:, 2::4] = 200
+    out = orc.resize_linear(src, 4, 2)
+    assert np.all(out == 150)
+
+
+def test_resize_upscale_edges_clamp():
+    src = np.array([[0, 100]], np.uint8)
+    out = orc.resize_linear(src, 4, 1)
+    # fx: -0.25 -> clamp 0 ; 0.25 ; 0.75 ; 1.25 -> clamp to last
+    assert out.tolist() == [[0, 25, 75, 100]]
+
+
+def test_equalize_two_levels_and_constant():
+    img = np.zeros((10, 10), np.uint8)
+    img[:, 5:] = 200
+    out = orc.equalize_hist(img)
+    assert set(np.unique(out)) == {0, 255}
+    const = np.full((7, 9), 42, np.uint8)
+    assert np.all(orc.equalize_hist(const) == 42)
+
+
+def test_equalize_matches_numpy_formula():
+    rng = np.random.default_rng(3)
+    img = rng.integers(10, 200, size=(64, 48), dtype=np.uint8)
+    hist = np.bincount(img.ravel(), minlength=256)
+    i = int(np.nonzero(hist)[0][0])
+    scale = np.float32(255.0) / np.float32(img.size - hist[i])
+    lut = np.zeros(256, np.uint8)
+    s = 0
+    for j in range(i + 1, 256):
+        s += int(hist[j])
+        lut[j] = np.clip(np.rint(np.float32(s) * scale), 0, 255)
+    assert np.array_equal(orc.equalize_hist(img), lut[img])
+
+
+def test_integral_ones_and_random():
+    s, q = orc.integral(np.ones((5, 7), np.uint8))
+    yy, xx = np.mgrid[0:6, 0:8]
+    assert np.array_equal(s, yy * xx)
+    assert np.array_equal(q, (yy * xx).astype(np.float64))
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, size=(33, 41), dtype=np.uint8)
+    s, q = orc.integral(img)
+    assert np.array_equal(s[1:, 1:], img.astype(np.int64).cumsum(0).cumsum(1))
+    assert np.array_equal(q[1:, 1:], (img.astype(np.int64) ** 2).cumsum(0).cumsum(1).astype(np.float64))
+    assert not s[0].any() and not s[:, 0].any()
+
+
+def test_flip():
+    img = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert np.array_equal(orc.flip_h(img), img[:, ::-1])
