@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- NuboFaceDetector Haar hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): NuboFaceDetector, one 1920x1080 BGR stream per
+GPU, full-resolution mode (width-to-process = 1920), scaleFactor 1.1, minNeighbors 3,
+minSize (96,54): 25 scales, <= 355 162 windows per frame.  A "step" is one pass of
+the hot path (resize/gray -> equalizeHist -> integral -> cascade -> groupRectangles
+-> track_faces) over one batch of F consecutive frames of the stream, frames already
+resident in HBM.  N > 1: one process per GPU, one stream per rank (streams are the
+independent units), no data-path collective; one RCCL all_gather of the fixed-size
+box table per step (the result gather).  value = frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "nubomedia-vca_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MAX_BOXES = 64
+
+
+def algorithmic_bytes(W, H, w, h, n_boxes=0):
+    """SURVEY.md 8d, per frame, split by kernel group."""
+    gray = 3 * W * H + w * h                           # BGR in, gray out
+    integral = w * h + 12 * (w + 1) * (h + 1)          # gray in, sum i32 + sqsum 8 B out
+    cascade = 12 * (w + 1) * (h + 1) + 16 * n_boxes    # integral pair read once, boxes out
+    return {"gray_resize_hist": gray, "integral": integral, "cascade_eval": cascade,
+            "total": gray + integral + cascade}
+
+
+def cpu_baseline(xml, frames_np, params, budget_s=12.0, max_frames=48):
+    """The CPU oracle (a restatement of the reference's OpenCV-2.4 path, NOT OpenCV itself)
+    timed on this box's host cores, 1 thread, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    oc = orc.parse_cascade_xml(xml)
+    s = orc.FaceStream(oc, width_to_process=params["width_to_process"], scale_factor_pct=params["multi_scale_factor"])
+    s.process(frames_np[0])                    # warm caches / page in
+    s = orc.FaceStream(oc, width_to_process=params["width_to_process"], scale_factor_pct=params["multi_scale_factor"])
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_frames and (time.perf_counter() - t0) < budget_s:
+        s.process(frames_np[n % len(frames_np)])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 1080p full-res workload, %.1f s, single thread; CPU restatement of the "
+                      "reference's OpenCV-2.4 path (OpenCV itself is not available offline)" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width-to-process", type=int, default=0, help="0 = full resolution (benchmark mode)")
+    ap.add_argument("--scale-factor-pct", type=int, default=10)
+    ap.add_argument("--content", default="natural", choices=["natural", "noise", "gradient"])
+    ap.add_argument("--faces", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from nubovca import capi, synth
+    W, H, F = args.width, args.height, args.frames_per_step
+    w2p = args.width_to_process or W
+    xml = synth.synthetic_cascade_xml()
+    ctx = capi.Context(local_rank)
+    casc = ctx.load_cascade_xml(xml)
+    props = {"width_to_process": w2p, "multi_scale_factor": args.scale_factor_pct}
+    stream = capi.FaceStream(ctx, casc, **props)
+    scale = W // w2p
+    w, h = int(np.rint(W / scale)), int(np.rint(H / scale))
+
+    # F consecutive synthetic frames of this rank's stream (stream id = rank), faces drifting 8 px/frame
+    base_faces = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)][:args.faces]
+    sx, sy = W / 1920.0, H / 1080.0
+    frames_np = []
+    for i in range(F):
+        faces = [(int((x + 8 * i) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in base_faces]
+        frames_np.append(synth.make_bgr(W, H, synth.frame_seed(rank, i), args.content, faces))
+    if args.host_frames:
+        frames = [capi.make_frame(f) for f in frames_np]
+        keep = frames_np
+    else:
+        keep = [torch.from_numpy(f).to(dev) for f in frames_np]
+        frames = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
+    torch.cuda.synchronize()
+    streams = [stream] * F
+    gather_in = torch.zeros((F, 1 + 4 * MAX_BOXES), dtype=torch.int32, device=dev)
+    gather_out = torch.zeros((world * F, 1 + 4 * MAX_BOXES), dtype=torch.int32, device=dev) if world > 1 else None
+    host_tab = np.zeros((F, 1 + 4 * MAX_BOXES), np.int32)
+
+    def step():
+        res = ctx.face_batch_process(streams, frames, cap=MAX_BOXES)
+        if world > 1:           # result gather (the only collective): fixed-size box table per stream tick
+            host_tab[:] = 0
+            for i, (b, _) in enumerate(res):
+                host_tab[i, 0] = len(b)
+                host_tab[i, 1:1 + 4 * len(b)] = b.reshape(-1)
+            gather_in.copy_(torch.from_numpy(host_tab))
+            dist.all_gather_into_tensor(gather_out, gather_in)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    n_boxes = float(np.mean([len(b) for b, _ in res])) if args.warmup else 0.0
+    ctx.enable_kernel_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ktimes = ctx.kernel_timing()
+    ctx.enable_kernel_timing(False)
+    n_boxes = float(np.mean([len(b) for b, _ in res]))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = world * F * args.steps
+        fps = total_frames / dt
+        ab = algorithmic_bytes(W, H, w, h, n_boxes)
+        groups = {"gray_resize_hist": ["gray_resize_hist"], "equalize_lut": ["equalize_lut"],
+                  "integral": ["integral_colsum", "integral_bandscan", "integral_rows"], "cascade_eval": ["cascade_eval"]}
+        kern = {}
+        for gname, members in groups.items():
+            ms = sum(ktimes.get(m, (0.0, 0))[0] for m in members)
+            launches = max([ktimes.get(m, (0.0, 0))[1] for m in members] + [0])
+            if launches:
+                per_launch_ms = ms / launches
+                bytes_per_launch = ab.get(gname, 0) * F
+                kern[gname] = {"ms_per_launch": per_launch_ms, "launches": launches,
+                               "alg_bytes_per_launch": bytes_per_launch,
+                               "achieved_GBs": bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0}
+        dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if dom and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = None
+        if dom:
+            a = kern[dom]["achieved_GBs"]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": a / HBM_PEAK_GBS, "traffic": traffic,
+                        "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
+                        "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
+                        "kernels": kern}
+        out = {
+            "metric": "1080p frames/sec/node (NuboFaceDetector); achieved HBM GB/s vs peak",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i32 rect sums / f32 products / f64 stage sums (u8 pixels)",
+            "data": "synthetic (%s field + %d pasted templates; seeded synthetic stump cascade shaped like "
+                    "haarcascade_frontalface_alt: 22 stages, 2135 stumps)" % (args.content, args.faces),
+            "config": {"workload": "NuboFaceDetector %dx%d single stream per GPU, working image %dx%d, scaleFactor %.2f, "
+                                   "minNeighbors 3, minSize (w/20,h/20)" % (W, H, w, h, 1 + args.scale_factor_pct / 100.0),
+                       "frames_per_step": F, "streams": world, "frames_resident": "host" if args.host_frames else "hbm",
+                       "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(xml, frames_np, props)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+/*
+ * nubovca.h -- C ABI of libnubovca_hip: the MI355X (gfx950) implementation of
+ * NUBOMEDIA-VCA's per-frame Haar detection hot path.
+ *
+ * Every entry point replaces a call the reference makes into OpenCV 2.4 (or a
+ * static function of the reference's GStreamer elements); the reference site
+ * each one replaces is cited as file:line relative to the reference tree, with
+ *   FACE/ = modules/nubo_face/nubo-face-detector/src/gst-plugins/
+ *   TRK/  = modules/nubo_tracker/nubo-tracker/src/gst-plugins/
+ *   EYE/ NOSE/ MOUTH/ EAR/ analogous.
+ *
+ * Conventions: plain C types only; opaque handles; the caller owns all frame
+ * memory; the library owns device state.  Every function returns an int status
+ * (NVCA_OK == 0, < 0 error) and never throws.  A handle may be used by one
+ * thread at a time; distinct contexts may be used concurrently.  There is no
+ * CPU fallback: without a HIP device nvca_ctx_create fails.
+ */
+#ifndef NUBOVCA_H
+#define NUBOVCA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVCA_OK              0
+#define NVCA_ERR_ARG        -1   /* bad argument                                   */
+#define NVCA_ERR_NO_DEVICE  -2   /* no HIP device / device id out of range         */
+#define NVCA_ERR_HIP        -3   /* a HIP runtime call failed (see nvca_last_error)*/
+#define NVCA_ERR_IO         -4   /* cascade file unreadable                        */
+#define NVCA_ERR_PARSE      -5   /* cascade XML malformed                          */
+#define NVCA_ERR_UNSUPPORTED -6  /* tilted / tree-structured cascade               */
+#define NVCA_ERR_OVERFLOW   -7   /* more raw candidates than the context's cap     */
+#define NVCA_ERR_NOMEM      -8
+
+/* where a buffer handed to the library lives */
+#define NVCA_MEM_HOST   0
+#define NVCA_MEM_DEVICE 1
+
+/* detectMultiScale flags -- values of OpenCV's CV_HAAR_* */
+#define NVCA_HAAR_DO_CANNY_PRUNING    1   /* accepted, ignored (never set by the reference) */
+#define NVCA_HAAR_SCALE_IMAGE         2
+#define NVCA_HAAR_FIND_BIGGEST_OBJECT 4
+#define NVCA_HAAR_DO_ROUGH_SEARCH     8
+
+/* feature-sum accumulation policy (OpenCV build variant) */
+#define NVCA_SUM_F32PAIR 0   /* SSE2 build (distro default): 2-rect stages add in f32 */
+#define NVCA_SUM_F64     1   /* plain C build                                          */
+
+typedef struct nvca_ctx nvca_ctx;
+typedef struct nvca_cascade nvca_cascade;
+typedef struct nvca_face_stream nvca_face_stream;
+typedef struct nvca_tracker nvca_tracker;
+
+typedef struct nvca_rect { int x, y, w, h; } nvca_rect;
+
+typedef struct nvca_frame {
+    const void *data;     /* packed rows, BGR (3 B/px) or BGRA (4 B/px)              */
+    int width, height;
+    int stride;           /* bytes per row; the reference assumes align4(width*bpp),
+                             FACE/kmsfacedetect.cpp:300-305                          */
+    int mem;              /* NVCA_MEM_HOST or NVCA_MEM_DEVICE                        */
+    uint64_t pts;
+} nvca_frame;
+
+/* ---- context ----------------------------------------------------------- */
+int  nvca_ctx_create(int device_id, nvca_ctx **out);
+void nvca_ctx_destroy(nvca_ctx *ctx);
+/* text of the last error on this context (never NULL) */
+const char *nvca_last_error(const nvca_ctx *ctx);
+const char *nvca_version(void);
+/* raw-candidate capacity per frame (default 16384); more -> NVCA_ERR_OVERFLOW */
+int  nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap);
+int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
+/* block until everything queued on the context's HIP stream has finished */
+int  nvca_ctx_synchronize(nvca_ctx *ctx);
+/* the hipStream_t the context launches on (for interop / profiling) */
+void *nvca_ctx_stream(nvca_ctx *ctx);
+
+/* Per-kernel timing with HIP events on the context's stream.  While enabled,
+ * every kernel launch is bracketed by events; nvca_ctx_kernel_timing drains them. */
+#define NVCA_K_GRAY      0  /* resize + BGR2GRAY + histogram   */
+#define NVCA_K_LUT       1  /* equalizeHist LUT                */
+#define NVCA_K_COLSUM    2  /* integral: band column sums      */
+#define NVCA_K_BANDSCAN  3  /* integral: scan over bands       */
+#define NVCA_K_INTEGRAL  4  /* integral: row scan + write      */
+#define NVCA_K_CASCADE   5  /* cascade evaluator               */
+#define NVCA_K_GROUP     6  /* candidate sort + groupRectangles*/
+#define NVCA_K_TRACKER   7  /* tracker pixel pass + labelling  */
+#define NVCA_K_RESIZE1   8  /* 8UC1 resize (pyramid / parts)   */
+#define NVCA_K_COUNT     9
+int  nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on);
+/* total_ms[NVCA_K_COUNT], launches[NVCA_K_COUNT]; resets the accumulators */
+int  nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches);
+const char *nvca_kernel_name(int k);
+
+/* ---- cascade: replaces cv::CascadeClassifier::load ---------------------
+ * FACE/kmsfacedetect.cpp:162-177 (HAAR_CONF_FILE :40), EYE/kmseyedetect.cpp:27-29,
+ * NOSE/kmsnosedetect.cpp:31-32, MOUTH/kmsmouthdetect.cpp:37-38, EAR/kmseardetect.cpp:29-31.
+ * Old-format ("opencv-haar-classifier") XML only, stump or tree weak classifiers,
+ * upright features. */
+int  nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out);
+int  nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out);
+void nvca_cascade_free(nvca_cascade *c);
+/* window size, stage count, weak-classifier count (any pointer may be NULL) */
+int  nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stages, int *n_weak);
+/* flat dump for cross-checking the loader: arrays sized by nvca_cascade_info;
+ * rects[n_weak*12] (3 rects x,y,w,h), weights[n_weak*3], thr/left_val/right_val[n_weak],
+ * stage_sizes/stage_thr[n_stages] (stump cascades only) */
+int  nvca_cascade_dump(const nvca_cascade *c, int *rects, float *weights, float *thr,
+                       float *left_val, float *right_val, int *stage_sizes, float *stage_thr);
+
+/* ---- imgproc primitives (each = one cv:: call of the reference) -------- */
+/* cv::cvtColor(CV_BGR2GRAY) FACE/kmsfacedetect.cpp:806, TRK/gstnubotracker.cpp:356 (channels 4) */
+int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int channels,
+                  int mem, void *dst_gray, int dst_stride);
+/* cv::resize(INTER_LINEAR) FACE/kmsfacedetect.cpp:805 (3 ch), EYE/kmseyedetect.cpp:956,963 (1 ch) */
+int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstride, int channels,
+                       int mem, void *dst, int dw, int dh, int dstride);
+/* cv::equalizeHist FACE/kmsfacedetect.cpp:807 */
+int nvca_equalize_hist(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
+                       void *dst_gray, int dst_stride);
+/* cv::integral as used inside detectMultiScale: sum int32 and sqsum float64,
+ * both dense (h+1)*(w+1) */
+int nvca_integral(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
+                  int32_t *sum, double *sqsum);
+
+/* ---- detectMultiScale ---------------------------------------------------
+ * cv::CascadeClassifier::detectMultiScale(gray, objects, scaleFactor, minNeighbors,
+ * flags, minSize, maxSize) -- FACE/kmsfacedetect.cpp:809-811 and the sibling call
+ * sites listed in SURVEY.md Appendix B.  max_w/max_h == 0 -> image size.
+ * Objects are written in OpenCV's serial order; *n_out may exceed cap (then only
+ * cap are written). */
+int nvca_detect_multiscale(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray,
+                           int w, int h, int stride, int mem, double scale_factor,
+                           int min_neighbors, int flags, int min_w, int min_h, int max_w,
+                           int max_h, nvca_rect *out, int cap, int *n_out);
+/* raw candidates before groupRectangles, canonical (scale, y, x) order; not
+ * defined for FIND_BIGGEST_OBJECT */
+int nvca_detect_raw(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray, int w, int h,
+                    int stride, int mem, double scale_factor, int flags, int min_w, int min_h,
+                    int max_w, int max_h, nvca_rect *out, int cap, int *n_out);
+/* cv::groupRectangles(rects, groupThreshold, eps) on the device; in place */
+int nvca_group_rectangles(nvca_ctx *ctx, nvca_rect *rects, int n, int group_threshold, double eps,
+                          int *n_out);
+
+/* ---- NuboFaceDetector stream -------------------------------------------
+ * One handle == one element instance == one media stream.  Replaces
+ * kms_face_detect_conf_images + kms_face_detect_process_frame + the box scaling
+ * of kms_face_send_event (FACE/kmsfacedetect.cpp:282-306, 757-853, 190-211),
+ * with Faces::track_faces (FACE/Faces.cpp:78-153) kept on the host. */
+typedef struct nvca_face_params {
+    int width_to_process;      /* "width-to-process", default 160  (:26)            */
+    int process_x_every_4;     /* "process-x-every-4-frames", 4    (:24)            */
+    int scale_factor_pct;      /* "multi-scale-factor", 25 -> 1.25 (:25,142)        */
+    int track_threshold;       /* 40 (:33)                                          */
+    int euclidean_threshold;   /* "euclidean-distance" 8 (:32) (unused by track_faces)*/
+    int area_threshold;        /* 500 (:34) (unused by track_faces)                 */
+    int min_neighbors;         /* 3 (:810)                                          */
+    int detect_event;          /* "detect-event" 0 (:722): 1 = analyse only after
+                                  nvca_face_stream_motion_event()                   */
+} nvca_face_params;
+void nvca_face_params_default(nvca_face_params *p);
+int  nvca_face_stream_create(nvca_ctx *ctx, const nvca_cascade *cascade,
+                             const nvca_face_params *params, nvca_face_stream **out);
+void nvca_face_stream_destroy(nvca_face_stream *s);
+int  nvca_face_stream_set_params(nvca_face_stream *s, const nvca_face_params *params);
+/* a "motion" custom event arrived (FACE/kmsfacedetect.cpp:680-755): analyse the
+ * next NUM_FRAMES_TO_PROCESS (10) frames */
+int  nvca_face_stream_motion_event(nvca_face_stream *s);
+/* One kms_face_detect_transform_frame_ip (FACE/kmsfacedetect.cpp:857-898): boxes
+ * in original-frame pixels exactly as kms_face_send_event emits them; ids (may
+ * be NULL) are the Faces ids. */
+int  nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca_rect *out,
+                              int *ids, int cap, int *n_out);
+/* Batched frontend: frame i belongs to streams[i]; a stream may appear several
+ * times (consecutive frames, in order).  All analysed frames go through one
+ * launch set per distinct geometry.  out is [n][cap], ids (may be NULL) likewise. */
+int  nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams,
+                             const nvca_frame *frames, nvca_rect *out, int *ids, int cap,
+                             int *n_out);
+
+/* ---- NuboTracker stream -------------------------------------------------
+ * Replaces gst_nubo_tracker_img_conf + gst_nubo_tracker_process
+ * (TRK/gstnubotracker.cpp:202-237, 339-421): BGRA -> gray, absdiff, threshold,
+ * updateMotionHistory, segmentMotion, __join_objects.  img_prev is per stream
+ * (the reference's process-global Mat, :108, is a bug). */
+typedef struct nvca_tracker_params {
+    int    threshold;     /* "set_threshold" 20  (:23) */
+    int    min_area;      /* "set_min_area"  50  (:24) */
+    long   max_area;      /* "set_max_area"  30000 (:25) */
+    int    distance;      /* "set_distance"  35  (:26) */
+    double mhi_duration;  /* MHI_DURATION 0.2 (:28) */
+    double seg_thresh;    /* SEGMENTATION 32  (:31) */
+} nvca_tracker_params;
+void nvca_tracker_params_default(nvca_tracker_params *p);
+int  nvca_tracker_create(nvca_ctx *ctx, const nvca_tracker_params *params, nvca_tracker **out);
+void nvca_tracker_destroy(nvca_tracker *t);
+int  nvca_tracker_set_params(nvca_tracker *t, const nvca_tracker_params *params);
+/* timestamp_ms: the reference passes 1000*clock()/CLOCKS_PER_SEC (:349) */
+int  nvca_tracker_process(nvca_tracker *t, const nvca_frame *frame_bgra, double timestamp_ms,
+                          nvca_rect *out, int cap, int *n_out);
+int  nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *trackers,
+                                const nvca_frame *frames, const double *timestamps_ms,
+                                nvca_rect *out, int cap, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUBOVCA_H */

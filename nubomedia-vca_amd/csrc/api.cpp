@@ -1,0 +1,833 @@
+// api.cpp -- C ABI of libnubovca_hip (include/nubovca.h): context, workspace,
+// launch sequencing, the stream objects that mirror the reference's elements.
+#include "nvca_internal.h"
+#include "plan.h"
+#include "host_logic.h"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <climits>
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+
+using namespace nvca;
+
+// =========================================================================
+// buffers, timing
+// =========================================================================
+namespace nvca {
+
+int DevBuf::ensure(size_t n)
+{
+    if (n <= bytes) return 0;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; bytes = 0; }
+    size_t want = n + n / 4;                                  // head-room: batches grow
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; e = hipMalloc(&p, n); want = n; }
+    if (e != hipSuccess) { p = nullptr; bytes = 0; return (int)e; }
+    bytes = want;
+    return 0;
+}
+void DevBuf::release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+int PinnedBuf::ensure(size_t n)
+{
+    if (n <= bytes) return 0;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return (int)e; }
+    bytes = n;
+    return 0;
+}
+void PinnedBuf::release() { if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; } }
+
+TimedLaunch::TimedLaunch(nvca_ctx *c, int kind) : ctx(c), k(kind)
+{
+    KernelTimer &t = ctx->timer;
+    if (!t.on) return;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!t.pool.empty()) { e = t.pool.back(); t.pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    a = get(); b = get();
+    (void)hipEventRecord(a, ctx->stream);
+}
+TimedLaunch::~TimedLaunch()
+{
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timer.pending.push_back(KernelTimer::Ev{a, b, k});
+}
+static void drain_timer(nvca_ctx *ctx)     // stream must be idle
+{
+    KernelTimer &t = ctx->timer;
+    for (auto &e : t.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { t.total_ms[e.k] += ms; t.launches[e.k]++; }
+        t.pool.push_back(e.a); t.pool.push_back(e.b);
+    }
+    t.pending.clear();
+}
+
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cv_round(double v)
+{
+    if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;   // _mm_cvtsd_si32 on overflow / inf
+    return (int)lrint(v);
+}
+
+struct Workspace {
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux;
+    PinnedBuf h_hits, h_srcptrs;
+    void release_all()
+    {
+        gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
+        sqsum.release(); hits.release(); srcptrs.release(); staging.release(); aux.release();
+        h_hits.release(); h_srcptrs.release();
+    }
+};
+
+// one cached geometry: source frame -> working image -> scan tables
+struct GeomPlan {
+    ResizeTab tab;
+    DevBuf d_xofs, d_yofs, d_ialpha, d_ibeta;
+    DetectPlan det;
+    PreGeom g;
+    bool has_det = false;
+    ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); }
+};
+
+DetectPlan::~DetectPlan()
+{
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release();
+}
+
+int DetectPlan::upload(nvca_ctx *ctx)
+{
+    struct Item { DevBuf *d; const void *h; size_t n; } items[] = {
+        {&d_scales, scales.data(), scales.size() * sizeof(ScaleRec)},
+        {&d_stumps, stumps.data(), stumps.size() * sizeof(StumpRec)},
+        {&d_stages, stages.data(), stages.size() * sizeof(StageRec)},
+        {&d_strips, strips.data(), strips.size() * sizeof(StripRec)},
+        {&d_pos, pos.data(), pos.size() * sizeof(int)},
+    };
+    for (auto &it : items) {
+        if (it.n == 0) continue;
+        if (it.d->ensure(it.n)) { ctx->set_error("hipMalloc failed for plan tables"); return NVCA_ERR_NOMEM; }
+        NVCA_HIP_CHECK(ctx, hipMemcpy(it.d->p, it.h, it.n, hipMemcpyHostToDevice));
+    }
+    return NVCA_OK;
+}
+
+static void make_geom(PreGeom &g, int sw, int sh, int sstride, int cn, int w, int h)
+{
+    memset(&g, 0, sizeof(g));
+    g.sw = sw; g.sh = sh; g.sstride = sstride; g.cn = cn;
+    g.w = w; g.h = h;
+    g.gpitch = (int)round_up(w, 64);
+    g.spitch = (int)round_up(w + 1, 8);
+    g.nbands = (h + kIntegralBand - 1) / kIntegralBand;
+    g.gray_slot = round_up((size_t)g.gpitch * h, 256);
+    g.sum_slot = round_up((size_t)g.spitch * (h + 1), 64);
+    g.band_slot = (size_t)g.nbands * round_up(w, 8);
+}
+
+static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
+{
+    Workspace &ws = *ctx->ws;
+    int e = 0;
+    e |= ws.gray.ensure(g.gray_slot * batch + 64);
+    e |= ws.hist.ensure((size_t)batch * 256 * sizeof(unsigned));
+    e |= ws.lut.ensure((size_t)batch * 256);
+    e |= ws.bandsum.ensure(g.band_slot * batch * sizeof(unsigned));
+    e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
+    e |= ws.sum.ensure(g.sum_slot * batch * sizeof(int));
+    e |= ws.sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
+    e |= ws.hits.ensure(((size_t)ctx->hit_cap * batch + 1) * sizeof(unsigned long long));
+    e |= ws.srcptrs.ensure((size_t)batch * sizeof(void *));
+    e |= ws.h_srcptrs.ensure((size_t)batch * sizeof(void *));
+    e |= ws.h_hits.ensure(((size_t)ctx->hit_cap * batch + 1) * sizeof(unsigned long long));
+    if (e) { ctx->set_error("device/pinned allocation failed for the workspace"); return NVCA_ERR_NOMEM; }
+    return NVCA_OK;
+}
+
+static int upload_tab(nvca_ctx *ctx, GeomPlan &gp)
+{
+    const ResizeTab &t = gp.tab;
+    if (t.mode != 1) return NVCA_OK;
+    if (gp.d_xofs.ensure(t.xofs.size() * 4) || gp.d_yofs.ensure(t.yofs.size() * 4) ||
+        gp.d_ialpha.ensure(t.ialpha.size() * 2) || gp.d_ibeta.ensure(t.ibeta.size() * 2)) {
+        ctx->set_error("hipMalloc failed for resize tables"); return NVCA_ERR_NOMEM;
+    }
+    NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_xofs.p, t.xofs.data(), t.xofs.size() * 4, hipMemcpyHostToDevice));
+    NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_yofs.p, t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice));
+    NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_ialpha.p, t.ialpha.data(), t.ialpha.size() * 2, hipMemcpyHostToDevice));
+    NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_ibeta.p, t.ibeta.data(), t.ibeta.size() * 2, hipMemcpyHostToDevice));
+    return NVCA_OK;
+}
+
+// ---- launch sequences ----------------------------------------------------
+
+// integral planes for `batch` slots of ws.gray (lut == nullptr -> identity)
+static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int batch)
+{
+    Workspace &ws = *ctx->ws;
+    { TimedLaunch t(ctx, NVCA_K_COLSUM);
+      launch_colsum(ctx->stream, ws.gray.as<uint8_t>(), lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
+    { TimedLaunch t(ctx, NVCA_K_BANDSCAN);
+      launch_bandscan(ctx->stream, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
+    { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
+      launch_integral(ctx->stream, ws.gray.as<uint8_t>(), lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(),
+                      ws.sum.as<int>(), ws.sqsum.as<unsigned long long>(), batch); }
+}
+
+// cascade scan over the integral planes; fills raw[b] (canonical scale,y,x order)
+static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::vector<nvca_rect>> &raw)
+{
+    Workspace &ws = *ctx->ws;
+    DetectPlan &dp = gp.det;
+    raw.assign(batch, {});
+    const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hits.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (!dp.strips.empty()) {
+        CascadeArgs a;
+        a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
+        a.sum_slot = gp.g.sum_slot; a.spitch = gp.g.spitch;
+        a.scales = dp.d_scales.as<ScaleRec>(); a.stumps = dp.d_stumps.as<StumpRec>();
+        a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
+        a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
+        TimedLaunch t(ctx, NVCA_K_CASCADE);
+        launch_cascade_sc(ctx->stream, a, (int)dp.strips.size(), batch);
+    }
+    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    // one D2H covers the count and (almost always) every candidate
+    unsigned long long *hh = ws.h_hits.as<unsigned long long>();
+    const size_t first = std::min<size_t>(cap, 2048);
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh, ws.hits.p, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long total = hh[0];
+    if (total > cap) {
+        drain_timer(ctx);
+        ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
+        return NVCA_ERR_OVERFLOW;
+    }
+    if (total > first) {
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ws.hits.as<unsigned long long>() + 1 + first,
+                                           (total - first) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    drain_timer(ctx);
+    std::sort(hh + 1, hh + 1 + total);
+    for (unsigned long long i = 0; i < total; i++) {
+        const unsigned long long e = hh[1 + i];
+        const int slot = (int)(e >> 32);
+        const unsigned key = (unsigned)e;
+        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+        const ScaleRec &sc = dp.scales[s];
+        raw[slot].push_back(nvca_rect{dp.pos[sc.xpos_off + ix], dp.pos[sc.ypos_off + iy], sc.winw, sc.winh});
+    }
+    return NVCA_OK;
+}
+
+static void group_all(std::vector<std::vector<nvca_rect>> &raw, int min_neighbors)
+{
+    const double GROUP_EPS = 0.2;
+    for (auto &r : raw)
+        if (min_neighbors != 0) group_rectangles(r, std::max(min_neighbors, 1), GROUP_EPS);
+}
+
+// copy a host/device 2-D byte image into device memory with a pitch
+static int stage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
+                    size_t height, int mem)
+{
+    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
+                                         mem == NVCA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                         ctx->stream));
+    return NVCA_OK;
+}
+static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
+                      size_t height, int mem)
+{
+    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
+                                         mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                         ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timer(ctx);
+    return NVCA_OK;
+}
+
+static GeomPlan *find_plan(nvca_ctx *ctx, const std::string &key)
+{
+    auto it = ctx->plans.find(key);
+    return it == ctx->plans.end() ? nullptr : it->second.get();
+}
+
+// plan for "BGR frame -> working image -> scale-cascade scan"
+static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, int stride, int cn, int cols, int rows,
+                         double sf, int minw, int minh, int maxw, int maxh, GeomPlan **out)
+{
+    char key[256];
+    snprintf(key, sizeof(key), "F|%llu|%d|%d|%d|%d|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)casc->c.uid, W, H, stride,
+             cn, cols, rows, sf, minw, minh, maxw, maxh);
+    if (GeomPlan *gp = find_plan(ctx, key)) { *out = gp; return NVCA_OK; }
+    std::unique_ptr<GeomPlan> gp(new GeomPlan());
+    make_geom(gp->g, W, H, stride, cn, cols, rows);
+    build_resize_tab(W, H, cols, rows, gp->tab);
+    int rc = upload_tab(ctx, *gp);
+    if (rc) return rc;
+    std::string err;
+    rc = gp->det.build_scale_cascade(casc->c, cols, rows, gp->g.spitch, sf, minw, minh, maxw, maxh, err);
+    if (rc) { ctx->set_error(err); return rc; }
+    if (gp->det.scales.size() > 63) { ctx->set_error("too many scales"); return NVCA_ERR_ARG; }
+    rc = gp->det.upload(ctx);
+    if (rc) return rc;
+    gp->has_det = true;
+    *out = gp.get();
+    ctx->plans[key] = std::move(gp);
+    return NVCA_OK;
+}
+
+} // namespace nvca
+
+// =========================================================================
+// context
+// =========================================================================
+nvca_ctx::nvca_ctx() {}
+nvca_ctx::~nvca_ctx()
+{
+    plans.clear();
+    if (ws) ws->release_all();
+    if (identity_lut) (void)hipFree(identity_lut);
+    for (auto e : timer.pool) (void)hipEventDestroy(e);
+    for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+extern "C" {
+
+const char *nvca_version(void) { return "nubovca-hip 0.1 (gfx950)"; }
+
+int nvca_ctx_create(int device_id, nvca_ctx **out)
+{
+    if (!out) return NVCA_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NVCA_ERR_NO_DEVICE;   // no CPU fallback
+    if (device_id < 0 || device_id >= n) return NVCA_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return NVCA_ERR_HIP;
+    nvca_ctx *ctx = new (std::nothrow) nvca_ctx();
+    if (!ctx) return NVCA_ERR_NOMEM;
+    ctx->device = device_id;
+    ctx->ws.reset(new Workspace());
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NVCA_ERR_HIP; }
+    *out = ctx;
+    return NVCA_OK;
+}
+
+void nvca_ctx_destroy(nvca_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+const char *nvca_last_error(const nvca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap)
+{
+    if (!ctx || cap < 1 || cap > (1 << 22)) return NVCA_ERR_ARG;
+    ctx->hit_cap = cap;
+    return NVCA_OK;
+}
+int nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy)
+{
+    if (!ctx || (policy != NVCA_SUM_F32PAIR && policy != NVCA_SUM_F64)) return NVCA_ERR_ARG;
+    ctx->policy = policy;
+    return NVCA_OK;
+}
+int nvca_ctx_synchronize(nvca_ctx *ctx)
+{
+    if (!ctx) return NVCA_ERR_ARG;
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVCA_OK;
+}
+void *nvca_ctx_stream(nvca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
+{
+    if (!ctx) return NVCA_ERR_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_timer(ctx);
+    ctx->timer.on = on != 0;
+    for (int k = 0; k < NVCA_K_COUNT; k++) { ctx->timer.total_ms[k] = 0; ctx->timer.launches[k] = 0; }
+    return NVCA_OK;
+}
+int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
+{
+    if (!ctx) return NVCA_ERR_ARG;
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timer(ctx);
+    for (int k = 0; k < NVCA_K_COUNT; k++) {
+        if (total_ms) total_ms[k] = ctx->timer.total_ms[k];
+        if (launches) launches[k] = ctx->timer.launches[k];
+        ctx->timer.total_ms[k] = 0; ctx->timer.launches[k] = 0;
+    }
+    return NVCA_OK;
+}
+const char *nvca_kernel_name(int k)
+{
+    static const char *names[NVCA_K_COUNT] = {"gray_resize_hist", "equalize_lut", "integral_colsum", "integral_bandscan",
+                                              "integral_rows", "cascade_eval", "group_rects", "tracker", "resize_gray"};
+    return (k >= 0 && k < NVCA_K_COUNT) ? names[k] : "?";
+}
+
+// =========================================================================
+// cascade
+// =========================================================================
+int nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out)
+{
+    if (!ctx || !xml || len <= 0 || !out) return NVCA_ERR_ARG;
+    *out = nullptr;
+    std::unique_ptr<nvca_cascade> c(new nvca_cascade());
+    std::string err;
+    int rc = parse_cascade_xml(xml, (size_t)len, c->c, err);
+    if (rc) { ctx->set_error("cascade XML: " + err); return rc; }
+    c->ctx = ctx;
+    c->c.uid = ctx->next_uid++;
+    *out = c.release();
+    return NVCA_OK;
+}
+
+int nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out)
+{
+    if (!ctx || !path || !out) return NVCA_ERR_ARG;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { ctx->set_error(std::string("cannot open cascade file ") + path); return NVCA_ERR_IO; }
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string s = ss.str();
+    if (s.empty()) { ctx->set_error(std::string("empty cascade file ") + path); return NVCA_ERR_IO; }
+    return nvca_cascade_load_mem(ctx, s.data(), (int64_t)s.size(), out);
+}
+
+void nvca_cascade_free(nvca_cascade *c)
+{
+    if (!c) return;
+    // drop cached plans that reference this cascade
+    if (c->ctx) {
+        char pre[64];
+        for (auto it = c->ctx->plans.begin(); it != c->ctx->plans.end();) {
+            const std::string &k = it->first;
+            snprintf(pre, sizeof(pre), "|%llu|", (unsigned long long)c->c.uid);
+            if (k.size() > 1 && k.compare(1, strlen(pre), pre) == 0) { (void)hipDeviceSynchronize(); it = c->ctx->plans.erase(it); }
+            else ++it;
+        }
+    }
+    delete c;
+}
+
+int nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stages, int *n_weak)
+{
+    if (!c) return NVCA_ERR_ARG;
+    if (win_w) *win_w = c->c.ow;
+    if (win_h) *win_h = c->c.oh;
+    if (n_stages) *n_stages = (int)c->c.stages.size();
+    if (n_weak) *n_weak = (int)c->c.cls.size();
+    return NVCA_OK;
+}
+
+int nvca_cascade_dump(const nvca_cascade *c, int *rects, float *weights, float *thr, float *left_val,
+                      float *right_val, int *stage_sizes, float *stage_thr)
+{
+    if (!c) return NVCA_ERR_ARG;
+    if (!c->c.stump_based) return NVCA_ERR_UNSUPPORTED;
+    for (size_t i = 0; i < c->c.cls.size(); i++) {
+        const HaarNode &n = c->c.nodes[c->c.cls[i].first_node];
+        if (rects) memcpy(rects + i * 12, n.rect, sizeof(int) * 12);
+        if (weights) memcpy(weights + i * 3, n.weight, sizeof(float) * 3);
+        if (thr) thr[i] = n.threshold;
+        if (left_val) left_val[i] = c->c.alpha[c->c.cls[i].first_alpha];
+        if (right_val) right_val[i] = c->c.alpha[c->c.cls[i].first_alpha + 1];
+    }
+    for (size_t s = 0; s < c->c.stages.size(); s++) {
+        if (stage_sizes) stage_sizes[s] = c->c.stages[s].ncls;
+        if (stage_thr) stage_thr[s] = c->c.stages[s].threshold;
+    }
+    return NVCA_OK;
+}
+
+// =========================================================================
+// imgproc primitives
+// =========================================================================
+static int check_img(nvca_ctx *ctx, const void *p, int w, int h, int stride, int bpp, int mem)
+{
+    if (!ctx || !p || w <= 0 || h <= 0 || stride < w * bpp || (mem != NVCA_MEM_HOST && mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
+    return NVCA_OK;
+}
+
+// stage `n` source frames (host or device) and return device pointers in ws.srcptrs
+static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx, int n, int bpp)
+{
+    Workspace &ws = *ctx->ws;
+    if (ws.srcptrs.ensure((size_t)n * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)n * sizeof(void *))) {
+        ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
+    }
+    size_t need = 0;
+    for (int i = 0; i < n; i++) {
+        const nvca_frame &f = frames[idx ? idx[i] : i];
+        if (f.mem == NVCA_MEM_HOST) need += round_up((size_t)f.stride * f.height, 256);
+    }
+    if (need && ws.staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
+    const void **hp = ws.h_srcptrs.as<const void *>();
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        const nvca_frame &f = frames[idx ? idx[i] : i];
+        if (f.mem == NVCA_MEM_HOST) {
+            uint8_t *d = ws.staging.as<uint8_t>() + off;
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp,
+                                               hipMemcpyHostToDevice, ctx->stream));
+            hp[i] = d;
+            off += round_up((size_t)f.stride * f.height, 256);
+        } else
+            hp[i] = f.data;
+    }
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.srcptrs.p, hp, (size_t)n * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    return NVCA_OK;
+}
+
+static bool frames_aligned4(const nvca_frame *frames, const int *idx, int n)
+{
+    for (int i = 0; i < n; i++) {
+        const nvca_frame &f = frames[idx ? idx[i] : i];
+        if ((f.stride & 3) || (f.mem == NVCA_MEM_DEVICE && ((uintptr_t)f.data & 15))) return false;
+    }
+    return true;
+}
+
+int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int channels, int mem, void *dst, int dst_stride)
+{
+    if (channels != 3 && channels != 4) return NVCA_ERR_ARG;
+    int rc = check_img(ctx, src, w, h, stride, channels, mem);
+    if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    PreGeom g; make_geom(g, w, h, stride, channels, w, h);
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    nvca_frame f{src, w, h, stride, mem, 0};
+    if ((rc = stage_frames(ctx, &f, nullptr, 1, channels))) return rc;
+    { TimedLaunch t(ctx, NVCA_K_GRAY);
+      launch_gray(ctx->stream, ctx->ws->srcptrs.as<const uint8_t *>(), g, 0, nullptr, nullptr, nullptr, nullptr, w,
+                  ctx->ws->gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
+    return unstage_2d(ctx, dst, dst_stride, ctx->ws->gray.p, g.gpitch, w, h, mem);
+}
+
+int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstride, int channels, int mem, void *dst,
+                       int dw, int dh, int dstride)
+{
+    if (channels != 1) {
+        if (ctx) ctx->set_error("nvca_resize_linear: only the 8UC1 form is exposed; the 8UC3 form is fused with BGR2GRAY "
+                                "inside the face stream (FACE/kmsfacedetect.cpp:805-806)");
+        return NVCA_ERR_UNSUPPORTED;
+    }
+    int rc = check_img(ctx, src, sw, sh, sstride, 1, mem);
+    if (rc || !dst || dw <= 0 || dh <= 0 || dstride < dw) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    PreGeom gs; make_geom(gs, sw, sh, sstride, 1, sw, sh);
+    PreGeom gd; make_geom(gd, sw, sh, sstride, 1, dw, dh);
+    if ((rc = ensure_ws(ctx, gs, 1)) || (rc = ensure_ws(ctx, gd, 1))) return rc;
+    if (ws.aux.ensure(gd.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.gray.p, gs.gpitch, src, sstride, sw, sh, mem))) return rc;
+    GeomPlan gp; build_resize_tab(sw, sh, dw, dh, gp.tab);
+    if ((rc = upload_tab(ctx, gp))) return rc;
+    { TimedLaunch t(ctx, NVCA_K_RESIZE1);
+      launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), sw, sh, gs.gpitch, gp.tab.mode, gp.d_xofs.as<int>(),
+                     gp.d_ialpha.as<short>(), gp.d_yofs.as<int>(), gp.d_ibeta.as<short>(), gp.tab.xmax,
+                     ws.aux.as<uint8_t>(), dw, dh, gd.gpitch, nullptr); }
+    return unstage_2d(ctx, dst, dstride, ws.aux.p, gd.gpitch, dw, dh, mem);
+}
+
+int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
+{
+    int rc = check_img(ctx, src, w, h, stride, 1, mem);
+    if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    PreGeom g; make_geom(g, w, h, stride, 1, w, h);
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
+    { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.hist.as<unsigned>()); }
+    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1); }
+    launch_apply_lut(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.lut.as<uint8_t>(), ws.aux.as<uint8_t>(), g.gpitch);
+    return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
+}
+
+int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *sum, double *sqsum)
+{
+    int rc = check_img(ctx, src, w, h, stride, 1, mem);
+    if (rc || !sum) return NVCA_ERR_ARG;
+    if (mem != NVCA_MEM_HOST) { ctx->set_error("nvca_integral: host output only"); return NVCA_ERR_ARG; }
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    PreGeom g; make_geom(g, w, h, stride, 1, w, h);
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    run_integral(ctx, g, nullptr, 1);
+    rc = unstage_2d(ctx, sum, (size_t)(w + 1) * 4, ws.sum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+    if (rc) return rc;
+    if (sqsum) {
+        std::vector<unsigned long long> tmp((size_t)(w + 1) * (h + 1));
+        rc = unstage_2d(ctx, tmp.data(), (size_t)(w + 1) * 8, ws.sqsum.p, (size_t)g.spitch * 8, (size_t)(w + 1) * 8, h + 1, NVCA_MEM_HOST);
+        if (rc) return rc;
+        for (size_t i = 0; i < tmp.size(); i++) sqsum[i] = (double)tmp[i];
+    }
+    return NVCA_OK;
+}
+
+// =========================================================================
+// detectMultiScale
+// =========================================================================
+static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
+                       double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only,
+                       std::vector<nvca_rect> &out)
+{
+    int rc = check_img(ctx, gray, w, h, stride, 1, mem);
+    if (rc || !casc || !(sf > 1.0)) return NVCA_ERR_ARG;
+    if (flags & (NVCA_HAAR_SCALE_IMAGE | NVCA_HAAR_FIND_BIGGEST_OBJECT)) {
+        ctx->set_error("detectMultiScale: SCALE_IMAGE / FIND_BIGGEST_OBJECT variants are not implemented yet");
+        return NVCA_ERR_UNSUPPORTED;
+    }
+    (void)hipSetDevice(ctx->device);
+    GeomPlan *gp = nullptr;
+    if ((rc = get_face_plan(ctx, casc, w, h, stride, 1, w, h, sf, minw, minh, maxw, maxh, &gp))) return rc;
+    if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, gray, stride, w, h, mem))) return rc;
+    run_integral(ctx, gp->g, nullptr, 1);
+    std::vector<std::vector<nvca_rect>> raw;
+    if ((rc = run_cascade(ctx, *gp, 1, raw))) return rc;
+    if (!raw_only) group_all(raw, min_neighbors);
+    out.swap(raw[0]);
+    return NVCA_OK;
+}
+
+int nvca_detect_multiscale(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray, int w, int h, int stride,
+                           int mem, double scale_factor, int min_neighbors, int flags, int min_w, int min_h,
+                           int max_w, int max_h, nvca_rect *out, int cap, int *n_out)
+{
+    if (!n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    std::vector<nvca_rect> r;
+    int rc = detect_gray(ctx, cascade, gray, w, h, stride, mem, scale_factor, min_neighbors, flags, min_w, min_h, max_w,
+                         max_h, false, r);
+    if (rc) return rc;
+    *n_out = (int)r.size();
+    for (int i = 0; i < std::min<int>(cap, (int)r.size()); i++) out[i] = r[i];
+    return NVCA_OK;
+}
+
+int nvca_detect_raw(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray, int w, int h, int stride, int mem,
+                    double scale_factor, int flags, int min_w, int min_h, int max_w, int max_h, nvca_rect *out,
+                    int cap, int *n_out)
+{
+    if (!n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    if (flags & NVCA_HAAR_FIND_BIGGEST_OBJECT) return NVCA_ERR_ARG;
+    std::vector<nvca_rect> r;
+    int rc = detect_gray(ctx, cascade, gray, w, h, stride, mem, scale_factor, 0, flags, min_w, min_h, max_w, max_h, true, r);
+    if (rc) return rc;
+    *n_out = (int)r.size();
+    for (int i = 0; i < std::min<int>(cap, (int)r.size()); i++) out[i] = r[i];
+    return NVCA_OK;
+}
+
+int nvca_group_rectangles(nvca_ctx *ctx, nvca_rect *rects, int n, int group_threshold, double eps, int *n_out)
+{
+    if (!ctx || n < 0 || (n > 0 && !rects) || !n_out) return NVCA_ERR_ARG;
+    std::vector<nvca_rect> v(rects, rects + n);
+    group_rectangles(v, group_threshold, eps);
+    for (size_t i = 0; i < v.size(); i++) rects[i] = v[i];
+    *n_out = (int)v.size();
+    return NVCA_OK;
+}
+
+} // extern "C"
+
+// =========================================================================
+// NuboFaceDetector stream
+// =========================================================================
+struct nvca_face_stream {
+    nvca_ctx *ctx;
+    const nvca_cascade *cascade;
+    nvca_face_params p;
+    Faces faces;
+    int num_frame = 0, num_iter = 0, frames_with_no_detection = 0, num_frames_to_process = 0;
+    int pending_events = 0;
+};
+
+namespace {
+constexpr int kGOP = 4;                               // FACE/kmsfacedetect.cpp:28
+constexpr int kMaxNoDetection = 1;                    // :30
+constexpr int kNumFramesToProcess = 10;               // :23
+
+struct FrameWork {
+    bool analysed = false;
+    int cols = 0, rows = 0, norm_scale = 0;
+    std::vector<nvca_rect> det;
+};
+
+// the frame gating of kms_face_detect_process_frame (:794-803, :829-830); independent of detection results
+bool face_gate(nvca_face_stream *s)
+{
+    bool received = true;
+    if (s->p.detect_event) {                          // __receive_event :722-755
+        received = false;
+        if (s->pending_events > 0) { s->pending_events--; received = true; s->num_frames_to_process = kNumFramesToProcess; }
+    }
+    if (!received && s->num_frames_to_process <= 0) return false;     // early return: counters untouched
+    s->num_frame++; s->num_iter++;
+    bool run = false;
+    const int px = s->p.process_x_every_4;
+    if ((2 == px && (1 == s->num_frame % 2)) || ((2 != px) && (s->num_frame <= px))) {
+        s->num_frames_to_process--;
+        run = true;
+    }
+    if (kGOP == s->num_frame) s->num_frame = 0;
+    return run;
+}
+} // namespace
+
+extern "C" {
+
+void nvca_face_params_default(nvca_face_params *p)
+{
+    if (!p) return;
+    p->width_to_process = 160; p->process_x_every_4 = 4; p->scale_factor_pct = 25; p->track_threshold = 40;
+    p->euclidean_threshold = 8; p->area_threshold = 500; p->min_neighbors = 3; p->detect_event = 0;
+}
+
+int nvca_face_stream_create(nvca_ctx *ctx, const nvca_cascade *cascade, const nvca_face_params *params, nvca_face_stream **out)
+{
+    if (!ctx || !cascade || !out) return NVCA_ERR_ARG;
+    nvca_face_stream *s = new (std::nothrow) nvca_face_stream();
+    if (!s) return NVCA_ERR_NOMEM;
+    s->ctx = ctx; s->cascade = cascade;
+    if (params) s->p = *params; else nvca_face_params_default(&s->p);
+    *out = s;
+    return NVCA_OK;
+}
+void nvca_face_stream_destroy(nvca_face_stream *s) { delete s; }
+int nvca_face_stream_set_params(nvca_face_stream *s, const nvca_face_params *params)
+{
+    if (!s || !params) return NVCA_ERR_ARG;
+    s->p = *params;
+    return NVCA_OK;
+}
+int nvca_face_stream_motion_event(nvca_face_stream *s)
+{
+    if (!s) return NVCA_ERR_ARG;
+    s->pending_events++;
+    return NVCA_OK;
+}
+
+int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames,
+                            nvca_rect *out, int *ids, int cap, int *n_out)
+{
+    if (!ctx || n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::vector<FrameWork> work(n);
+    // ---- pass 1: geometry + gating, in frame order
+    for (int i = 0; i < n; i++) {
+        nvca_face_stream *s = streams[i];
+        const nvca_frame &f = frames[i];
+        if (!s || s->ctx != ctx || check_img(ctx, f.data, f.width, f.height, f.stride, 3, f.mem)) return NVCA_ERR_ARG;
+        if (s->p.width_to_process <= 0) { ctx->set_error("width-to-process must be > 0"); return NVCA_ERR_ARG; }
+        FrameWork &w = work[i];
+        // kms_face_detect_conf_images :304 -- INTEGER ratio kept in a float; kms_face_send_event :190
+        const float fscale = (float)(f.width / s->p.width_to_process);
+        w.norm_scale = f.width / s->p.width_to_process;
+        double scale = fscale;
+        w.rows = f.height; w.cols = f.width;                           // process_frame :770-783
+        if (cv_round(f.height / scale) > 0) w.rows = cv_round(f.height / scale); else scale = 1;
+        if (cv_round(f.width / scale) > 0) w.cols = cv_round(f.width / scale); else scale = 1;
+        w.analysed = face_gate(s);
+    }
+    // ---- pass 2: one launch set per distinct geometry
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n; i++) {
+        if (!work[i].analysed || done[i]) continue;
+        const nvca_face_stream *s0 = streams[i];
+        const nvca_frame &f0 = frames[i];
+        std::vector<int> idx;
+        for (int j = i; j < n; j++) {
+            const nvca_face_stream *sj = streams[j];
+            const nvca_frame &fj = frames[j];
+            if (work[j].analysed && !done[j] && sj->cascade == s0->cascade && fj.width == f0.width && fj.height == f0.height &&
+                fj.stride == f0.stride && work[j].cols == work[i].cols && work[j].rows == work[i].rows &&
+                sj->p.scale_factor_pct == s0->p.scale_factor_pct) { idx.push_back(j); done[j] = 1; }
+        }
+        const int batch = (int)idx.size();
+        const int cols = work[i].cols, rows = work[i].rows;
+        GeomPlan *gp = nullptr;
+        const double sf = 1 + s0->p.scale_factor_pct * 1.0 / 100;      // MULTI_SCALE_FACTOR :142
+        int rc = get_face_plan(ctx, s0->cascade, f0.width, f0.height, f0.stride, 3, cols, rows, sf, cols / 20, rows / 20, 0, 0, &gp);
+        if (rc) return rc;
+        if ((rc = ensure_ws(ctx, gp->g, batch))) return rc;
+        if ((rc = stage_frames(ctx, frames, idx.data(), batch, 3))) return rc;
+        Workspace &ws = *ctx->ws;
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)batch * 256 * sizeof(unsigned), ctx->stream));
+        { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
+          launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>(), gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
+                      gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
+                      ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), batch, frames_aligned4(frames, idx.data(), batch)); }
+        { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
+          launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), batch); }
+        run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), batch);
+        std::vector<std::vector<nvca_rect>> raw;
+        if ((rc = run_cascade(ctx, *gp, batch, raw))) return rc;       // detectMultiScale :809-811
+        for (int b = 0; b < batch; b++) {
+            const int mn = streams[idx[b]]->p.min_neighbors;
+            if (mn != 0) group_rectangles(raw[b], std::max(mn, 1), 0.2);
+            work[idx[b]].det.swap(raw[b]);
+        }
+    }
+    // ---- pass 3: temporal logic + emission, in frame order
+    for (int i = 0; i < n; i++) {
+        nvca_face_stream *s = streams[i];
+        FrameWork &w = work[i];
+        if (w.analysed) {
+            if (!w.det.empty()) s->faces.track(w.det, s->p.track_threshold);           // :813-816
+            else if (s->frames_with_no_detection < kMaxNoDetection) s->frames_with_no_detection += 1;   // :817-826
+            else { s->frames_with_no_detection = 0; s->faces.clear(); }
+        }
+        const int nf = (int)s->faces.faces.size();
+        n_out[i] = nf;
+        for (int k = 0; k < std::min(nf, cap); k++) {                  // kms_face_send_event :208-211
+            const nvca_rect &r = s->faces.faces[k].box;
+            nvca_rect &o = out[(size_t)i * cap + k];
+            o.x = (int)((unsigned)r.x * (unsigned)w.norm_scale); o.y = (int)((unsigned)r.y * (unsigned)w.norm_scale);
+            o.w = (int)((unsigned)r.w * (unsigned)w.norm_scale); o.h = (int)((unsigned)r.h * (unsigned)w.norm_scale);
+            if (ids) ids[(size_t)i * cap + k] = s->faces.faces[k].id;
+        }
+    }
+    return NVCA_OK;
+}
+
+int nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca_rect *out, int *ids, int cap, int *n_out)
+{
+    if (!s || !frame) return NVCA_ERR_ARG;
+    nvca_face_stream *arr[1] = {s};
+    return nvca_face_batch_process(s->ctx, 1, arr, frame, out, ids, cap, n_out);
+}
+
+// =========================================================================
+// NuboTracker stream (device path lands with the tracker kernels)
+// =========================================================================
+void nvca_tracker_params_default(nvca_tracker_params *p)
+{
+    if (!p) return;
+    p->threshold = 20; p->min_area = 50; p->max_area = 30000; p->distance = 35; p->mhi_duration = 0.2; p->seg_thresh = 32;
+}
+
+} // extern "C"

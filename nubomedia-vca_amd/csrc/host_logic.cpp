@@ -1,0 +1,177 @@
+// host_logic.cpp -- the small sequential pieces of the path that stay on the
+// host exactly as in the reference / OpenCV:
+//   cv::groupRectangles + cv::partition   (cascadedetect.cpp, operations.hpp; inside
+//                                          detectMultiScale, FACE/kmsfacedetect.cpp:809)
+//   Faces::track_faces and helpers        (FACE/Faces.cpp:78-188, FACE/BaseFace.cpp:97-101)
+//   __join_objects / __merge / calc_dist  (TRK/gstnubotracker.cpp:119-200)
+// They are O(#boxes) integer code that decides the emitted boxes.
+#include "host_logic.h"
+#include <cmath>
+#include <cstdlib>
+#include <algorithm>
+
+namespace nvca {
+
+static inline int cv_round(double v) { return (int)lrint(v); }
+
+// ------------------------------------------------------------ groupRectangles
+namespace {
+struct SimilarRects {
+    double eps;
+    bool operator()(const nvca_rect &r1, const nvca_rect &r2) const {
+        double delta = eps * (std::min(r1.w, r2.w) + std::min(r1.h, r2.h)) * 0.5;
+        return std::abs(r1.x - r2.x) <= delta && std::abs(r1.y - r2.y) <= delta &&
+               std::abs(r1.x + r1.w - r2.x - r2.w) <= delta && std::abs(r1.y + r1.h - r2.y - r2.h) <= delta;
+    }
+};
+
+// cv::partition: disjoint-set forest; class ids in order of first appearance
+int partition(const std::vector<nvca_rect> &v, std::vector<int> &labels, SimilarRects pred)
+{
+    const int N = (int)v.size();
+    std::vector<int> parent(N, -1), rank(N, 0);
+    auto find = [&](int i) { while (parent[i] >= 0) i = parent[i]; return i; };
+    for (int i = 0; i < N; i++) {
+        int root = find(i);
+        for (int j = 0; j < N; j++) {
+            if (i == j || !pred(v[i], v[j])) continue;
+            int root2 = find(j);
+            if (root2 == root) continue;
+            if (rank[root] > rank[root2]) parent[root2] = root;
+            else {
+                parent[root] = root2;
+                rank[root2] += rank[root] == rank[root2];
+                root = root2;
+            }
+            for (int k = j, p; (p = parent[k]) >= 0; k = p) parent[k] = root;
+            for (int k = i, p; (p = parent[k]) >= 0; k = p) parent[k] = root;
+        }
+    }
+    labels.assign(N, 0);
+    std::vector<int> cls(N, -1);
+    int nclasses = 0;
+    for (int i = 0; i < N; i++) {
+        int root = find(i);
+        if (cls[root] < 0) cls[root] = nclasses++;
+        labels[i] = cls[root];
+    }
+    return nclasses;
+}
+} // namespace
+
+void group_rectangles(std::vector<nvca_rect> &rects, int groupThreshold, double eps, std::vector<int> *weights)
+{
+    if (groupThreshold <= 0 || rects.empty()) {
+        if (weights) weights->assign(rects.size(), 1);
+        return;
+    }
+    std::vector<int> labels;
+    const int nclasses = partition(rects, labels, SimilarRects{eps});
+    std::vector<nvca_rect> rr(nclasses, nvca_rect{0, 0, 0, 0});
+    std::vector<int> rw(nclasses, 0);
+    for (size_t i = 0; i < rects.size(); i++) {
+        nvca_rect &a = rr[labels[i]];
+        a.x += rects[i].x; a.y += rects[i].y; a.w += rects[i].w; a.h += rects[i].h;
+        rw[labels[i]]++;
+    }
+    for (int i = 0; i < nclasses; i++) {
+        const float s = 1.f / rw[i];
+        nvca_rect r = rr[i];
+        rr[i] = nvca_rect{cv_round(r.x * s), cv_round(r.y * s), cv_round(r.w * s), cv_round(r.h * s)};
+    }
+    rects.clear();
+    if (weights) weights->clear();
+    for (int i = 0; i < nclasses; i++) {
+        const nvca_rect r1 = rr[i];
+        const int n1 = rw[i];
+        if (n1 <= groupThreshold) continue;
+        int j;
+        for (j = 0; j < nclasses; j++) {
+            const int n2 = rw[j];
+            if (j == i || n2 <= groupThreshold) continue;
+            const nvca_rect r2 = rr[j];
+            const int dx = cv_round(r2.w * eps), dy = cv_round(r2.h * eps);
+            if (r1.x >= r2.x - dx && r1.y >= r2.y - dy && r1.x + r1.w <= r2.x + r2.w + dx &&
+                r1.y + r1.h <= r2.y + r2.h + dy && (n2 > std::max(3, n1) || n1 < 3))
+                break;
+        }
+        if (j == nclasses) {
+            rects.push_back(r1);
+            if (weights) weights->push_back(n1);
+        }
+    }
+}
+
+// ------------------------------------------------------------ Faces
+namespace {
+inline int area(const nvca_rect &r) { return r.w * r.h; }
+inline int centre_distance(const nvca_rect &a, const nvca_rect &b)
+{   // Faces::calc_distance over BaseFace::calc_center: truncated Euclidean distance
+    const int ax = a.x + a.w / 2, ay = a.y + a.h / 2, bx = b.x + b.w / 2, by = b.y + b.h / 2;
+    return (int)std::sqrt(std::pow((double)(bx - ax), 2) + std::pow((double)(by - ay), 2));
+}
+inline int distance_limit(int s1, int s2) { const int big = std::max(s1, s2); return big > 5000 ? 8 : (big > 2500 ? 5 : 3); }
+inline int diff_area_pct(int s1, int s2) { return (std::abs(s1 - s2) * 100) / s2; }
+} // namespace
+
+void Faces::track(const std::vector<nvca_rect> &current, int track_threshold)
+{
+    std::vector<nvca_rect> cf(current);
+    std::vector<TrackedFace> next;
+    for (const TrackedFace &f : faces) {
+        int best = track_threshold, pos = -1;
+        for (size_t i = 0; i < cf.size(); i++) {
+            const int d = centre_distance(cf[i], f.box);
+            if (best > d) { pos = (int)i; best = d; }
+        }
+        if (pos < 0) continue;                         // unmatched old faces are dropped
+        const nvca_rect &n = cf[pos];
+        const int d = centre_distance(f.box, n);
+        if (distance_limit(area(f.box), area(n)) < d) next.push_back(TrackedFace{n, f.id});
+        else if (15 < diff_area_pct(area(f.box), area(n))) next.push_back(TrackedFace{nvca_rect{f.box.x, f.box.y, n.w, n.h}, f.id});
+        else next.push_back(f);
+        cf.erase(cf.begin() + pos);
+    }
+    for (const nvca_rect &r : cf) next.push_back(TrackedFace{r, next_id++});
+    faces.swap(next);
+}
+
+// ------------------------------------------------------------ tracker boxes
+namespace {
+inline float trk_dist(const nvca_rect &a, const nvca_rect &b)
+{
+    const int c1x = a.x + a.w / 2, c1y = a.y + a.h / 2, c2x = b.x + b.w / 2, c2y = b.y + b.h / 2;
+    return (float)std::sqrt((double)((c1x - c2x) * (c1x - c2x) + (c1y - c2y) * (c1y - c2y)));
+}
+inline bool inside(int px, int py, const nvca_rect &r) { return r.x <= px && px < r.x + r.w && r.y <= py && py < r.y + r.h; }
+nvca_rect merge(const nvca_rect &r1, const nvca_rect &r2)
+{
+    if (inside(r2.x, r2.y, r1) && inside(r2.x + r2.w, r2.y + r2.h, r1)) return r1;
+    if (inside(r1.x, r1.y, r2) && inside(r1.x + r1.w, r1.y + r1.h, r2)) return r2;
+    const int tx = std::min(r1.x, r2.x), ty = std::min(r1.y, r2.y);
+    const int bx = std::max(r1.x + r1.w, r2.x + r2.w), by = std::max(r1.y + r1.h, r2.y + r2.h);
+    nvca_rect r;            // cv::Rect(Point, Point)
+    r.x = std::min(tx, bx); r.y = std::min(ty, by);
+    r.w = std::max(tx, bx) - r.x; r.h = std::max(ty, by) - r.y;
+    return r;
+}
+} // namespace
+
+void join_objects(std::vector<nvca_rect> &sb, int min_area, long max_area, int distance)
+{
+    for (int a = (int)sb.size() - 1; a >= 0; a--) {
+        if (area(sb[a]) > min_area && area(sb[a]) < max_area) {
+            for (int b = a - 1; b >= 0; b--) {
+                if (area(sb[b]) > min_area && area(sb[b]) < max_area)
+                    if ((float)distance > trk_dist(sb[a], sb[b])) {
+                        sb[b] = merge(sb[a], sb[b]);
+                        sb.erase(sb.begin() + a);
+                        break;
+                    }
+            }
+        } else
+            sb.erase(sb.begin() + a);
+    }
+}
+
+} // namespace nvca

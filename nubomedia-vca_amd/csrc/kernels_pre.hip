@@ -1,0 +1,471 @@
+// kernels_pre.hip -- gfx950 kernels for the image preparation in front of the
+// cascade: cv::resize + cv::cvtColor + cv::equalizeHist + cv::integral as the
+// reference calls them (FACE/kmsfacedetect.cpp:805-811; integral inside
+// detectMultiScale).  All integer; HBM-bound streaming work.
+//
+// Data layout (per batch slot): gray u8 [h][gpitch]; sum i32 [(h+1)][spitch];
+// sqsum u64 [(h+1)][spitch] (exact integers -> bit-identical to OpenCV's f64);
+// band partials u32 [nbands][bpitch] for column sums of pixel and pixel^2.
+#include "nvca_internal.h"
+
+namespace nvca {
+
+static constexpr int kGrayRows = 8;        // rows per block in the gray kernels
+
+__device__ __forceinline__ int gray_of(int b, int g, int r)
+{   // RGB2Gray<uchar>: B2Y 1868, G2Y 9617, R2Y 4899, shift 14, rounding 1<<13
+    return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;
+}
+
+__device__ __forceinline__ void hist_flush(unsigned (*lh)[256], unsigned *hist, int tid)
+{
+    __syncthreads();
+    unsigned v = lh[0][tid] + lh[1][tid] + lh[2][tid] + lh[3][tid];
+    if (v) atomicAdd(&hist[tid], v);
+}
+
+// ---- K1 generic: one output pixel per thread, any resize mode, any alignment.
+// mode 0 identity, 1 bilinear (fixed point, 11-bit coefficients), 2 area 2x2.
+__global__ __launch_bounds__(256) void k_gray_generic(
+    const uint8_t *const *__restrict__ srcs, PreGeom g, int mode,
+    const int *__restrict__ xofs, const short *__restrict__ ialpha,
+    const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax,
+    uint8_t *__restrict__ gray, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, slot = blockIdx.z;
+    for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint8_t *src = srcs[slot];
+    const int cn = g.cn;
+    const int x = blockIdx.x * 256 + tid;
+    uint8_t *grow = gray + (size_t)slot * g.gray_slot;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y >= g.h) break;
+        if (x < g.w) {
+            int B, G, R;
+            if (mode == 0) {
+                const uint8_t *s = src + (size_t)y * g.sstride + (size_t)x * cn;
+                B = s[0]; G = s[1]; R = s[2];
+            } else if (mode == 2) {
+                const uint8_t *s0 = src + (size_t)(2 * y) * g.sstride + (size_t)(2 * x) * cn;
+                const uint8_t *s1 = s0 + g.sstride;
+                B = (s0[0] + s0[cn] + s1[0] + s1[cn] + 2) >> 2;
+                G = (s0[1] + s0[cn + 1] + s1[1] + s1[cn + 1] + 2) >> 2;
+                R = (s0[2] + s0[cn + 2] + s1[2] + s1[cn + 2] + 2) >> 2;
+            } else {
+                int sy0 = yofs[y], sy1 = sy0 + 1;
+                sy0 = sy0 >= 0 ? (sy0 < g.sh ? sy0 : g.sh - 1) : 0;
+                sy1 = sy1 >= 0 ? (sy1 < g.sh ? sy1 : g.sh - 1) : 0;
+                const int sx = xofs[x] * cn;
+                const uint8_t *s0 = src + (size_t)sy0 * g.sstride + sx;
+                const uint8_t *s1 = src + (size_t)sy1 * g.sstride + sx;
+                const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+                int c[3];
+                if (x < xmax) {
+                    const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        int h0 = s0[k] * a0 + s0[cn + k] * a1;
+                        int h1 = s1[k] * a0 + s1[cn + k] * a1;
+                        c[k] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        int h0 = s0[k] * 2048, h1 = s1[k] * 2048;
+                        c[k] = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    }
+                }
+                B = c[0] & 255; G = c[1] & 255; R = c[2] & 255;
+            }
+            const int v = gray_of(B, G, R);
+            grow[(size_t)y * g.gpitch + x] = (uint8_t)v;
+            if (hist) atomicAdd(&lh[wave][v], 1u);
+        }
+    }
+    if (hist) hist_flush(lh, hist + slot * 256, tid);
+}
+
+// ---- K1 fast path: identity geometry, rows and base 4-byte aligned: 4 pixels per thread.
+template <int CN>
+__global__ __launch_bounds__(256) void k_gray_fast4(
+    const uint8_t *const *__restrict__ srcs, PreGeom g, uint8_t *__restrict__ gray,
+    unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, slot = blockIdx.z;
+    for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint8_t *src = srcs[slot];
+    const int x4 = (blockIdx.x * 256 + tid) * 4;
+    uint8_t *grow = gray + (size_t)slot * g.gray_slot;
+    if (x4 < g.w) {
+        for (int ry = 0; ry < kGrayRows; ry++) {
+            const int y = blockIdx.y * kGrayRows + ry;
+            if (y >= g.h) break;
+            const unsigned *s = (const unsigned *)(src + (size_t)y * g.sstride + (size_t)x4 * CN);
+            int v[4];
+            if (x4 + 4 <= g.w) {
+                if (CN == 3) {
+                    const unsigned d0 = s[0], d1 = s[1], d2 = s[2];
+                    v[0] = gray_of(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255);
+                    v[1] = gray_of(d0 >> 24, d1 & 255, (d1 >> 8) & 255);
+                    v[2] = gray_of((d1 >> 16) & 255, d1 >> 24, d2 & 255);
+                    v[3] = gray_of((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24);
+                } else {
+                    const uint4 d = *(const uint4 *)s;
+                    v[0] = gray_of(d.x & 255, (d.x >> 8) & 255, (d.x >> 16) & 255);
+                    v[1] = gray_of(d.y & 255, (d.y >> 8) & 255, (d.y >> 16) & 255);
+                    v[2] = gray_of(d.z & 255, (d.z >> 8) & 255, (d.z >> 16) & 255);
+                    v[3] = gray_of(d.w & 255, (d.w >> 8) & 255, (d.w >> 16) & 255);
+                }
+                *(unsigned *)(grow + (size_t)y * g.gpitch + x4) =
+                    (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+                if (hist) {
+                    atomicAdd(&lh[wave][v[0]], 1u); atomicAdd(&lh[wave][v[1]], 1u);
+                    atomicAdd(&lh[wave][v[2]], 1u); atomicAdd(&lh[wave][v[3]], 1u);
+                }
+            } else {
+                const uint8_t *sb = (const uint8_t *)s;
+                for (int k = 0; x4 + k < g.w; k++) {
+                    const int vv = gray_of(sb[k * CN], sb[k * CN + 1], sb[k * CN + 2]);
+                    grow[(size_t)y * g.gpitch + x4 + k] = (uint8_t)vv;
+                    if (hist) atomicAdd(&lh[wave][vv], 1u);
+                }
+            }
+        }
+    }
+    if (hist) hist_flush(lh, hist + slot * 256, tid);
+}
+
+void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, int mode,
+                 const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta, int xmax,
+                 uint8_t *gray, unsigned *hist, int batch, bool aligned4)
+{
+    const int gy = (g.h + kGrayRows - 1) / kGrayRows;
+    if (mode == 0 && aligned4 && (g.cn == 3 || g.cn == 4)) {
+        dim3 grid((g.w + 1023) / 1024, gy, batch);
+        if (g.cn == 3) hipLaunchKernelGGL(k_gray_fast4<3>, grid, dim3(256), 0, st, d_src, g, gray, hist);
+        else           hipLaunchKernelGGL(k_gray_fast4<4>, grid, dim3(256), 0, st, d_src, g, gray, hist);
+    } else {
+        dim3 grid((g.w + 255) / 256, gy, batch);
+        hipLaunchKernelGGL(k_gray_generic, grid, dim3(256), 0, st, d_src, g, mode, d_xofs, d_ialpha, d_yofs,
+                           d_ibeta, xmax, gray, hist);
+    }
+}
+
+// ---- 8UC1 resize (gray-then-resize order of the part detectors, pyramid levels)
+__global__ __launch_bounds__(256) void k_resize1(
+    const uint8_t *__restrict__ src, int sw, int sh, int sstride, int mode,
+    const int *__restrict__ xofs, const short *__restrict__ ialpha,
+    const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax,
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const int x = blockIdx.x * 256 + tid;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y >= dh) break;
+        if (x < dw) {
+            int v;
+            if (mode == 0) v = src[(size_t)y * sstride + x];
+            else if (mode == 2) {
+                const uint8_t *s0 = src + (size_t)(2 * y) * sstride + 2 * x, *s1 = s0 + sstride;
+                v = (s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2;
+            } else {
+                int sy0 = yofs[y], sy1 = sy0 + 1;
+                sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+                sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+                const int sx = xofs[x];
+                const uint8_t *s0 = src + (size_t)sy0 * sstride + sx, *s1 = src + (size_t)sy1 * sstride + sx;
+                const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+                int h0, h1;
+                if (x < xmax) {
+                    const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+                    h0 = s0[0] * a0 + s0[1] * a1; h1 = s1[0] * a0 + s1[1] * a1;
+                } else { h0 = s0[0] * 2048; h1 = s1[0] * 2048; }
+                v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
+            }
+            dst[(size_t)y * dstride + x] = (uint8_t)v;
+            if (hist) atomicAdd(&lh[wave][v], 1u);
+        }
+    }
+    if (hist) hist_flush(lh, hist, tid);
+}
+
+void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
+                    const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist)
+{
+    dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, 1);
+    hipLaunchKernelGGL(k_resize1, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs,
+                       d_ibeta, xmax, dst, dw, dh, dstride, hist);
+}
+
+// ---- K2: equalizeHist LUT from the histogram (one block per slot)
+__global__ __launch_bounds__(256) void k_lut(const unsigned *__restrict__ hist, int total, uint8_t *__restrict__ lut)
+{
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned long long wmask[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
+    const unsigned h = hist[slot * 256 + tid];
+    unsigned incl = h;
+    for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const unsigned long long m = __ballot(h != 0);
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wmask[wave] = m;
+    __syncthreads();
+    for (int j = 0; j < wave; j++) incl += wsum[j];
+    int first = 256;
+    for (int j = 3; j >= 0; j--) if (wmask[j]) first = j * 64 + __ffsll((long long)wmask[j]) - 1;
+    uint8_t out;
+    if (first == 256) out = 0;
+    else {
+        const unsigned hf = hist[slot * 256 + first];
+        if (hf == (unsigned)total) out = (uint8_t)first;         // dst.setTo(i)
+        else if (tid <= first) out = 0;
+        else {
+            const float scale = 255.f / (float)(int)(total - (int)hf);   // (hist_sz-1.f)/(total-hist[i])
+            const float v = (float)(int)(incl - hf) * scale;             // sum*scale, int -> float
+            int iv = (int)rintf(v);                                      // saturate_cast<uchar>: cvRound + clamp
+            out = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+        }
+    }
+    lut[slot * 256 + tid] = out;
+}
+
+void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch)
+{
+    hipLaunchKernelGGL(k_lut, dim3(batch), dim3(256), 0, st, hist, total, lut);
+}
+
+__global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ gray, int w, int h, int pitch,
+                                              unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const int x = blockIdx.x * 256 + tid;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y < h && x < w) atomicAdd(&lh[wave][gray[(size_t)y * pitch + x]], 1u);
+    }
+    hist_flush(lh, hist, tid);
+}
+void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist)
+{
+    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
+    hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, st, gray, w, h, pitch, hist);
+}
+
+__global__ __launch_bounds__(256) void k_apply_lut(const uint8_t *__restrict__ src, int w, int h, int spitch,
+                                                   const uint8_t *__restrict__ lut, uint8_t *__restrict__ dst, int dpitch)
+{
+    __shared__ uint8_t sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y < h && x < w) dst[(size_t)y * dpitch + x] = sl[src[(size_t)y * spitch + x]];
+    }
+}
+void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spitch, const uint8_t *lut,
+                      uint8_t *dst, int dpitch)
+{
+    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
+    hipLaunchKernelGGL(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch);
+}
+
+// ---- K3a: per-band column sums of lut[gray] and its square
+__global__ __launch_bounds__(256) void k_colsum(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut,
+                                                int lut_stride, PreGeom g, unsigned *__restrict__ bandsum,
+                                                unsigned *__restrict__ bandsq)
+{
+    __shared__ uint8_t sl[256];
+    const int tid = threadIdx.x, band = blockIdx.y, slot = blockIdx.z;
+    sl[tid] = lut ? lut[(size_t)slot * lut_stride + tid] : (uint8_t)tid;
+    __syncthreads();
+    const int x4 = (blockIdx.x * 256 + tid) * 4;
+    const int bpitch = (int)(g.band_slot / g.nbands);
+    if (x4 >= bpitch) return;
+    const int y0 = band * kIntegralBand, y1 = min(g.h, y0 + kIntegralBand);
+    unsigned s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (x4 < g.w) {
+        const uint8_t *base = gray + (size_t)slot * g.gray_slot + x4;
+        for (int y = y0; y < y1; y++) {
+            const unsigned px = *(const unsigned *)(base + (size_t)y * g.gpitch);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned v = (x4 + k < g.w) ? sl[(px >> (8 * k)) & 255] : 0u;
+                s[k] += v; q[k] += v * v;
+            }
+        }
+    }
+    const size_t o = (size_t)slot * g.band_slot + (size_t)band * bpitch + x4;
+    *(uint4 *)(bandsum + o) = make_uint4(s[0], s[1], s[2], s[3]);
+    *(uint4 *)(bandsq + o) = make_uint4(q[0], q[1], q[2], q[3]);
+}
+void launch_colsum(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
+                   unsigned *bandsum, unsigned *bandsq, int batch)
+{
+    const int bpitch = (int)(g.band_slot / g.nbands);
+    dim3 grid((bpitch / 4 + 255) / 256, g.nbands, batch);
+    hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, st, gray, lut, lut_stride, g, bandsum, bandsq);
+}
+
+// ---- K3b: exclusive scan over bands, per column (in place)
+__global__ __launch_bounds__(256) void k_bandscan(PreGeom g, unsigned *__restrict__ bandsum, unsigned *__restrict__ bandsq)
+{
+    const int bpitch = (int)(g.band_slot / g.nbands);
+    const int x = blockIdx.x * 256 + threadIdx.x, slot = blockIdx.y;
+    if (x >= bpitch) return;
+    unsigned rs = 0, rq = 0;
+    size_t o = (size_t)slot * g.band_slot + x;
+    for (int b = 0; b < g.nbands; b++, o += bpitch) {
+        const unsigned ts = bandsum[o], tq = bandsq[o];
+        bandsum[o] = rs; bandsq[o] = rq;
+        rs += ts; rq += tq;
+    }
+}
+void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsigned *bandsq, int batch)
+{
+    const int bpitch = (int)(g.band_slot / g.nbands);
+    hipLaunchKernelGGL(k_bandscan, dim3((bpitch + 255) / 256, batch), dim3(256), 0, st, g, bandsum, bandsq);
+}
+
+// ---- K3c: integral + squared integral.  One block per band of rows; a block
+// scans whole rows (8 integral columns per thread, 2048 per pass), keeps the
+// vertical running sums in registers and writes 32 B / 64 B aligned vectors.
+// Thread t owns integral columns X in [8t, 8t+8): value(X) = prefix up to pixel X-1
+// = exclusive base of the thread (X = 8t) or base + local inclusive (X > 8t).
+__global__ __launch_bounds__(256) void k_integral(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut,
+                                                  int lut_stride, PreGeom g, const unsigned *__restrict__ bandsum,
+                                                  const unsigned *__restrict__ bandsq, int *__restrict__ sum,
+                                                  unsigned long long *__restrict__ sqsum)
+{
+    __shared__ uint8_t sl[256];
+    __shared__ unsigned ws_s[2][4], ws_q[2][4];
+    __shared__ unsigned wb_s[4];
+    __shared__ unsigned long long wb_q[4];
+    __shared__ unsigned carry_s[kIntegralBand], carry_q[kIntegralBand];
+    __shared__ unsigned cbase_s;
+    __shared__ unsigned long long cbase_q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = blockIdx.x, slot = blockIdx.y;
+    sl[tid] = lut ? lut[(size_t)slot * lut_stride + tid] : (uint8_t)tid;
+    if (tid < kIntegralBand) { carry_s[tid] = 0; carry_q[tid] = 0; }
+    if (tid == 0) { cbase_s = 0; cbase_q = 0; }
+    __syncthreads();
+    const int y0 = band * kIntegralBand, y1 = min(g.h, y0 + kIntegralBand);
+    const int bpitch = (int)(g.band_slot / g.nbands);
+    const uint8_t *gbase = gray + (size_t)slot * g.gray_slot;
+    int *sbase = sum + (size_t)slot * g.sum_slot;
+    unsigned long long *qbase = sqsum + (size_t)slot * g.sum_slot;
+    const unsigned *bs = bandsum + (size_t)slot * g.band_slot + (size_t)band * bpitch;
+    const unsigned *bq = bandsq + (size_t)slot * g.band_slot + (size_t)band * bpitch;
+    const int nchunks = (g.w + 1 + 2047) / 2048;
+
+    for (int c = 0; c < nchunks; c++) {
+        const int X0 = c * 2048 + tid * 8;
+        const bool in_pitch = X0 < g.spitch;
+        // ---- base row: prefix over x of the column sums above this band
+        unsigned ps[8]; unsigned long long pq[8];
+        {
+            unsigned vs[8], vq[8];
+            if (X0 + 8 <= bpitch) {
+                const uint4 a = *(const uint4 *)(bs + X0), b = *(const uint4 *)(bs + X0 + 4);
+                const uint4 e = *(const uint4 *)(bq + X0), f = *(const uint4 *)(bq + X0 + 4);
+                vs[0] = a.x; vs[1] = a.y; vs[2] = a.z; vs[3] = a.w; vs[4] = b.x; vs[5] = b.y; vs[6] = b.z; vs[7] = b.w;
+                vq[0] = e.x; vq[1] = e.y; vq[2] = e.z; vq[3] = e.w; vq[4] = f.x; vq[5] = f.y; vq[6] = f.z; vq[7] = f.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { vs[k] = 0; vq[k] = 0; }
+            }
+            unsigned rs = 0; unsigned long long rq = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool ok = X0 + k < g.w;
+                rs += ok ? vs[k] : 0u; rq += ok ? vq[k] : 0u;
+                ps[k] = rs; pq[k] = rq;
+            }
+        }
+        unsigned ts = ps[7]; unsigned long long tq = pq[7];
+        unsigned is = ts + (tid == 0 ? cbase_s : 0u);
+        unsigned long long iq = tq + (tid == 0 ? cbase_q : 0ull);
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned a = __shfl_up(is, d); const unsigned long long b = __shfl_up(iq, d);
+            if (lane >= d) { is += a; iq += b; }
+        }
+        if (lane == 63) { wb_s[wave] = is; wb_q[wave] = iq; }
+        __syncthreads();
+        for (int j = 0; j < wave; j++) { is += wb_s[j]; iq += wb_q[j]; }
+        unsigned acc_s[8]; unsigned long long acc_q[8];
+        {
+            const unsigned es = is - ts; const unsigned long long eq = iq - tq;
+            acc_s[0] = es; acc_q[0] = eq;
+#pragma unroll
+            for (int k = 1; k < 8; k++) { acc_s[k] = es + ps[k - 1]; acc_q[k] = eq + pq[k - 1]; }
+        }
+        __syncthreads();                                   // wb_* consumed
+        if (tid == 255) { cbase_s = is; cbase_q = iq; }
+        if (band == 0 && in_pitch) {                        // integral row 0 (all zero)
+            int *so = sbase + X0; unsigned long long *qo = qbase + X0;
+            *(int4 *)so = make_int4(0, 0, 0, 0); *(int4 *)(so + 4) = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) *(ulonglong2 *)(qo + k) = make_ulonglong2(0, 0);
+        }
+        // ---- rows of the band
+        for (int y = y0; y < y1; y++) {
+            const int r = y - y0, par = r & 1;
+            unsigned long long px = 0;
+            if (X0 < g.w) px = *(const unsigned long long *)(gbase + (size_t)y * g.gpitch + X0);
+            unsigned ls[8], lq[8];
+            unsigned rs = 0, rq = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned v = (X0 + k < g.w) ? (unsigned)sl[(px >> (8 * k)) & 255] : 0u;
+                rs += v; rq += v * v;
+                ls[k] = rs; lq[k] = rq;
+            }
+            const unsigned t_s = rs, t_q = rq;
+            unsigned i_s = t_s + (tid == 0 ? carry_s[r] : 0u), i_q = t_q + (tid == 0 ? carry_q[r] : 0u);
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned a = __shfl_up(i_s, d), b = __shfl_up(i_q, d);
+                if (lane >= d) { i_s += a; i_q += b; }
+            }
+            if (lane == 63) { ws_s[par][wave] = i_s; ws_q[par][wave] = i_q; }
+            __syncthreads();
+            for (int j = 0; j < wave; j++) { i_s += ws_s[par][j]; i_q += ws_q[par][j]; }
+            if (tid == 255) { carry_s[r] = i_s; carry_q[r] = i_q; }
+            const unsigned e_s = i_s - t_s, e_q = i_q - t_q;
+            acc_s[0] += e_s; acc_q[0] += e_q;
+#pragma unroll
+            for (int k = 1; k < 8; k++) { acc_s[k] += e_s + ls[k - 1]; acc_q[k] += e_q + lq[k - 1]; }
+            if (in_pitch) {
+                int *so = sbase + (size_t)(y + 1) * g.spitch + X0;
+                unsigned long long *qo = qbase + (size_t)(y + 1) * g.spitch + X0;
+                *(int4 *)so = make_int4((int)acc_s[0], (int)acc_s[1], (int)acc_s[2], (int)acc_s[3]);
+                *(int4 *)(so + 4) = make_int4((int)acc_s[4], (int)acc_s[5], (int)acc_s[6], (int)acc_s[7]);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) *(ulonglong2 *)(qo + k) = make_ulonglong2(acc_q[k], acc_q[k + 1]);
+            }
+        }
+        __syncthreads();
+    }
+}
+void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
+                     const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
+                     int batch)
+{
+    hipLaunchKernelGGL(k_integral, dim3(g.nbands, batch), dim3(256), 0, st, gray, lut, lut_stride, g, bandsum,
+                       bandsq, sum, sqsum);
+}
+
+} // namespace nvca

@@ -1,0 +1,189 @@
+// nvca_internal.h -- shared declarations of libnubovca_hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+#include "../../include/nubovca.h"
+
+namespace nvca {
+
+// --------------------------------------------------------------------------
+// Cascade as loaded from old-format XML (OpenCV CvHaarClassifierCascade).
+// --------------------------------------------------------------------------
+struct HaarNode {
+    int   rect[3][4];   // x,y,w,h ; zero when absent
+    float weight[3];
+    int   nrect;        // 2 or 3 (icvCreateHidHaarClassifierCascade's rect[2] test)
+    float threshold;
+    int   left, right;  // >0 child node index, <=0 -> alpha[-idx]
+    int   tilted;
+};
+struct HaarClassifier { int first_node, nnodes, first_alpha; };
+struct HaarStage { int first_cls, ncls; float threshold; /* as in the XML */ };
+
+struct Cascade {
+    int ow = 0, oh = 0;
+    std::vector<HaarStage> stages;
+    std::vector<HaarClassifier> cls;
+    std::vector<HaarNode> nodes;
+    std::vector<float> alpha;
+    bool stump_based = true;
+    uint64_t uid = 0;       // identity for plan caching
+};
+
+// returns NVCA_OK or NVCA_ERR_PARSE / NVCA_ERR_UNSUPPORTED; err gets a message
+int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &err);
+
+// --------------------------------------------------------------------------
+// Device-side records (plain structs shared by host table builder and kernels)
+// --------------------------------------------------------------------------
+struct StumpRec {           // one weak classifier at one scale: 20 dwords
+    int   p[3][4];          // corner offsets (elements of the pitched sum plane), relative to the window origin
+    float w[3];             // hidden weights (rect 0 re-balanced)
+    float thr;
+    float a0, a1;           // alpha[0] (sum < t) , alpha[1] (sum >= t)
+    int   nrect;
+    int   pad;
+};
+static_assert(sizeof(StumpRec) == 80, "StumpRec layout");
+
+struct StageRec { int first, count; float thr; int two_rects; };
+
+struct ScaleRec {           // one evaluated scale
+    int    winw, winh;
+    int    startX, startY, endX, endY;   // ix / iy ranges
+    int    eq[4];           // equRect corner offsets
+    int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
+    int    stump_off;       // first StumpRec of this scale
+    int    pad;
+    double inv_area;
+    double factor;
+};
+
+struct StripRec { int scale, iy0, nrows, pad; };   // a block's share of the scan
+
+static constexpr int kStripMaxWin = 2048;  // windows per strip (LDS budget of the evaluator)
+static constexpr int kIntegralBand = 16;   // rows per integral band
+
+// resize tables (cv::resize INTER_LINEAR 8U fixed point)
+struct ResizeTab {
+    int sw = 0, sh = 0, dw = 0, dh = 0;
+    int mode = 0;           // 0 identity, 1 bilinear, 2 area-fast 2x2
+    int xmax = 0;
+    std::vector<int> xofs, yofs;
+    std::vector<short> ialpha, ibeta;
+};
+void build_resize_tab(int sw, int sh, int dw, int dh, ResizeTab &t);
+
+// --------------------------------------------------------------------------
+// Context
+// --------------------------------------------------------------------------
+#define NVCA_HIP_CHECK(ctx, expr)                                                   \
+    do {                                                                            \
+        hipError_t e__ = (expr);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(e__));   \
+            return NVCA_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t n);          // grows (never shrinks); returns hipError as int
+    void release();
+    template <class T> T *as() const { return (T *)p; }
+};
+struct PinnedBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t n);
+    void release();
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct DetectPlan;   // plan.cpp
+struct GeomPlan;     // api.cpp
+struct Workspace;    // api.cpp
+
+struct KernelTimer {
+    bool on = false;
+    struct Ev { hipEvent_t a, b; int k; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[NVCA_K_COUNT] = {0};
+    int64_t launches[NVCA_K_COUNT] = {0};
+};
+
+} // namespace nvca
+
+struct nvca_cascade { nvca::Cascade c; nvca_ctx *ctx; };
+
+struct nvca_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int hit_cap = 16384;
+    int policy = NVCA_SUM_F32PAIR;
+    uint64_t next_uid = 1;
+    nvca::KernelTimer timer;
+    std::map<std::string, std::unique_ptr<nvca::GeomPlan>> plans;
+    std::unique_ptr<nvca::Workspace> ws;
+    void *identity_lut = nullptr;     // 256 B on device
+    void set_error(const std::string &s) { err = s; }
+    nvca_ctx();
+    ~nvca_ctx();
+};
+
+namespace nvca {
+
+// RAII bracket: records events around a kernel class when timing is enabled
+struct TimedLaunch {
+    nvca_ctx *ctx; int k; hipEvent_t a = nullptr, b = nullptr;
+    TimedLaunch(nvca_ctx *c, int kind);
+    ~TimedLaunch();
+};
+
+// --------------------------------------------------------------------------
+// Kernel launch wrappers (kernels_pre.hip / kernels_cascade.hip)
+// --------------------------------------------------------------------------
+struct PreGeom {
+    int sw, sh, sstride, cn;      // source frame
+    int w, h, gpitch;             // working gray image (pitch in bytes)
+    int spitch;                   // integral pitch (elements), rows = h+1
+    int nbands;
+    size_t src_slot, gray_slot, sum_slot, band_slot;   // strides between batch slots (elements of each plane)
+};
+
+// src[b] pointers are passed as a device array of pointers (frames need not be contiguous)
+void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, int mode,
+                 const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta, int xmax,
+                 uint8_t *gray, unsigned *hist, int batch, bool aligned4);
+void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
+                    const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist);
+void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist);
+void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch);
+void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spitch, const uint8_t *lut,
+                      uint8_t *dst, int dpitch);
+void launch_colsum(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
+                   unsigned *bandsum, unsigned *bandsq, int batch);
+void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsigned *bandsq, int batch);
+void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
+                     const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
+                     int batch);
+
+struct CascadeArgs {
+    const int *sum; const unsigned long long *sqsum;
+    size_t sum_slot;               // elements between slots
+    int spitch;
+    const ScaleRec *scales; const StumpRec *stumps; const StageRec *stages;
+    const StripRec *strips; const int *pos;
+    int nstages; int pair_policy;  // 1 = F32PAIR
+    unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
+    unsigned hit_cap;
+};
+void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int nstrips, int batch);
+
+} // namespace nvca

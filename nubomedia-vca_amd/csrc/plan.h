@@ -1,0 +1,30 @@
+// plan.h -- per-(cascade, geometry) tables, host copy + device copy.
+#pragma once
+#include "nvca_internal.h"
+
+namespace nvca {
+
+void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw, int minh,
+                int maxw, int maxh, bool findBiggest, std::vector<double> &factors);
+void build_scale_tables(const Cascade &c, double factor, int pitch, ScaleRec &sr, StumpRec *out);
+void build_stage_recs(const Cascade &c, std::vector<StageRec> &out);
+
+struct DetectPlan {
+    // geometry of the working (gray) image the detector runs on
+    int cols = 0, rows = 0, spitch = 0;
+    int nstumps = 0;
+    std::vector<ScaleRec> scales;
+    std::vector<StumpRec> stumps;
+    std::vector<StageRec> stages;
+    std::vector<StripRec> strips;
+    std::vector<int> pos;
+    // device copies
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos;
+
+    int build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
+                            int minw, int minh, int maxw, int maxh, std::string &err);
+    int upload(nvca_ctx *ctx);
+    ~DetectPlan();
+};
+
+} // namespace nvca

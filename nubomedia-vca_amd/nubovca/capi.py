@@ -1,0 +1,365 @@
+"""ctypes binding of libnubovca_hip's C ABI (include/nubovca.h).
+
+This is the harness side used by tests/ and bench.py; the product host code is
+the C++ GStreamer shim under nubomedia-vca_amd/gst/.  There is no fallback: if
+the shared library is missing, or no HIP device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libnubovca_hip.so")
+
+OK = 0
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OVERFLOW, ERR_NOMEM = range(-1, -9, -1)
+MEM_HOST, MEM_DEVICE = 0, 1
+HAAR_DO_CANNY_PRUNING, HAAR_SCALE_IMAGE, HAAR_FIND_BIGGEST_OBJECT, HAAR_DO_ROUGH_SEARCH = 1, 2, 4, 8
+SUM_F32PAIR, SUM_F64 = 0, 1
+K_COUNT = 9
+
+
+class NvcaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nubovca error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int),
+                ("mem", C.c_int), ("pts", C.c_uint64)]
+
+
+class FaceParams(C.Structure):
+    _fields_ = [("width_to_process", C.c_int), ("process_x_every_4", C.c_int), ("scale_factor_pct", C.c_int),
+                ("track_threshold", C.c_int), ("euclidean_threshold", C.c_int), ("area_threshold", C.c_int),
+                ("min_neighbors", C.c_int), ("detect_event", C.c_int)]
+
+
+class TrackerParams(C.Structure):
+    _fields_ = [("threshold", C.c_int), ("min_area", C.c_int), ("max_area", C.c_long), ("distance", C.c_int),
+                ("mhi_duration", C.c_double), ("seg_thresh", C.c_double)]
+
+
+# every symbol include/nubovca.h declares
+SYMBOLS = [
+    "nvca_ctx_create", "nvca_ctx_destroy", "nvca_last_error", "nvca_version", "nvca_ctx_set_hit_capacity",
+    "nvca_ctx_set_sum_policy", "nvca_ctx_synchronize", "nvca_ctx_stream", "nvca_ctx_enable_kernel_timing",
+    "nvca_ctx_kernel_timing", "nvca_kernel_name", "nvca_cascade_load_xml", "nvca_cascade_load_mem",
+    "nvca_cascade_free", "nvca_cascade_info", "nvca_cascade_dump", "nvca_bgr2gray", "nvca_resize_linear",
+    "nvca_equalize_hist", "nvca_integral", "nvca_detect_multiscale", "nvca_detect_raw", "nvca_group_rectangles",
+    "nvca_face_params_default", "nvca_face_stream_create", "nvca_face_stream_destroy",
+    "nvca_face_stream_set_params", "nvca_face_stream_motion_event", "nvca_face_stream_process",
+    "nvca_face_batch_process", "nvca_tracker_params_default", "nvca_tracker_create", "nvca_tracker_destroy",
+    "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process",
+]
+
+_lib = None
+
+
+def _preload_torch_hip():
+    """One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as
+    /opt/rocm's).  Whichever is mapped first serves both, and torch cannot see the GPU
+    through the system copy, so map torch's copy first when torch is installed."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load():
+    """dlopen the library and declare prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python __graft_entry__.py build` (hipcc, gfx950)" % LIB_PATH)
+    _preload_torch_hip()
+    L = C.CDLL(LIB_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.nvca_version.restype = C.c_char_p
+    L.nvca_last_error.restype = C.c_char_p
+    L.nvca_last_error.argtypes = [vp]
+    L.nvca_kernel_name.restype = C.c_char_p
+    L.nvca_kernel_name.argtypes = [C.c_int]
+    L.nvca_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.nvca_ctx_destroy.argtypes = [vp]
+    L.nvca_ctx_destroy.restype = None
+    L.nvca_ctx_set_hit_capacity.argtypes = [vp, C.c_int]
+    L.nvca_ctx_set_sum_policy.argtypes = [vp, C.c_int]
+    L.nvca_ctx_synchronize.argtypes = [vp]
+    L.nvca_ctx_stream.argtypes = [vp]
+    L.nvca_ctx_stream.restype = vp
+    L.nvca_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.nvca_ctx_kernel_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.nvca_cascade_load_xml.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.nvca_cascade_load_mem.argtypes = [vp, C.c_char_p, C.c_int64, C.POINTER(vp)]
+    L.nvca_cascade_free.argtypes = [vp]
+    L.nvca_cascade_free.restype = None
+    L.nvca_cascade_info.argtypes = [vp, ip, ip, ip, ip]
+    L.nvca_cascade_dump.argtypes = [vp, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), ip, C.POINTER(C.c_float)]
+    L.nvca_bgr2gray.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.nvca_resize_linear.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.nvca_equalize_hist.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.nvca_integral.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.nvca_detect_multiscale.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, ip]
+    L.nvca_detect_raw.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.POINTER(Rect), C.c_int, ip]
+    L.nvca_group_rectangles.argtypes = [vp, C.POINTER(Rect), C.c_int, C.c_int, C.c_double, ip]
+    L.nvca_face_params_default.argtypes = [C.POINTER(FaceParams)]
+    L.nvca_face_params_default.restype = None
+    L.nvca_face_stream_create.argtypes = [vp, vp, C.POINTER(FaceParams), C.POINTER(vp)]
+    L.nvca_face_stream_destroy.argtypes = [vp]
+    L.nvca_face_stream_destroy.restype = None
+    L.nvca_face_stream_set_params.argtypes = [vp, C.POINTER(FaceParams)]
+    L.nvca_face_stream_motion_event.argtypes = [vp]
+    L.nvca_face_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), ip, C.c_int, ip]
+    L.nvca_face_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(Rect), ip, C.c_int, ip]
+    L.nvca_tracker_params_default.argtypes = [C.POINTER(TrackerParams)]
+    L.nvca_tracker_params_default.restype = None
+    L.nvca_tracker_create.argtypes = [vp, C.POINTER(TrackerParams), C.POINTER(vp)]
+    L.nvca_tracker_destroy.argtypes = [vp]
+    L.nvca_tracker_destroy.restype = None
+    L.nvca_tracker_set_params.argtypes = [vp, C.POINTER(TrackerParams)]
+    L.nvca_tracker_process.argtypes = [vp, C.POINTER(Frame), C.c_double, C.POINTER(Rect), C.c_int, ip]
+    L.nvca_tracker_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(C.c_double),
+                                             C.POINTER(Rect), C.c_int, ip]
+    _lib = L
+    return L
+
+
+def _rects(buf, n):
+    return np.array([[buf[i].x, buf[i].y, buf[i].w, buf[i].h] for i in range(n)], dtype=np.int32).reshape(n, 4)
+
+
+class Context:
+    """nvca_ctx: one per GPU."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.nvca_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise NvcaError(rc, "nvca_ctx_create failed (no HIP device? this library has no CPU fallback)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != OK:
+            raise NvcaError(rc, self.L.nvca_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.nvca_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_hit_capacity(self, cap):
+        self.check(self.L.nvca_ctx_set_hit_capacity(self.h, cap))
+
+    def set_sum_policy(self, policy):
+        self.check(self.L.nvca_ctx_set_sum_policy(self.h, policy))
+
+    def synchronize(self):
+        self.check(self.L.nvca_ctx_synchronize(self.h))
+
+    def enable_kernel_timing(self, on=True):
+        self.check(self.L.nvca_ctx_enable_kernel_timing(self.h, int(on)))
+
+    def kernel_timing(self):
+        ms = (C.c_double * K_COUNT)()
+        n = (C.c_int64 * K_COUNT)()
+        self.check(self.L.nvca_ctx_kernel_timing(self.h, ms, n))
+        return {self.L.nvca_kernel_name(k).decode(): (ms[k], n[k]) for k in range(K_COUNT) if n[k]}
+
+    # ---- cascade
+    def load_cascade_xml(self, text):
+        if isinstance(text, str):
+            text = text.encode()
+        h = C.c_void_p()
+        self.check(self.L.nvca_cascade_load_mem(self.h, text, len(text), C.byref(h)))
+        return Cascade(self, h)
+
+    def load_cascade_file(self, path):
+        h = C.c_void_p()
+        self.check(self.L.nvca_cascade_load_xml(self.h, path.encode(), C.byref(h)))
+        return Cascade(self, h)
+
+    # ---- primitives on host numpy arrays
+    def bgr2gray(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, cn = img.shape
+        out = np.empty((h, w), np.uint8)
+        self.check(self.L.nvca_bgr2gray(self.h, img.ctypes.data, w, h, img.strides[0], cn, MEM_HOST, out.ctypes.data, w))
+        return out
+
+    def resize_linear(self, img, dw, dh):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty((dh, dw), np.uint8)
+        self.check(self.L.nvca_resize_linear(self.h, img.ctypes.data, w, h, img.strides[0], 1, MEM_HOST, out.ctypes.data,
+                                             dw, dh, dw))
+        return out
+
+    def equalize_hist(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty_like(img)
+        self.check(self.L.nvca_equalize_hist(self.h, img.ctypes.data, w, h, img.strides[0], MEM_HOST, out.ctypes.data, w))
+        return out
+
+    def integral(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        s = np.empty((h + 1, w + 1), np.int32)
+        q = np.empty((h + 1, w + 1), np.float64)
+        self.check(self.L.nvca_integral(self.h, img.ctypes.data, w, h, img.strides[0], MEM_HOST,
+                                        s.ctypes.data_as(C.POINTER(C.c_int32)), q.ctypes.data_as(C.POINTER(C.c_double))))
+        return s, q
+
+    def detect_multiscale(self, casc, gray, scale_factor=1.1, min_neighbors=3, flags=0, min_size=(0, 0),
+                          max_size=(0, 0), cap=4096):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        buf = (Rect * cap)()
+        n = C.c_int()
+        self.check(self.L.nvca_detect_multiscale(self.h, casc.h, gray.ctypes.data, w, h, gray.strides[0], MEM_HOST,
+                                                 scale_factor, min_neighbors, flags, min_size[0], min_size[1],
+                                                 max_size[0], max_size[1], buf, cap, C.byref(n)))
+        return _rects(buf, min(n.value, cap))
+
+    def detect_raw(self, casc, gray, scale_factor=1.1, flags=0, min_size=(0, 0), max_size=(0, 0), cap=1 << 18):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        buf = (Rect * cap)()
+        n = C.c_int()
+        self.check(self.L.nvca_detect_raw(self.h, casc.h, gray.ctypes.data, w, h, gray.strides[0], MEM_HOST, scale_factor,
+                                          flags, min_size[0], min_size[1], max_size[0], max_size[1], buf, cap, C.byref(n)))
+        return _rects(buf, min(n.value, cap))
+
+    def group_rectangles(self, rects, group_threshold, eps=0.2):
+        rects = np.asarray(rects, np.int32).reshape(-1, 4)
+        buf = (Rect * max(len(rects), 1))()
+        for i, r in enumerate(rects):
+            buf[i] = Rect(*[int(v) for v in r])
+        n = C.c_int()
+        self.check(self.L.nvca_group_rectangles(self.h, buf, len(rects), group_threshold, eps, C.byref(n)))
+        return _rects(buf, n.value)
+
+    # ---- batched frontend
+    def face_batch_process(self, streams, frames, cap=64):
+        """frames: list of Frame (see make_frame); streams: list of FaceStream (same length)."""
+        n = len(frames)
+        sh = (C.c_void_p * n)(*[s.h for s in streams])
+        fr = (Frame * n)(*frames)
+        out = (Rect * (n * cap))()
+        ids = (C.c_int * (n * cap))()
+        cnt = (C.c_int * n)()
+        self.check(self.L.nvca_face_batch_process(self.h, n, sh, fr, out, ids, cap, cnt))
+        res = []
+        for i in range(n):
+            k = min(cnt[i], cap)
+            boxes = np.array([[out[i * cap + j].x, out[i * cap + j].y, out[i * cap + j].w, out[i * cap + j].h]
+                              for j in range(k)], np.int32).reshape(k, 4)
+            res.append((boxes, np.array(ids[i * cap:i * cap + k], np.int32)))
+        return res
+
+
+class Cascade:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.L.nvca_cascade_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def dump(self):
+        ow, oh, ns, nw = self.info()
+        rects = np.zeros((nw, 3, 4), np.int32)
+        wts = np.zeros((nw, 3), np.float32)
+        thr, lv, rv = np.zeros(nw, np.float32), np.zeros(nw, np.float32), np.zeros(nw, np.float32)
+        ss, st = np.zeros(ns, np.int32), np.zeros(ns, np.float32)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        self.ctx.check(self.ctx.L.nvca_cascade_dump(self.h, rects.ctypes.data_as(ip), wts.ctypes.data_as(fp),
+                                                    thr.ctypes.data_as(fp), lv.ctypes.data_as(fp), rv.ctypes.data_as(fp),
+                                                    ss.ctypes.data_as(ip), st.ctypes.data_as(fp)))
+        return dict(size=(ow, oh), rects=rects, weights=wts, thr=thr, left=lv, right=rv, stage_sizes=ss, stage_thr=st)
+
+    def free(self):
+        if self.h:
+            self.ctx.L.nvca_cascade_free(self.h)
+            self.h = None
+
+
+def make_frame(arr_or_ptr, width=None, height=None, stride=None, mem=MEM_HOST, pts=0):
+    """Frame from a numpy HxWxC uint8 array (host) or a raw device pointer."""
+    if isinstance(arr_or_ptr, np.ndarray):
+        a = arr_or_ptr
+        assert a.dtype == np.uint8 and a.flags.c_contiguous
+        f = Frame(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], MEM_HOST, pts)
+        f._keep = a
+        return f
+    return Frame(int(arr_or_ptr), width, height, stride, mem, pts)
+
+
+class FaceStream:
+    """nvca_face_stream: mirrors one `nubofacedetector` element instance
+    (properties of FACE/kmsfacedetect.cpp:1043-1102 by their reference names)."""
+
+    PROPS = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4",
+             "multi_scale_factor": "scale_factor_pct", "track_threshold": "track_threshold",
+             "euclidean_distance": "euclidean_threshold", "area_threshold": "area_threshold",
+             "min_neighbors": "min_neighbors", "detect_event": "detect_event"}
+
+    def __init__(self, ctx, cascade, **props):
+        self.ctx, self.cascade = ctx, cascade
+        self.p = FaceParams()
+        ctx.L.nvca_face_params_default(C.byref(self.p))
+        for k, v in props.items():
+            setattr(self.p, self.PROPS[k], int(v))
+        h = C.c_void_p()
+        ctx.check(ctx.L.nvca_face_stream_create(ctx.h, cascade.h, C.byref(self.p), C.byref(h)))
+        self.h = h
+
+    def set_property(self, name, value):
+        setattr(self.p, self.PROPS[name], int(value))
+        self.ctx.check(self.ctx.L.nvca_face_stream_set_params(self.h, C.byref(self.p)))
+
+    def motion_event(self):
+        self.ctx.check(self.ctx.L.nvca_face_stream_motion_event(self.h))
+
+    def process(self, bgr, cap=64):
+        """One transform_frame_ip on a host BGR frame -> (boxes[n,4], ids[n])."""
+        return self.ctx.face_batch_process([self], [make_frame(np.ascontiguousarray(bgr, np.uint8))], cap)[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.nvca_face_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,274 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Bit-exact everywhere (integer / byte / index work;
+the f32/f64 comparisons inside the cascade are reproduced operation by
+operation, so raw candidate lists must be identical, in order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from nubovca import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def casc(ctx, synth_xml):
+    return ctx.load_cascade_xml(synth_xml)
+
+
+@pytest.fixture(scope="module")
+def casc_small(ctx, small_xml):
+    return ctx.load_cascade_xml(small_xml)
+
+
+# ------------------------------------------------------------------ loader
+def test_loader_matches_python_reader(casc, orc_cascade):
+    d = casc.dump()
+    assert d["size"] == (orc_cascade.ow, orc_cascade.oh)
+    assert np.array_equal(d["stage_sizes"], orc_cascade.stage_ncls)
+    assert np.array_equal(d["stage_thr"], orc_cascade.stage_thr)
+    assert np.array_equal(d["rects"], orc_cascade.rects)
+    assert np.array_equal(d["weights"], orc_cascade.rweights)
+    assert np.array_equal(d["thr"], orc_cascade.node_thr)
+    assert np.array_equal(d["left"], orc_cascade.alpha[0::2])
+    assert np.array_equal(d["right"], orc_cascade.alpha[1::2])
+
+
+def test_loader_rejects_garbage(ctx):
+    from nubovca import capi
+    for bad in ("", "<opencv_storage></opencv_storage>", "<a><b></a>", "not xml at all"):
+        with pytest.raises(capi.NvcaError):
+            ctx.load_cascade_xml(bad or " ")
+
+
+# ------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("w,h,cn", [(1, 1, 3), (7, 5, 3), (64, 64, 3), (161, 33, 3), (640, 480, 3), (1920, 1080, 3),
+                                    (333, 77, 4), (1280, 720, 4)])
+def test_bgr2gray(ctx, w, h, cn):
+    import orc
+    img = np.random.default_rng(w * h + cn).integers(0, 256, size=(h, w, cn), dtype=np.uint8)
+    assert np.array_equal(ctx.bgr2gray(img), orc.bgr2gray(img))
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 160, 120), (1920, 1080, 160, 90), (1280, 720, 320, 180),
+                                         (640, 480, 320, 240), (100, 80, 100, 80), (97, 61, 41, 29), (50, 40, 120, 90),
+                                         (1920, 1080, 640, 360), (33, 2, 7, 1)])
+def test_resize_gray(ctx, sw, sh, dw, dh):
+    import orc
+    img = np.random.default_rng(sw + dw).integers(0, 256, size=(sh, sw), dtype=np.uint8)
+    assert np.array_equal(ctx.resize_linear(img, dw, dh), orc.resize_linear(img, dw, dh))
+
+
+@pytest.mark.parametrize("w,h,kind", [(160, 90, "natural"), (640, 480, "noise"), (1920, 1080, "natural"),
+                                      (333, 77, "gradient"), (64, 64, "flat"), (5, 3, "noise")])
+def test_equalize_hist(ctx, w, h, kind):
+    import orc
+    from nubovca import synth
+    img = synth.make_gray(w, h, 5, kind)
+    assert np.array_equal(ctx.equalize_hist(img), orc.equalize_hist(img))
+
+
+def test_equalize_lut_division_sweep(ctx):
+    """every LUT entry goes through a device f32 divide + multiply + round: sweep many totals."""
+    import orc
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        w, h = int(rng.integers(8, 400)), int(rng.integers(8, 300))
+        lo, hi = sorted(rng.integers(0, 256, size=2))
+        img = rng.integers(lo, hi + 1, size=(h, w)).astype(np.uint8)
+        assert np.array_equal(ctx.equalize_hist(img), orc.equalize_hist(img))
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (64, 16), (65, 17), (640, 480), (1920, 1080), (2047, 20), (2048, 20),
+                                 (2500, 37), (4100, 33)])
+def test_integral(ctx, w, h):
+    import orc
+    img = np.random.default_rng(w + h).integers(0, 256, size=(h, w), dtype=np.uint8)
+    s, q = ctx.integral(img)
+    es, eq = orc.integral(img)
+    assert np.array_equal(s, es)
+    assert np.array_equal(q, eq)
+
+
+def test_integral_all_white_1080p(ctx):
+    img = np.full((1080, 1920), 255, np.uint8)
+    s, q = ctx.integral(img)
+    assert s[-1, -1] == 255 * 1920 * 1080 and q[-1, -1] == 255.0 * 255 * 1920 * 1080
+
+
+# ------------------------------------------------------------------ detectMultiScale
+CASES = [
+    (160, 120, "natural", [(40, 30, 60)], 1.25, (8, 6)),
+    (320, 240, "natural", [(60, 40, 100), (200, 120, 50)], 1.1, (16, 12)),
+    (640, 480, "noise", [(100, 80, 120)], 1.1, (32, 24)),
+    (640, 480, "gradient", [(100, 80, 120), (300, 200, 60)], 1.2, (0, 0)),
+    (333, 251, "natural", [(30, 20, 90)], 1.1, (0, 0)),
+    (1280, 720, "natural", [(200, 150, 300), (900, 400, 180)], 1.1, (64, 36)),
+]
+
+
+@pytest.mark.parametrize("w,h,kind,faces,sf,ms", CASES)
+def test_detect_raw_and_grouped(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms):
+    import orc
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(w, h, 3, kind, faces))
+    raw = ctx.detect_raw(casc, g, sf, 0, ms)
+    eraw = orc.detect_raw(orc_cascade, g, sf, 0, ms)
+    assert np.array_equal(raw, eraw), (len(raw), len(eraw))
+    assert len(eraw) > 0
+    det = ctx.detect_multiscale(casc, g, sf, 3, 0, ms)
+    edet = orc.detect_multiscale(orc_cascade, g, sf, 3, 0, ms)
+    assert np.array_equal(det, edet)
+
+
+def test_detect_1080p_fullres(ctx, casc, orc_cascade):
+    """BASELINE config 2 geometry: 1920x1080, sf 1.1, minSize (96,54): 25 scales."""
+    import orc
+    from nubovca import synth
+    faces = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
+    g = orc.equalize_hist(synth.make_gray(1920, 1080, 3, "natural", faces))
+    raw = ctx.detect_raw(casc, g, 1.1, 0, (96, 54))
+    eraw, st = orc.detect_raw(orc_cascade, g, 1.1, 0, (96, 54), return_stats=True)
+    assert st.n_scales == 25
+    assert np.array_equal(raw, eraw)
+    det = ctx.detect_multiscale(casc, g, 1.1, 3, 0, (96, 54))
+    assert np.array_equal(det, orc.detect_multiscale(orc_cascade, g, 1.1, 3, 0, (96, 54)))
+    assert len(det) == 4
+
+
+def test_detect_lenient_cascade_many_hits(ctx, casc_small, orc_small):
+    """a 6-stage cascade lets thousands of windows through: stresses the queue / candidate path."""
+    import orc
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(400, 300, 8, "gradient", [(50, 40, 150)]))
+    raw = ctx.detect_raw(casc_small, g, 1.1, 0, (0, 0))
+    eraw = orc.detect_raw(orc_small, g, 1.1, 0, (0, 0))
+    assert len(eraw) > 100
+    assert np.array_equal(raw, eraw)
+    det = ctx.detect_multiscale(casc_small, g, 1.1, 3, 0, (0, 0))
+    assert np.array_equal(det, orc.detect_multiscale(orc_small, g, 1.1, 3, 0, (0, 0)))
+
+
+def test_detect_f64_policy(ctx, casc, orc_cascade):
+    import orc
+    from nubovca import capi, synth
+    g = orc.equalize_hist(synth.make_gray(320, 240, 12, "natural", [(60, 40, 100)]))
+    ctx.set_sum_policy(capi.SUM_F64)
+    try:
+        raw = ctx.detect_raw(casc, g, 1.1, 0, (0, 0))
+    finally:
+        ctx.set_sum_policy(capi.SUM_F32PAIR)
+    assert np.array_equal(raw, orc.detect_raw(orc_cascade, g, 1.1, 0, (0, 0), policy=orc.SUM_F64))
+
+
+def test_detect_degenerate_images(ctx, casc, orc_cascade):
+    import orc
+    for img in (np.zeros((60, 80), np.uint8), np.full((31, 31), 200, np.uint8), np.zeros((25, 400), np.uint8)):
+        assert np.array_equal(ctx.detect_raw(casc, img, 1.1, 0, (0, 0)), orc.detect_raw(orc_cascade, img, 1.1, 0, (0, 0)))
+
+
+def test_hit_capacity_overflow_is_loud(ctx, casc_small):
+    import orc
+    from nubovca import capi, synth
+    g = orc.equalize_hist(synth.make_gray(400, 300, 8, "gradient", [(50, 40, 150)]))
+    ctx.set_hit_capacity(16)
+    try:
+        with pytest.raises(capi.NvcaError) as e:
+            ctx.detect_raw(casc_small, g, 1.1, 0, (0, 0))
+        assert e.value.code == capi.ERR_OVERFLOW
+    finally:
+        ctx.set_hit_capacity(16384)
+
+
+def test_group_rectangles_abi(ctx):
+    import orc
+    rng = np.random.default_rng(1)
+    base = rng.integers(0, 300, size=(12, 2))
+    rects = []
+    for bx, by in base:
+        for _ in range(int(rng.integers(1, 9))):
+            s = int(rng.integers(30, 34))
+            rects.append([bx + int(rng.integers(-2, 3)), by + int(rng.integers(-2, 3)), s, s])
+    rects = np.array(rects, np.int32)[rng.permutation(len(rects))]
+    for thr in (0, 1, 2, 3):
+        exp, _ = orc.group_rectangles(rects, thr)
+        assert np.array_equal(ctx.group_rectangles(rects, thr), exp)
+
+
+# ------------------------------------------------------------------ NuboFaceDetector stream
+def _sequence(W, H, n, seed0):
+    from nubovca import synth
+    frames = []
+    for i in range(n):
+        if i % 5 == 3:
+            frames.append(synth.make_bgr(W, H, seed0 + i, "natural"))          # no face
+        else:
+            x = 40 + 6 * i
+            frames.append(synth.make_bgr(W, H, seed0 + i, "natural", [(x, H // 6, H // 2)]))
+    return frames
+
+
+@pytest.mark.parametrize("W,H,props", [
+    (640, 480, {}),                                                   # BASELINE config 1: w2p 160 -> 160x120, sf 1.25
+    (1280, 720, {"width_to_process": 320}),
+    (320, 240, {"width_to_process": 320, "multi_scale_factor": 10}),  # full-res mode
+    (640, 480, {"process_x_every_4_frames": 2}),
+    (640, 480, {"process_x_every_4_frames": 3, "width_to_process": 213}),
+    (322, 242, {"width_to_process": 161}),                            # exact 2x -> area-fast resize
+])
+def test_face_stream_sequence(ctx, casc, orc_cascade, W, H, props):
+    import orc
+    from nubovca import capi
+    kw = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4",
+          "multi_scale_factor": "scale_factor_pct"}
+    fs = capi.FaceStream(ctx, casc, **props)
+    ofs = orc.FaceStream(orc_cascade, **{kw[k]: v for k, v in props.items()})
+    seen = 0
+    for f in _sequence(W, H, 12, 100):
+        boxes, ids = fs.process(f)
+        eb, eid = ofs.process(f)
+        assert np.array_equal(boxes, eb), (boxes, eb)
+        assert np.array_equal(ids, eid)
+        seen += len(eb)
+    assert seen > 0
+    fs.close()
+
+
+def test_face_batch_equals_sequential(ctx, casc, orc_cascade):
+    """3 streams x 6 frames interleaved in ONE batched call == each stream run alone on the oracle."""
+    import orc
+    from nubovca import capi
+    W, H = 640, 480
+    seqs = [_sequence(W, H, 6, 1000 * s) for s in range(3)]
+    streams = [capi.FaceStream(ctx, casc) for _ in range(3)]
+    order = [(s, i) for i in range(6) for s in range(3)]
+    res = ctx.face_batch_process([streams[s] for s, _ in order], [capi.make_frame(seqs[s][i]) for s, i in order])
+    for s in range(3):
+        ofs = orc.FaceStream(orc_cascade)
+        for i in range(6):
+            eb, eid = ofs.process(seqs[s][i])
+            boxes, ids = res[order.index((s, i))]
+            assert np.array_equal(boxes, eb) and np.array_equal(ids, eid)
+
+
+def test_face_stream_device_frames(ctx, casc, orc_cascade):
+    """frames already resident in HBM (torch tensors) give the same boxes as host frames."""
+    import orc
+    import torch
+    from nubovca import capi
+    W, H = 640, 480
+    frames = _sequence(W, H, 4, 7)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    fs = capi.FaceStream(ctx, casc)
+    ofs = orc.FaceStream(orc_cascade)
+    fr = [capi.make_frame(d.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for d in dev]
+    res = ctx.face_batch_process([fs] * 4, fr)
+    for i in range(4):
+        eb, eid = ofs.process(frames[i])
+        assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid)
