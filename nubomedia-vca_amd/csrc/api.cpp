@@ -101,7 +101,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -112,6 +112,7 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_stages, stages.data(), stages.size() * sizeof(StageRec)},
         {&d_strips, strips.data(), strips.size() * sizeof(StripRec)},
         {&d_pos, pos.data(), pos.size() * sizeof(int)},
+        {&d_order, order.data(), order.size() * sizeof(int)},
     };
     for (auto &it : items) {
         if (it.n == 0) continue;
@@ -197,10 +198,11 @@ static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::
         a.sum_slot = gp.g.sum_slot; a.spitch = gp.g.spitch;
         a.scales = dp.d_scales.as<ScaleRec>(); a.stumps = dp.d_stumps.as<StumpRec>();
         a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
+        a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
         a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
         TimedLaunch t(ctx, NVCA_K_CASCADE);
-        launch_cascade_sc(ctx->stream, a, (int)dp.strips.size(), batch);
+        launch_cascade_sc(ctx->stream, a, batch);
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     // one D2H covers the count and (almost always) every candidate

@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
     __shared__ unsigned gbase_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.y;
-    const StripRec strip = a.strips[blockIdx.x];
+    // 1-D grid, frame-major: frames are worked through in dispatch order (few integral planes live
+    // at a time), and within a frame slot%8 (= XCD) selects a contiguous equal-work run of strips
+    const int slot = blockIdx.x / a.blocks_per_frame;
+    const int sidx = a.order[blockIdx.x - slot * a.blocks_per_frame];
+    if (sidx < 0) return;
+    const StripRec strip = a.strips[sidx];
     const ScaleRec &sc = a.scales[strip.scale];
     const int endX = sc.endX, nwin = strip.nrows * endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
     }
 }
 
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int nstrips, int batch)
+void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch)
 {
-    if (nstrips <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(k_cascade_sc, dim3(nstrips, batch), dim3(256), 0, st, a);
+    if (a.blocks_per_frame <= 0 || batch <= 0) return;
+    hipLaunchKernelGGL(k_cascade_sc, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
 }
 
 } // namespace nvca

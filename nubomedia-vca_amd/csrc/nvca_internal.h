@@ -65,7 +65,7 @@ struct ScaleRec {           // one evaluated scale
 
 struct StripRec { int scale, iy0, nrows, pad; };   // a block's share of the scan
 
-static constexpr int kStripMaxWin = 2048;  // windows per strip (LDS budget of the evaluator)
+static constexpr int kStripMaxWin = 512;   // windows per strip (LDS budget of the evaluator)
 static constexpr int kIntegralBand = 16;   // rows per integral band
 
 // resize tables (cv::resize INTER_LINEAR 8U fixed point)
@@ -180,10 +180,11 @@ struct CascadeArgs {
     int spitch;
     const ScaleRec *scales; const StumpRec *stumps; const StageRec *stages;
     const StripRec *strips; const int *pos;
+    const int *order; int blocks_per_frame;   // dispatch slot -> strip
     int nstages; int pair_policy;  // 1 = F32PAIR
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
 };
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int nstrips, int batch);
+void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch);
 
 } // namespace nvca

@@ -160,7 +160,28 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
             strips.push_back(st);
         }
     }
-    // heavy strips first: small scales have the most windows per strip
+    // Dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), each with
+    // its own 4 MiB L2.  Give every XCD one contiguous run of strips (scale-major, then y) of about equal
+    // window count, so that the integral rows an XCD gathers from stay resident in its L2
+    // (placement only changes speed, never results).
+    {
+        long long total = 0;
+        for (const StripRec &st : strips) total += (long long)st.nrows * scales[st.scale].endX;
+        std::vector<int> start(9, (int)strips.size());
+        start[0] = 0;
+        long long acc = 0; int k = 1;
+        for (size_t i = 0; i < strips.size() && k < 8; i++) {
+            acc += (long long)strips[i].nrows * scales[strips[i].scale].endX;
+            while (k < 8 && acc * 8 >= total * k) { start[k] = (int)i + 1; k++; }
+        }
+        for (; k < 8; k++) start[k] = (int)strips.size();
+        int maxlen = 0;
+        for (int x = 0; x < 8; x++) maxlen = std::max(maxlen, start[x + 1] - start[x]);
+        blocks_per_frame = 8 * maxlen;
+        order.assign(blocks_per_frame, -1);
+        for (int x = 0; x < 8; x++)
+            for (int j = 0; j < start[x + 1] - start[x]; j++) order[j * 8 + x] = start[x] + j;
+    }
     return NVCA_OK;
 }
 

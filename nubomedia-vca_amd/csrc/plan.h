@@ -18,8 +18,10 @@ struct DetectPlan {
     std::vector<StageRec> stages;
     std::vector<StripRec> strips;
     std::vector<int> pos;
+    std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
+    int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order;
 
     int build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                             int minw, int minh, int maxw, int maxh, std::string &err);
