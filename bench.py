@@ -38,7 +38,7 @@ def algorithmic_bytes(W, H, w, h, n_boxes=0):
     gray = 3 * W * H + w * h                           # BGR in, gray out
     integral = w * h + 12 * (w + 1) * (h + 1)          # gray in, sum i32 + sqsum 8 B out
     cascade = 12 * (w + 1) * (h + 1) + 16 * n_boxes    # integral pair read once, boxes out
-    return {"gray_resize_hist": gray, "integral": integral, "cascade_eval": cascade,
+    return {"gray_resize_hist": gray, "integral": integral, "cascade": cascade,
             "total": gray + integral + cascade}
 
 
@@ -156,7 +156,8 @@ def main():
         fps = total_frames / dt
         ab = algorithmic_bytes(W, H, w, h, n_boxes)
         groups = {"gray_resize_hist": ["gray_resize_hist"], "equalize_lut": ["equalize_lut"],
-                  "integral": ["integral_colsum", "integral_bandscan", "integral_rows"], "cascade_eval": ["cascade_eval"]}
+                  "integral": ["integral_colsum", "integral_bandscan", "integral_rows"],
+                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep"]}
         kern = {}
         for gname, members in groups.items():
             ms = sum(ktimes.get(m, (0.0, 0))[0] for m in members)
@@ -182,7 +183,8 @@ def main():
                         "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                         "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
                         "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
-                        "kernels": kern}
+                        "kernels": kern,
+                        "detail_ms_per_launch": {k: v[0] / v[1] for k, v in ktimes.items() if v[1]}}
         out = {
             "metric": "1080p frames/sec/node (NuboFaceDetector); achieved HBM GB/s vs peak",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

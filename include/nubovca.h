@@ -80,16 +80,19 @@ void *nvca_ctx_stream(nvca_ctx *ctx);
 
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,
  * every kernel launch is bracketed by events; nvca_ctx_kernel_timing drains them. */
-#define NVCA_K_GRAY      0  /* resize + BGR2GRAY + histogram   */
-#define NVCA_K_LUT       1  /* equalizeHist LUT                */
-#define NVCA_K_COLSUM    2  /* integral: band column sums      */
-#define NVCA_K_BANDSCAN  3  /* integral: scan over bands       */
-#define NVCA_K_INTEGRAL  4  /* integral: row scan + write      */
-#define NVCA_K_CASCADE   5  /* cascade evaluator               */
-#define NVCA_K_GROUP     6  /* candidate sort + groupRectangles*/
-#define NVCA_K_TRACKER   7  /* tracker pixel pass + labelling  */
-#define NVCA_K_RESIZE1   8  /* 8UC1 resize (pyramid / parts)   */
-#define NVCA_K_COUNT     9
+#define NVCA_K_GRAY      0  /* resize + BGR2GRAY + histogram            */
+#define NVCA_K_LUT       1  /* equalizeHist LUT                         */
+#define NVCA_K_COLSUM    2  /* integral: band column sums               */
+#define NVCA_K_BANDSCAN  3  /* integral: scan over bands                */
+#define NVCA_K_INTEGRAL  4  /* integral: row scan + write               */
+#define NVCA_K_STAGE0    5  /* cascade: variance + stage 0, all windows */
+#define NVCA_K_STRIP     6  /* cascade: early stages, window per lane   */
+#define NVCA_K_DEEP      7  /* cascade: late stages, stump per lane     */
+#define NVCA_K_GROUP     8  /* candidate sort + groupRectangles         */
+#define NVCA_K_TRACKER   9  /* tracker pixel pass + labelling           */
+#define NVCA_K_RESIZE1  10  /* 8UC1 resize (pyramid / parts)            */
+#define NVCA_K_TILE     11  /* cascade: early stages from LDS-staged tiles */
+#define NVCA_K_COUNT    12
 int  nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on);
 /* total_ms[NVCA_K_COUNT], launches[NVCA_K_COUNT]; resets the accumulators */
 int  nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches);

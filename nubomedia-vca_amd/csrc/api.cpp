@@ -79,12 +79,13 @@ static inline int cv_round(double v)
 }
 
 struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep;
     PinnedBuf h_hits, h_srcptrs;
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
         sqsum.release(); hits.release(); srcptrs.release(); staging.release(); aux.release();
+        failbits.release(); vnf.release(); deep.release();
         h_hits.release(); h_srcptrs.release();
     }
 };
@@ -101,7 +102,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_stumps_lds.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -113,6 +114,10 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_strips, strips.data(), strips.size() * sizeof(StripRec)},
         {&d_pos, pos.data(), pos.size() * sizeof(int)},
         {&d_order, order.data(), order.size() * sizeof(int)},
+        {&d_tasks, tasks.data(), tasks.size() * sizeof(unsigned)},
+        {&d_tiles, tiles.data(), tiles.size() * sizeof(TileRec)},
+        {&d_tile_order, tile_order.data(), tile_order.size() * sizeof(int)},
+        {&d_stumps_lds, stumps_lds.data(), stumps_lds.size() * sizeof(StumpRec)},
     };
     for (auto &it : items) {
         if (it.n == 0) continue;
@@ -191,18 +196,32 @@ static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::
     DetectPlan &dp = gp.det;
     raw.assign(batch, {});
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
+    const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * batch + 64, 1u << 28);   // every window may survive
+    if (ws.failbits.ensure(dp.tasks.size() * sizeof(unsigned long long) * batch + 8) ||
+        ws.vnf.ensure(dp.tasks.size() * 64 * sizeof(double) * batch + 8) ||
+        ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long))) {
+        ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
+    }
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hits.p, 0, sizeof(unsigned long long), ctx->stream));
-    if (!dp.strips.empty()) {
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (!dp.tasks.empty()) {
         CascadeArgs a;
         a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
         a.sum_slot = gp.g.sum_slot; a.spitch = gp.g.spitch;
         a.scales = dp.d_scales.as<ScaleRec>(); a.stumps = dp.d_stumps.as<StumpRec>();
         a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
+        a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
+        a.failbits = ws.failbits.as<unsigned long long>(); a.vnf = ws.vnf.as<double>();
         a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
+        a.deep_stage = dp.deep_stage; a.deep = ws.deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
-        TimedLaunch t(ctx, NVCA_K_CASCADE);
-        launch_cascade_sc(ctx->stream, a, batch);
+        { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
+        a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
+        a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.stumps_lds = dp.d_stumps_lds.as<StumpRec>();
+        { TimedLaunch t(ctx, NVCA_K_TILE); launch_cascade_sc(ctx->stream, a, batch, 3); }
+        { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
+        { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     // one D2H covers the count and (almost always) every candidate
@@ -383,7 +402,8 @@ int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
 const char *nvca_kernel_name(int k)
 {
     static const char *names[NVCA_K_COUNT] = {"gray_resize_hist", "equalize_lut", "integral_colsum", "integral_bandscan",
-                                              "integral_rows", "cascade_eval", "group_rects", "tracker", "resize_gray"};
+                                              "integral_rows", "cascade_stage0", "cascade_strip", "cascade_deep",
+                                              "group_rects", "tracker", "resize_gray", "cascade_tile"};
     return (k >= 0 && k < NVCA_K_COUNT) ? names[k] : "?";
 }
 

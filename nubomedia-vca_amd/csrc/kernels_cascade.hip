@@ -4,73 +4,146 @@
 // (OpenCV 2.4 haar.cpp) behind cascade->detectMultiScale at
 // FACE/kmsfacedetect.cpp:809-811.
 //
-// One workgroup = one strip (a few scan rows of one scale, <= 2048 windows):
-//   A. stage 0 + window variance for EVERY window of the strip (dense, one
-//      window per lane); stage-0 rejects are recorded as a bit string.
-//   B. OpenCV's adaptive x step (ix += result != 0 ? 1 : 2) is resolved in closed
-//      form: window j is visited iff the run of stage-0 rejects immediately before
-//      it in its row has even length.  Visited survivors are compacted into LDS.
-//   C. later stages run on the compacted queue, re-compacted after every stage, so
-//      lanes stay dense while most windows die early.
-// Stage/rect tables are wave-uniform -> scalar loads; window sums are gathers
-// from the integral planes (L2 / Infinity Cache resident).  No MFMA: integer
-// rect sums, f32 products, f64 stage sums, exactly the reference's arithmetic
-// (compiled with -ffp-contract=off).
+// Three launches per batch of frames:
+//  K5a k_stage0      every window of every scale, one lane per window, 64 consecutive
+//                    x positions per wave: window variance + stage 0.  Writes the
+//                    stage-0 reject bits (one u64 per wave task) and the variance
+//                    normaliser.  OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
+//                    is resolved later in closed form from these bits: window j is
+//                    visited iff the run of stage-0 rejects immediately left of it in
+//                    its row has even length.
+//  K5b k_strip       per strip (<= 512 windows of one scale): visited survivors are
+//                    compacted into LDS and run through the next stages one window
+//                    per lane, re-compacted after every stage; whoever survives
+//                    stage deep_stage-1 is appended to the deep list.
+//  K5c k_deep        one wave per surviving window, one stump per lane (the long
+//                    stages have 33..213 stumps): the serial 2000-stump tail of the
+//                    few face-like windows becomes ~34 wave-wide steps.
+// Stage/rect tables are wave-uniform in K5a/K5b (scalar loads) and coalesced
+// per-lane records in K5c; window sums are gathers from the integral planes.
+// No MFMA: integer rect sums, f32 products, f64 stage sums -- exactly the
+// reference's arithmetic (compiled with -ffp-contract=off).
 #include "nvca_internal.h"
 
 namespace nvca {
 
-__device__ __forceinline__ int rect_sum(const int *__restrict__ sum, int off, const int *p)
+__device__ __forceinline__ int ldsum(const int *__restrict__ sum, unsigned idx) { return sum[idx]; }
+
+__device__ __forceinline__ int rect_sum(const int *__restrict__ sum, unsigned off, const int *p)
 {
-    return sum[off + p[0]] - sum[off + p[1]] - sum[off + p[2]] + sum[off + p[3]];
+    return ldsum(sum, off + (unsigned)p[0]) - ldsum(sum, off + (unsigned)p[1]) - ldsum(sum, off + (unsigned)p[2]) +
+           ldsum(sum, off + (unsigned)p[3]);
 }
 
-// one stage on one window; recs are wave-uniform
+// feature value of one stump on one window (v) against its threshold: returns the vote
 template <bool PAIR>
-__device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, int off, double vnf,
+__device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, double vnf, const StumpRec &f)
+{
+    const int s0 = rect_sum(sum, off, f.p[0]);
+    const int s1 = rect_sum(sum, off, f.p[1]);
+    const double t = f.thr * vnf;                       // node->threshold * variance_norm_factor
+    double v;
+    if (PAIR) {
+        const float fs = (float)s0 * f.w[0] + (float)s1 * f.w[1];     // SSE2 path: f32 add
+        v = (double)fs;
+    } else {
+        v = (double)((float)s0 * f.w[0]);
+        v += (double)((float)s1 * f.w[1]);
+        if (f.nrect == 3) {
+            const int s2 = rect_sum(sum, off, f.p[2]);
+            v += (double)((float)s2 * f.w[2]);
+        }
+    }
+    return v >= t ? f.a1 : f.a0;
+}
+
+// one stage on one window per lane; recs are wave-uniform (scalar loads)
+template <bool PAIR>
+__device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned off, double vnf,
                                            const StumpRec *__restrict__ recs, int count, float stage_thr)
 {
     double stage_sum = 0.0;
-    for (int j = 0; j < count; j++) {
-        const StumpRec &f = recs[j];
-        const int s0 = rect_sum(sum, off, f.p[0]);
-        const int s1 = rect_sum(sum, off, f.p[1]);
-        const double t = (double)f.thr * vnf;
-        double v;
-        if (PAIR) {
-            const float fs = (float)s0 * f.w[0] + (float)s1 * f.w[1];
-            v = (double)fs;
-        } else {
-            v = (double)((float)s0 * f.w[0]);
-            v += (double)((float)s1 * f.w[1]);
-            if (f.nrect == 3) {
-                const int s2 = rect_sum(sum, off, f.p[2]);
-                v += (double)((float)s2 * f.w[2]);
-            }
-        }
-        stage_sum += (double)(v >= t ? f.a1 : f.a0);
-    }
+    for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR>(sum, off, vnf, recs[j]);
     return !(stage_sum < (double)stage_thr);
 }
 
-__device__ __forceinline__ bool run_stage(const int *__restrict__ sum, int off, double vnf,
+__device__ __forceinline__ bool run_stage(const int *__restrict__ sum, unsigned off, double vnf,
                                           const StumpRec *__restrict__ recs, const StageRec &st, int pair_policy)
 {
-    if (pair_policy && st.two_rects) return eval_stage<true>(sum, off, vnf, recs + st.first, st.count, st.thr);
+    if (pair_policy && (st.flags & 1)) return eval_stage<true>(sum, off, vnf, recs + st.first, st.count, st.thr);
     return eval_stage<false>(sum, off, vnf, recs + st.first, st.count, st.thr);
 }
 
-__global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
+// block -> (slot, local index): 1-D grid, frame-major (few integral planes live at a time); within a
+// frame consecutive local indices alternate over 8 contiguous chunks, i.e. blocks that share an XCD
+// (b % 8) walk one contiguous part of the scan (speed only)
+__device__ __forceinline__ bool xcd_chunk_index(int nlocal, int &slot, int &idx)
 {
-    __shared__ unsigned long long failbits[kStripMaxWin / 64];
-    __shared__ double vnf_s[kStripMaxWin];
+    const int per_frame = ((nlocal + 7) / 8) * 8;
+    slot = blockIdx.x / per_frame;
+    const int l = blockIdx.x - slot * per_frame;
+    const int chunk = per_frame / 8;
+    idx = (l & 7) * chunk + (l >> 3);
+    return idx < nlocal;
+}
+
+// ---- K5a: variance + stage 0 for every window --------------------------------
+__global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot, bidx;
+    if (!xcd_chunk_index((a.ntasks + 3) / 4, slot, bidx)) return;
+    const int t = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);
+    if (t >= a.ntasks) return;
+    const unsigned task = a.tasks[t];
+    const int s = task >> 20, iy = (task >> 7) & 8191, k = task & 127;
+    const ScaleRec &sc = a.scales[s];
+    const int ix = k * 64 + lane;
+    const bool active = ix < sc.endX;
+    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
+    const unsigned long long *__restrict__ sq = a.sqsum + (size_t)slot * a.sum_slot;
+    bool pass0 = false;
+    double vnf = 1.;
+    if (active) {
+        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * a.spitch + a.pos[sc.xpos_off + ix]);
+        const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
+        const int ws = sum[e0] - sum[e1] - sum[e2] + sum[e3];
+        const double mean = (double)ws * sc.inv_area;
+        vnf = (double)sq[e0] - (double)sq[e1] - (double)sq[e2] + (double)sq[e3];
+        vnf = vnf * sc.inv_area - mean * mean;
+        vnf = vnf >= 0. ? sqrt(vnf) : 1.;
+        pass0 = run_stage(sum, off, vnf, a.stumps + sc.stump_off, a.stages[0], a.pair_policy);
+    }
+    const unsigned long long fb = __ballot(active && !pass0);
+    const size_t o = (size_t)slot * a.ntasks + t;
+    if (lane == 0) a.failbits[o] = fb;
+    a.vnf[o * 64 + lane] = vnf;
+}
+
+// visited by OpenCV's adaptive scan?  row_bits: the row's stage-0 reject words
+__device__ __forceinline__ bool visited(const unsigned long long *__restrict__ row_bits, int ix)
+{
+    int d = 0, pos = ix;
+    while (pos > 0) {
+        const int p = pos - 1, b = p & 63;
+        const unsigned long long m = row_bits[p >> 6] << (63 - b);       // bit p at the MSB
+        const int ones = (~m == 0ull) ? 64 : __clzll((long long)~m);
+        const int lim = b + 1;
+        d += ones < lim ? ones : lim;
+        if (ones < lim) break;
+        pos -= lim;
+    }
+    return !(d & 1);
+}
+
+// ---- K5b: stages 1 .. deep_stage-1 on strips ---------------------------------
+__global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
+{
     __shared__ unsigned short q[2][kStripMaxWin];
     __shared__ int qn[2];
     __shared__ unsigned gbase_s;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // 1-D grid, frame-major: frames are worked through in dispatch order (few integral planes live
-    // at a time), and within a frame slot%8 (= XCD) selects a contiguous equal-work run of strips
+    const int tid = threadIdx.x, lane = tid & 63;
     const int slot = blockIdx.x / a.blocks_per_frame;
     const int sidx = a.order[blockIdx.x - slot * a.blocks_per_frame];
     if (sidx < 0) return;
@@ -78,58 +151,23 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
     const ScaleRec &sc = a.scales[strip.scale];
     const int endX = sc.endX, nwin = strip.nrows * endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
-    const unsigned long long *__restrict__ sq = a.sqsum + (size_t)slot * a.sum_slot;
     const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
     const int *__restrict__ xpos = a.pos + sc.xpos_off;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + strip.iy0;
-    const int e0 = sc.eq[0], e1 = sc.eq[1], e2 = sc.eq[2], e3 = sc.eq[3];
-    const double inv_area = sc.inv_area;
-    const StageRec st0 = a.stages[0];
+    const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)strip.iy0 * sc.wpr;
+    const double *__restrict__ vnfp = a.vnf + ((size_t)slot * a.ntasks + sc.task_off + (size_t)strip.iy0 * sc.wpr) * 64;
 
     if (tid < 2) qn[tid] = 0;
-
-    // ---- A: variance + stage 0, dense
-    for (int base = 0; base < nwin; base += 256) {
-        const int w = base + tid;
-        const bool active = w < nwin;
-        bool pass0 = false;
-        if (active) {
-            const int r = w / endX, ix = w - r * endX;
-            const int off = ypos[r] * a.spitch + xpos[ix];
-            const int ws = sum[off + e0] - sum[off + e1] - sum[off + e2] + sum[off + e3];
-            const double mean = (double)ws * inv_area;
-            double vnf = (double)sq[off + e0] - (double)sq[off + e1] - (double)sq[off + e2] + (double)sq[off + e3];
-            vnf = vnf * inv_area - mean * mean;
-            vnf = vnf >= 0. ? sqrt(vnf) : 1.;
-            vnf_s[w] = vnf;
-            pass0 = run_stage(sum, off, vnf, recs, st0, a.pair_policy);
-        }
-        const unsigned long long fb = __ballot(active && !pass0);
-        if (lane == 0) failbits[(base >> 6) + wave] = fb;
-    }
     __syncthreads();
 
-    // ---- B: adaptive-step reachability + compaction of visited survivors
+    // adaptive-step reachability + compaction of visited stage-0 survivors
     for (int base = 0; base < nwin; base += 256) {
         const int w = base + tid;
         bool keep = false;
         if (w < nwin) {
-            const bool fail = (failbits[w >> 6] >> (w & 63)) & 1ull;
-            if (!fail) {
-                const int r = w / endX, ix = w - r * endX;
-                int d = 0, pos = w, remaining = ix;
-                while (remaining > 0) {
-                    const int p = pos - 1, b = p & 63;
-                    const unsigned long long m = failbits[p >> 6] << (63 - b);   // bit p at the MSB
-                    int ones = (~m == 0ull) ? 64 : __clzll((long long)~m);
-                    int lim = b + 1 < remaining ? b + 1 : remaining;
-                    if (ones > lim) ones = lim;
-                    d += ones;
-                    if (ones < lim) break;
-                    pos -= ones; remaining -= ones;
-                }
-                keep = !(d & 1);
-            }
+            const int r = w / endX, ix = w - r * endX;
+            const unsigned long long *rb = bits + (size_t)r * sc.wpr;
+            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = visited(rb, ix);
         }
         const unsigned long long km = __ballot(keep);
         if (km) {
@@ -140,13 +178,12 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
         }
     }
 
-    // ---- C: remaining stages on the compacted queue
     int cur = 0;
-    for (int s = 1; s < a.nstages; s++) {
+    const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
+    for (int s = 1; s < last; s++) {
         __syncthreads();
         const int n = qn[cur];
         if (n == 0) break;
-        __syncthreads();
         if (tid == 0) qn[cur ^ 1] = 0;
         __syncthreads();
         const StageRec st = a.stages[s];
@@ -156,8 +193,9 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
             if (i < n) {
                 w = q[cur][i];
                 const int r = w / endX, ix = w - r * endX;
-                const int off = ypos[r] * a.spitch + xpos[ix];
-                pass = run_stage(sum, off, vnf_s[w], recs, st, a.pair_policy);
+                const unsigned off = (unsigned)(ypos[r] * a.spitch + xpos[ix]);
+                const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+                pass = run_stage(sum, off, vnf, recs, st, a.pair_policy);
             }
             const unsigned long long pm = __ballot(pass);
             if (pm) {
@@ -172,21 +210,233 @@ __global__ __launch_bounds__(256) void k_cascade_sc(CascadeArgs a)
     __syncthreads();
     const int nh = qn[cur];
     if (nh == 0) return;
-    if (tid == 0) gbase_s = (unsigned)atomicAdd(a.hits, (unsigned long long)nh);
+    // survivors: final candidates if the cascade ends here, otherwise work for k_deep
+    unsigned long long *list = last == a.nstages ? a.hits : a.deep;
+    const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
+    if (tid == 0) gbase_s = (unsigned)atomicAdd(list, (unsigned long long)nh);
     __syncthreads();
     const unsigned gb = gbase_s;
     for (int i = tid; i < nh; i += 256) {
         const int w = q[cur][i];
         const int r = w / endX, ix = w - r * endX;
         const unsigned key = ((unsigned)strip.scale << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
-        if (gb + i < a.hit_cap) a.hits[1 + gb + i] = ((unsigned long long)slot << 32) | key;
+        if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
     }
 }
 
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch)
+// ---- K5b': the same early stages for the small scales, window sums staged in LDS -------
+// A tw x tw block of windows of one scale reads a footprint of ((tw-1)*ystep + reach)^2
+// samples of the sum plane; it is copied once (coalesced 16-byte loads) into LDS and every
+// rectangle corner is then an LDS read instead of a cache-missing global gather.
+__global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
 {
-    if (a.blocks_per_frame <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(k_cascade_sc, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
+    __shared__ int tile[kTileRows * kTilePitch];
+    __shared__ double vnf_s[256];
+    __shared__ double psum[kTileThreads];
+    __shared__ unsigned short q[2][256];
+    __shared__ int qn[2];
+    __shared__ unsigned gbase_s;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slot = blockIdx.x / a.tile_blocks_per_frame;
+    const int tidx = a.tile_order[blockIdx.x - slot * a.tile_blocks_per_frame];
+    if (tidx < 0) return;
+    const TileRec t = a.tiles[tidx];
+    const ScaleRec &sc = a.scales[t.scale];
+    const StumpRec *__restrict__ recs = a.stumps_lds + t.stump_off;
+
+    if (tid < 2) qn[tid] = 0;
+    {   // stage the footprint
+        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + (size_t)t.y0 * a.spitch + t.x0a;
+        // 64 threads across a row (rw4 <= 49 groups), 8 rows in flight per pass, 4 passes unrolled
+        const int c4 = tid & 63, r0 = tid >> 6;
+        if (c4 < t.rw4) {
+            const int *__restrict__ sp = src + c4 * 4;
+            int *dp = &tile[c4 * 4];
+            int r = r0;
+            for (; r + 24 < t.rh; r += 32) {
+                const int4 v0 = *(const int4 *)(sp + (size_t)r * a.spitch);
+                const int4 v1 = *(const int4 *)(sp + (size_t)(r + 8) * a.spitch);
+                const int4 v2 = *(const int4 *)(sp + (size_t)(r + 16) * a.spitch);
+                const int4 v3 = *(const int4 *)(sp + (size_t)(r + 24) * a.spitch);
+                *(int4 *)(dp + r * kTilePitch) = v0;
+                *(int4 *)(dp + (r + 8) * kTilePitch) = v1;
+                *(int4 *)(dp + (r + 16) * kTilePitch) = v2;
+                *(int4 *)(dp + (r + 24) * kTilePitch) = v3;
+            }
+            for (; r < t.rh; r += 8) *(int4 *)(dp + r * kTilePitch) = *(const int4 *)(sp + (size_t)r * a.spitch);
+        }
+    }
+    // visited stage-0 survivors of the tile
+    const int nwin = t.tw * t.th;
+    bool keep = false;
+    if (tid < nwin) {
+        const int ty = tid / t.tw, tx = tid - ty * t.tw;
+        const int ix = t.ix0 + tx, iy = t.iy0 + ty;
+        const size_t rowtask = (size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr;
+        const unsigned long long *rb = a.failbits + rowtask;
+        if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = visited(rb, ix);
+        if (keep) vnf_s[tid] = a.vnf[(rowtask + (ix >> 6)) * 64 + (ix & 63)];
+    }
+    __syncthreads();                 // qn zeroed, tile staged
+    {
+        const unsigned long long km = __ballot(keep);
+        if (km) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&qn[0], __popcll(km));
+            wbase = __shfl(wbase, 0);
+            if (keep) q[0][wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+        }
+    }
+    int cur = 0;
+    const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
+    for (int s = 1; s < last; s++) {
+        __syncthreads();
+        const int n = qn[cur];
+        if (n == 0) break;
+        if (tid == 0) qn[cur ^ 1] = 0;
+        __syncthreads();
+        const StageRec st = a.stages[s];
+        bool pass = false; int w = 0;
+        if (st.flags & 2) {
+            // votes may be summed in any order: spread the stage's stumps over the idle lanes.
+            // thread = (window slot i, stump partition p); partition p takes stumps p, p+P, ...
+            int lg = 0;
+            while ((1 << lg) < n) lg++;
+            const int npad = 1 << lg;
+            int P = kTileThreads >> lg;
+            if (P > st.count) P = st.count;
+            const int i = tid & (npad - 1), p = tid >> lg;
+            double part = 0.0;
+            if (i < n && p < P) {
+                w = q[cur][i];
+                const int ty = w / t.tw, tx = w - ty * t.tw;
+                const unsigned o = (unsigned)((a.pos[sc.ypos_off + t.iy0 + ty] - t.y0) * kTilePitch +
+                                              (a.pos[sc.xpos_off + t.ix0 + tx] - t.x0a));
+                const double vnf = vnf_s[w];
+                const bool pair = a.pair_policy && (st.flags & 1);
+                if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
+                    const int pu = __builtin_amdgcn_readfirstlane(p);
+                    for (int j = pu; j < st.count; j += P)
+                        part += pair ? stump_vote<true>(tile, o, vnf, recs[st.first + j]) : stump_vote<false>(tile, o, vnf, recs[st.first + j]);
+                } else {
+                    for (int j = p; j < st.count; j += P)
+                        part += pair ? stump_vote<true>(tile, o, vnf, recs[st.first + j]) : stump_vote<false>(tile, o, vnf, recs[st.first + j]);
+                }
+            }
+            psum[tid] = part;
+            __syncthreads();
+            if (tid < n) {
+                double tot = 0.0;
+                for (int pp = 0; pp < P; pp++) tot += psum[(pp << lg) + tid];
+                pass = !(tot < (double)st.thr);
+            }
+        } else if (tid < n) {
+            w = q[cur][tid];
+            const int ty = w / t.tw, tx = w - ty * t.tw;
+            const unsigned o = (unsigned)((a.pos[sc.ypos_off + t.iy0 + ty] - t.y0) * kTilePitch +
+                                          (a.pos[sc.xpos_off + t.ix0 + tx] - t.x0a));
+            pass = run_stage(tile, o, vnf_s[w], recs, st, a.pair_policy);
+        }
+        const unsigned long long pm = __ballot(pass);
+        if (pm) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
+            wbase = __shfl(wbase, 0);
+            if (pass) q[cur ^ 1][wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    const int nh = qn[cur];
+    if (nh == 0) return;
+    unsigned long long *list = last == a.nstages ? a.hits : a.deep;
+    const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
+    if (tid == 0) gbase_s = (unsigned)atomicAdd(list, (unsigned long long)nh);
+    __syncthreads();
+    const unsigned gb = gbase_s;
+    if (tid < nh) {
+        const int w = q[cur][tid];
+        const int ty = w / t.tw, tx = w - ty * t.tw;
+        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + ty) << 13) | (unsigned)(t.ix0 + tx);
+        if (gb + tid < cap) list[1 + gb + tid] = ((unsigned long long)slot << 32) | key;
+    }
+}
+
+// ---- K5c: one wave per surviving window, one stump per lane -------------------
+__device__ __forceinline__ double wave_sum_exact(double v)
+{   // only used where every partial sum is exactly representable (StageRec flag bit 1)
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned long long cnt = a.deep[0];
+    if (cnt > a.deep_cap) {                              // list overflowed: poison the hit count (host reports it)
+        if (gw == 0 && lane == 0) atomicAdd(a.hits, 1ull << 40);
+        cnt = a.deep_cap;
+    }
+    for (unsigned long long i = gw; i < cnt; i += nwaves) {
+        const unsigned long long e = a.deep[1 + i];
+        const int slot = (int)(e >> 32);
+        const unsigned key = (unsigned)e;
+        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+        const ScaleRec &sc = a.scales[s];
+        const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
+        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * a.spitch + a.pos[sc.xpos_off + ix]);
+        const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+        const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
+        bool alive = true;
+        for (int st_i = a.deep_stage; st_i < a.nstages; st_i++) {
+            const StageRec st = a.stages[st_i];
+            const bool pair = a.pair_policy && (st.flags & 1);
+            double stage_sum = 0.0;
+            if (st.flags & 2) {                         // any summation order is exact
+                double part = 0.0;
+                for (int j = lane; j < st.count; j += 64) {
+                    const StumpRec &f = recs[st.first + j];
+                    part += pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
+                }
+                stage_sum = wave_sum_exact(part);
+            } else {                                    // keep OpenCV's left-to-right order
+                for (int c = 0; c < st.count; c += 64) {
+                    const int j = c + lane;
+                    double vote = 0.0;
+                    if (j < st.count) {
+                        const StumpRec &f = recs[st.first + j];
+                        vote = pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
+                    }
+                    const int m = st.count - c < 64 ? st.count - c : 64;
+                    for (int l = 0; l < m; l++) stage_sum += __shfl(vote, l);
+                }
+            }
+            if (stage_sum < (double)st.thr) { alive = false; break; }
+        }
+        if (alive && lane == 0) {
+            const unsigned long long h = atomicAdd(a.hits, 1ull);
+            if (h < a.hit_cap) a.hits[1 + h] = e;
+        }
+    }
+}
+
+void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which)
+{
+    if (batch <= 0 || a.ntasks <= 0) return;
+    if (which == 0) {
+        const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
+        hipLaunchKernelGGL(k_stage0, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
+    } else if (which == 3) {
+        if (a.tile_blocks_per_frame > 0)
+            hipLaunchKernelGGL(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), 0, st, a);
+    } else if (which == 1) {
+        if (a.blocks_per_frame > 0)
+            hipLaunchKernelGGL(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
+    } else if (a.deep_stage < a.nstages) {
+        hipLaunchKernelGGL(k_deep, dim3(256u * 8u), dim3(256), 0, st, a);    // 8192 waves, grid-stride over the list
+    }
 }
 
 } // namespace nvca

@@ -40,17 +40,20 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
 // --------------------------------------------------------------------------
 // Device-side records (plain structs shared by host table builder and kernels)
 // --------------------------------------------------------------------------
-struct StumpRec {           // one weak classifier at one scale: 20 dwords
-    int   p[3][4];          // corner offsets (elements of the pitched sum plane), relative to the window origin
-    float w[3];             // hidden weights (rect 0 re-balanced)
-    float thr;
-    float a0, a1;           // alpha[0] (sum < t) , alpha[1] (sum >= t)
-    int   nrect;
-    int   pad;
+struct StumpRec {           // one weak classifier at one scale: 24 dwords
+    int    p[3][4];         // corner offsets (elements of the pitched sum plane), relative to the window origin
+    float  w[3];            // hidden weights (rect 0 re-balanced)
+    int    nrect;
+    double thr;             // (double)node->threshold           (float -> double is exact)
+    double a0, a1;          // (double)alpha[0] (sum < t), (double)alpha[1] (sum >= t)
+    double pad;
 };
-static_assert(sizeof(StumpRec) == 80, "StumpRec layout");
+static_assert(sizeof(StumpRec) == 96, "StumpRec layout");
 
-struct StageRec { int first, count; float thr; int two_rects; };
+struct StageRec {
+    int first, count; float thr;
+    int flags;              // bit 0: two_rects (every stump has 2 rects); bit 1: votes may be summed in any order
+};
 
 struct ScaleRec {           // one evaluated scale
     int    winw, winh;
@@ -58,12 +61,24 @@ struct ScaleRec {           // one evaluated scale
     int    eq[4];           // equRect corner offsets
     int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
     int    stump_off;       // first StumpRec of this scale
+    int    task_off;        // first stage-0 wave task (64 windows) of this scale
+    int    wpr;             // wave tasks (64-bit reject words) per scan row
     int    pad;
     double inv_area;
     double factor;
 };
 
 struct StripRec { int scale, iy0, nrows, pad; };   // a block's share of the scan
+struct TileRec {            // a tw x th block of windows whose integral footprint is staged in LDS
+    int scale, ix0, iy0, tw, th;
+    int x0a, y0;            // top-left of the staged region (x0a multiple of 4)
+    int rw4, rh;            // region size: rw4 16-byte groups per row, rh rows
+    int stump_off;          // first StumpRec (LDS-pitch offsets) of this scale in stumps_lds
+    int pad0, pad1;
+};
+static constexpr int kTileRows = 192;               // staged region: at most 192 rows ...
+static constexpr int kTilePitch = 196;              // ... of 196 ints (147 KiB of the CU's 160 KiB LDS)
+static constexpr int kTileThreads = 512;
 
 static constexpr int kStripMaxWin = 512;   // windows per strip (LDS budget of the evaluator)
 static constexpr int kIntegralBand = 16;   // rows per integral band
@@ -180,11 +195,20 @@ struct CascadeArgs {
     int spitch;
     const ScaleRec *scales; const StumpRec *stumps; const StageRec *stages;
     const StripRec *strips; const int *pos;
-    const int *order; int blocks_per_frame;   // dispatch slot -> strip
+    const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
+    const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
+    const StumpRec *stumps_lds;
+    const unsigned *tasks; int ntasks;        // k_stage0 wave tasks: scale << 20 | iy << 7 | word
+    unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
+    double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
+    int deep_stage;                // first stage evaluated by k_deep
+    unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key
+    unsigned deep_cap;
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
 };
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch);
+// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile
+void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
 
 } // namespace nvca

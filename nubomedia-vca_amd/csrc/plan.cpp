@@ -11,6 +11,8 @@
 #include <cfloat>
 #include <cstring>
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 
 namespace nvca {
 
@@ -103,10 +105,20 @@ void build_scale_tables(const Cascade &c, double factor, int pitch, ScaleRec &sr
             }
         }
         r.w[0] = (float)(-sum0 / area0);
-        r.thr = n.threshold;
-        r.a0 = c.alpha[hc.first_alpha]; r.a1 = c.alpha[hc.first_alpha + 1];
+        r.thr = (double)n.threshold;
+        r.a0 = (double)c.alpha[hc.first_alpha]; r.a1 = (double)c.alpha[hc.first_alpha + 1];
         r.nrect = n.nrect;
     }
+}
+
+// lowest set bit of a float as a power of two (INT_MAX for 0)
+static int lsb_exponent(float x)
+{
+    if (x == 0.f || !std::isfinite(x)) return x == 0.f ? INT_MAX : INT_MIN;
+    int ex; const double fr = std::frexp(std::fabs((double)x), &ex);      // fr in [0.5,1)
+    unsigned long long m = (unsigned long long)std::ldexp(fr, 53);          // exact integer mantissa
+    int tz = 0; while (!(m & 1ull)) { m >>= 1; tz++; }
+    return ex - 53 + tz;
 }
 
 void build_stage_recs(const Cascade &c, std::vector<StageRec> &out)
@@ -115,11 +127,47 @@ void build_stage_recs(const Cascade &c, std::vector<StageRec> &out)
     for (const HaarStage &s : c.stages) {
         StageRec r; r.first = s.first_cls; r.count = s.ncls;
         r.thr = s.threshold - 0.0001f;      // icv_stage_threshold_bias, float arithmetic
-        r.two_rects = 1;
-        for (int j = 0; j < s.ncls; j++)
-            if (c.nodes[c.cls[s.first_cls + j].first_node].nrect == 3) r.two_rects = 0;
+        bool two_rects = true;
+        // The stage sum is a left-to-right f64 accumulation of f32 votes.  If every vote is a multiple
+        // of 2^e and the sum of |votes| stays below 2^(e+53), every partial sum of every subset is
+        // exactly representable, so any summation order gives OpenCV's result bit for bit.
+        int emin = INT_MAX; double bound = 0; bool finite = true;
+        for (int j = 0; j < s.ncls; j++) {
+            const HaarClassifier &hc = c.cls[s.first_cls + j];
+            if (c.nodes[hc.first_node].nrect == 3) two_rects = false;
+            const float a0 = c.alpha[hc.first_alpha], a1 = c.alpha[hc.first_alpha + 1];
+            if (!std::isfinite(a0) || !std::isfinite(a1)) finite = false;
+            emin = std::min(emin, std::min(lsb_exponent(a0), lsb_exponent(a1)));
+            bound += std::max(std::fabs((double)a0), std::fabs((double)a1));
+        }
+        bool order_free = finite && (emin == INT_MAX || (bound == 0) || std::ilogb(bound) + 1 <= emin + 52);
+        r.flags = (two_rects ? 1 : 0) | (order_free ? 2 : 0);
         out.push_back(r);
     }
+}
+
+// Dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), each with its
+// own 4 MiB L2.  Give every XCD one contiguous run of work items (scale-major, then y, x) of about equal
+// weight, so that the integral rows an XCD reads stay resident in its L2 (speed only, never results).
+static int build_xcd_order(const std::vector<long long> &weight, std::vector<int> &order)
+{
+    const int n = (int)weight.size();
+    long long total = 0;
+    for (long long w : weight) total += w;
+    std::vector<int> start(9, n);
+    start[0] = 0;
+    long long acc = 0; int k = 1;
+    for (int i = 0; i < n && k < 8; i++) {
+        acc += weight[i];
+        while (k < 8 && acc * 8 >= total * k) { start[k] = i + 1; k++; }
+    }
+    for (; k < 8; k++) start[k] = n;
+    int maxlen = 0;
+    for (int x = 0; x < 8; x++) maxlen = std::max(maxlen, start[x + 1] - start[x]);
+    order.assign((size_t)8 * maxlen, -1);
+    for (int x = 0; x < 8; x++)
+        for (int j = 0; j < start[x + 1] - start[x]; j++) order[(size_t)j * 8 + x] = start[x] + j;
+    return 8 * maxlen;
 }
 
 int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
@@ -129,9 +177,16 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
     std::vector<double> factors;
     scale_grid(c.ow, c.oh, cols, rows, scaleFactor, minw, minh, maxw, maxh, false, factors);
     nstumps = (int)c.cls.size();
-    scales.clear(); strips.clear(); pos.clear();
+    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps_lds.clear();
+    if (const char *e = getenv("NVCA_DEEP_STAGE")) deep_stage = std::max(1, atoi(e));
+    // LDS-staged tiles (k_tile) are kept as an option: on MI355X the row-strip kernel is faster for this
+    // workload ("what was tried"), so they are off unless NVCA_TILES=1
+    bool use_tiles = false;
+    if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
+    if (factors.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
     stumps.assign(factors.size() * (size_t)nstumps, StumpRec());
     build_stage_recs(c, stages);
+    std::vector<long long> strip_w, tile_w;
     for (size_t s = 0; s < factors.size(); s++) {
         double factor = factors[s];
         const double ystep = std::max(2., factor);
@@ -146,42 +201,82 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
         for (int ix = 0; ix < std::max(sr.endX, 0); ix++) pos.push_back(cv_round(ix * ystep));
         sr.ypos_off = (int)pos.size();
         for (int iy = 0; iy < std::max(sr.endY, 0); iy++) pos.push_back(cv_round(iy * ystep));
+        sr.task_off = (int)tasks.size();
+        sr.wpr = sr.endX > 0 ? (sr.endX + 63) / 64 : 0;
+        if (sr.wpr > 128) { err = "scan row too long for the task key"; return NVCA_ERR_ARG; }
+        if (sr.endX > 0)
+            for (int iy = 0; iy < sr.endY; iy++)
+                for (int k = 0; k < sr.wpr; k++) tasks.push_back(((unsigned)s << 20) | ((unsigned)iy << 7) | (unsigned)k);
         scales.push_back(sr);
         if (sr.endX <= 0 || sr.endY <= 0) continue;
+        const int *xp = &pos[sr.xpos_off], *yp = &pos[sr.ypos_off];
         // cvRunHaarClassifierCascadeSum's own bound: windows must satisfy x + w < cols + 1
-        // (always true inside the loop limits; checked so the kernel needs no test)
-        if (pos[sr.xpos_off + sr.endX - 1] + sr.winw >= cols + 1 || pos[sr.ypos_off + sr.endY - 1] + sr.winh >= rows + 1) {
+        // (always true inside the loop limits; checked so the kernels need no test)
+        if (xp[sr.endX - 1] + sr.winw >= cols + 1 || yp[sr.endY - 1] + sr.winh >= rows + 1) {
             err = "scan grid leaves the image"; return NVCA_ERR_ARG;
         }
-        int rows_per = std::max(1, std::min(kStripMaxWin / sr.endX, 64));
-        if (sr.endX > kStripMaxWin) { err = "row longer than a strip"; return NVCA_ERR_ARG; }
-        for (int iy = 0; iy < sr.endY; iy += rows_per) {
-            StripRec st; st.scale = (int)s; st.iy0 = iy; st.nrows = std::min(rows_per, sr.endY - iy); st.pad = 0;
-            strips.push_back(st);
+        // ---- LDS tiles for the small scales: a tw x tw block of windows reads a footprint of
+        // ((tw-1)*ystep + reach)^2 integral samples; stage it once in LDS when it fits and is reused enough
+        int reach_x = 0, reach_y = 0;          // furthest corner any stump reads, relative to the window origin
+        for (int k = 0; k < nstumps; k++) {
+            const StumpRec &r = stumps[s * (size_t)nstumps + k];
+            for (int q = 0; q < r.nrect; q++) { reach_x = std::max(reach_x, r.p[q][3] % pitch); reach_y = std::max(reach_y, r.p[q][3] / pitch); }
+        }
+        int tw = 0;
+        if (use_tiles && (int)stages.size() > 1 && deep_stage > 1) {
+            const int budget = std::min(kTileRows, kTilePitch - 4);
+            tw = (int)std::floor((budget - 2 - std::max(reach_x, reach_y) - 1) / ystep) + 1;
+            tw = std::min(tw, 16);
+            int min_tw = 10;
+            if (const char *e = getenv("NVCA_TILE_MIN_TW")) min_tw = std::max(2, atoi(e));
+            while (tw >= min_tw) {                  // verify with the real (rounded) positions
+                bool ok = true;
+                for (int i0 = 0; i0 < sr.endX && ok; i0 += tw) {
+                    const int i1 = std::min(i0 + tw, sr.endX) - 1;
+                    if ((xp[i1] + reach_x + 1) - (xp[i0] & ~3) > kTilePitch) ok = false;
+                }
+                for (int i0 = 0; i0 < sr.endY && ok; i0 += tw) {
+                    const int i1 = std::min(i0 + tw, sr.endY) - 1;
+                    if ((yp[i1] + reach_y + 1) - yp[i0] > kTileRows) ok = false;
+                }
+                if (ok) break;
+                tw--;
+            }
+            if (tw < min_tw) tw = 0;
+        }
+        if (tw) {
+            const int lds_off = (int)stumps_lds.size();
+            for (int k = 0; k < nstumps; k++) {          // same records, offsets re-based to the LDS pitch
+                StumpRec r = stumps[s * (size_t)nstumps + k];
+                for (int q = 0; q < r.nrect; q++)
+                    for (int e = 0; e < 4; e++) r.p[q][e] = (r.p[q][e] / pitch) * kTilePitch + (r.p[q][e] % pitch);
+                stumps_lds.push_back(r);
+            }
+            for (int iy0 = 0; iy0 < sr.endY; iy0 += tw)
+                for (int ix0 = 0; ix0 < sr.endX; ix0 += tw) {
+                    TileRec t; memset(&t, 0, sizeof(t));
+                    t.scale = (int)s; t.ix0 = ix0; t.iy0 = iy0;
+                    t.tw = std::min(tw, sr.endX - ix0); t.th = std::min(tw, sr.endY - iy0);
+                    t.x0a = xp[ix0] & ~3; t.y0 = yp[iy0];
+                    const int xend = std::min(xp[ix0 + t.tw - 1] + reach_x + 1, pitch);
+                    t.rw4 = (xend - t.x0a + 3) / 4;
+                    t.rh = std::min(yp[iy0 + t.th - 1] + reach_y + 1, rows + 1) - t.y0;
+                    t.stump_off = lds_off;
+                    tiles.push_back(t);
+                    tile_w.push_back((long long)t.tw * t.th + 64);
+                }
+        } else {
+            int rows_per = std::max(1, std::min(kStripMaxWin / sr.endX, 64));
+            if (sr.endX > kStripMaxWin) { err = "row longer than a strip"; return NVCA_ERR_ARG; }
+            for (int iy = 0; iy < sr.endY; iy += rows_per) {
+                StripRec st; st.scale = (int)s; st.iy0 = iy; st.nrows = std::min(rows_per, sr.endY - iy); st.pad = 0;
+                strips.push_back(st);
+                strip_w.push_back((long long)st.nrows * sr.endX);
+            }
         }
     }
-    // Dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), each with
-    // its own 4 MiB L2.  Give every XCD one contiguous run of strips (scale-major, then y) of about equal
-    // window count, so that the integral rows an XCD gathers from stay resident in its L2
-    // (placement only changes speed, never results).
-    {
-        long long total = 0;
-        for (const StripRec &st : strips) total += (long long)st.nrows * scales[st.scale].endX;
-        std::vector<int> start(9, (int)strips.size());
-        start[0] = 0;
-        long long acc = 0; int k = 1;
-        for (size_t i = 0; i < strips.size() && k < 8; i++) {
-            acc += (long long)strips[i].nrows * scales[strips[i].scale].endX;
-            while (k < 8 && acc * 8 >= total * k) { start[k] = (int)i + 1; k++; }
-        }
-        for (; k < 8; k++) start[k] = (int)strips.size();
-        int maxlen = 0;
-        for (int x = 0; x < 8; x++) maxlen = std::max(maxlen, start[x + 1] - start[x]);
-        blocks_per_frame = 8 * maxlen;
-        order.assign(blocks_per_frame, -1);
-        for (int x = 0; x < 8; x++)
-            for (int j = 0; j < start[x + 1] - start[x]; j++) order[j * 8 + x] = start[x] + j;
-    }
+    blocks_per_frame = build_xcd_order(strip_w, order);
+    tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
     return NVCA_OK;
 }
 

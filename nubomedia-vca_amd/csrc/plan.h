@@ -18,10 +18,15 @@ struct DetectPlan {
     std::vector<StageRec> stages;
     std::vector<StripRec> strips;
     std::vector<int> pos;
+    std::vector<unsigned> tasks; // stage-0 wave tasks
+    int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
+    std::vector<TileRec> tiles;  // LDS-staged tiles (small scales)
+    std::vector<int> tile_order; int tile_blocks_per_frame = 0;
+    std::vector<StumpRec> stumps_lds;
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_stumps_lds;
 
     int build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                             int minw, int minh, int maxw, int maxh, std::string &err);
