@@ -1,0 +1,186 @@
+// kernels_tracker.hip -- NuboTracker's per-frame pixel work on gfx950:
+// replaces, inside gst_nubo_tracker_process (TRK/gstnubotracker.cpp:339-421),
+//   cvtColor(BGRA->gray) :356, absdiff :361, threshold :364,
+//   updateMotionHistory :368, segmentMotion :376
+// (calcMotionGradient :372 has no observable effect: its outputs are never read).
+//
+// K7 k_trk_pixel   one streaming pass: gray, |gray-prev| > thr, MHI update, prev <- gray.
+// K8 segmentMotion as connected-component labelling: cvSegmentMotion flood-fills, in
+//    raster order, from every unlabelled pixel equal to (float)timestamp, joining
+//    4-neighbours whose MHI values differ by at most seg_thresh.  The relation is
+//    symmetric, so the filled regions are exactly the connected components of that
+//    graph which contain a seed, ordered by their first seed pixel.  Zero pixels (which
+//    OpenCV swaps for a huge sentinel) only ever connect to each other and hold no seed.
+//    k_ccl_init / k_ccl_merge / k_ccl_flatten: lock-free union-find on pixel indices;
+//    k_ccl_reduce: bounding box + first seed per root (atomics once per horizontal run);
+//    k_ccl_collect: roots that own a seed -> component list (host sorts by first seed).
+// All HBM-bound streaming / atomic work; no MFMA.
+#include "nvca_internal.h"
+
+namespace nvca {
+
+__device__ __forceinline__ int gray4(unsigned px)
+{
+    return (int)((px & 255) * 1868 + ((px >> 8) & 255) * 9617 + ((px >> 16) & 255) * 4899 + 8192) >> 14;
+}
+
+// 4 pixels per thread; w4 = ceil(w / 4); rows packed (prev / mhi pitch == w)
+__global__ __launch_bounds__(256) void k_trk_pixel(const TrkSlot *__restrict__ slots, int w, int h)
+{
+    const TrkSlot s = slots[blockIdx.z];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w) return;
+    const uint8_t *row = s.src + (size_t)y * s.sstride + (size_t)x4 * 4;
+    const size_t o = (size_t)y * w + x4;
+    const int n = w - x4 < 4 ? w - x4 : 4;
+    for (int k = 0; k < n; k++) {
+        const unsigned px = (unsigned)row[k * 4] | ((unsigned)row[k * 4 + 1] << 8) | ((unsigned)row[k * 4 + 2] << 16);
+        const int g = gray4(px);
+        if (s.has_prev) {
+            const int d = g - (int)s.prev[o + k];
+            const bool moved = (d < 0 ? -d : d) > s.threshold;           // absdiff + THRESH_BINARY
+            const float m = s.mhi[o + k];
+            s.mhi[o + k] = moved ? s.ts : (m < s.delbound ? 0.f : m);    // cvUpdateMotionHistory
+        }
+        s.prev[o + k] = (uint8_t)g;
+    }
+}
+
+// vectorised variant: w % 4 == 0, 16-byte aligned frame rows
+__global__ __launch_bounds__(256) void k_trk_pixel4(const TrkSlot *__restrict__ slots, int w, int h)
+{
+    const TrkSlot s = slots[blockIdx.z];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w) return;
+    const uint4 px = *(const uint4 *)(s.src + (size_t)y * s.sstride + (size_t)x4 * 4);
+    const size_t o = (size_t)y * w + x4;
+    const int g0 = gray4(px.x), g1 = gray4(px.y), g2 = gray4(px.z), g3 = gray4(px.w);
+    if (s.has_prev) {
+        const unsigned pv = *(const unsigned *)(s.prev + o);
+        float4 m = *(const float4 *)(s.mhi + o);
+        const int d0 = g0 - (int)(pv & 255), d1 = g1 - (int)((pv >> 8) & 255), d2 = g2 - (int)((pv >> 16) & 255), d3 = g3 - (int)(pv >> 24);
+        m.x = (d0 < 0 ? -d0 : d0) > s.threshold ? s.ts : (m.x < s.delbound ? 0.f : m.x);
+        m.y = (d1 < 0 ? -d1 : d1) > s.threshold ? s.ts : (m.y < s.delbound ? 0.f : m.y);
+        m.z = (d2 < 0 ? -d2 : d2) > s.threshold ? s.ts : (m.z < s.delbound ? 0.f : m.z);
+        m.w = (d3 < 0 ? -d3 : d3) > s.threshold ? s.ts : (m.w < s.delbound ? 0.f : m.w);
+        *(float4 *)(s.mhi + o) = m;
+    }
+    *(unsigned *)(s.prev + o) = (unsigned)g0 | ((unsigned)g1 << 8) | ((unsigned)g2 << 16) | ((unsigned)g3 << 24);
+}
+
+// ---- union-find on pixel indices (labels[i] = parent; roots are self-parented) ----
+__device__ __forceinline__ int uf_find(int *labels, int i)
+{
+    int p = labels[i];
+    while (p != i) { i = p; p = labels[i]; }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int *labels, int a, int b)
+{
+    for (;;) {
+        a = uf_find(labels, a); b = uf_find(labels, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&labels[b], a);     // hang the larger root under the smaller
+        if (old == b) return;
+        b = old;                                      // someone re-parented b meanwhile: retry from there
+    }
+}
+__device__ __forceinline__ bool joined(float a, float b, float seg)
+{   // Diff32fC1 with lo = up = seg_thresh: -seg <= a - b <= seg
+    const float d = a - b;
+    return -seg <= d && d <= seg;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int n)
+{
+    const TrkSlot s = slots[blockIdx.y];
+    int *lab = labels + (size_t)blockIdx.y * n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) lab[i] = s.mhi[i] != 0.f ? i : -1;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h)
+{
+    const TrkSlot s = slots[blockIdx.z];
+    const int n = w * h;
+    int *lab = labels + (size_t)blockIdx.z * n;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int i = y * w + x;
+    const float v = s.mhi[i];
+    if (v == 0.f) return;
+    if (x > 0) { const float l = s.mhi[i - 1]; if (l != 0.f && joined(v, l, s.seg)) uf_union(lab, i, i - 1); }
+    if (y > 0) { const float u = s.mhi[i - w]; if (u != 0.f && joined(v, u, s.seg)) uf_union(lab, i, i - w); }
+}
+
+
+__global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, CompAcc *__restrict__ acc, int n)
+{
+    int *lab = labels + (size_t)blockIdx.y * n;
+    CompAcc *ac = acc + (size_t)blockIdx.y * n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || lab[i] < 0) return;
+    const int r = uf_find(lab, i);
+    lab[i] = r;
+    if (r == i) { CompAcc c; c.minx = c.miny = 0x7fffffff; c.maxx = c.maxy = -1; c.seed = 0x7fffffff; c.pad = 0; ac[i] = c; }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
+                                                    CompAcc *__restrict__ acc, int w, int h)
+{
+    const TrkSlot s = slots[blockIdx.z];
+    const int n = w * h;
+    const int *lab = labels + (size_t)blockIdx.z * n;
+    CompAcc *ac = acc + (size_t)blockIdx.z * n;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int i = y * w + x;
+    int r = lab[i];
+    if (r < 0) return;
+    const bool same_l = x > 0 && lab[i - 1] == r;     // labels are final roots after k_ccl_flatten
+    const bool same_r = x + 1 < w && lab[i + 1] == r;
+    if (!same_l) { atomicMin(&ac[r].minx, x); atomicMin(&ac[r].miny, y); atomicMax(&ac[r].maxy, y); }
+    if (!same_r) atomicMax(&ac[r].maxx, x);
+    if (__float_as_int(s.mhi[i]) == __float_as_int(s.ts)) {
+        const bool seed_l = same_l && __float_as_int(s.mhi[i - 1]) == __float_as_int(s.ts);
+        if (!seed_l) atomicMin(&ac[r].seed, i);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_collect(const int *__restrict__ labels, const CompAcc *__restrict__ acc, int n,
+                                                     int *__restrict__ out /* [0]=count, then 6 ints per comp */, int cap)
+{
+    const int slot = blockIdx.y;
+    const int *lab = labels + (size_t)slot * n;
+    const CompAcc *ac = acc + (size_t)slot * n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || lab[i] != i) return;
+    const CompAcc c = ac[i];
+    if (c.seed == 0x7fffffff) return;
+    const int k = atomicAdd(&out[0], 1);
+    if (k < cap) {
+        int *o = out + 2 + (size_t)k * 6;
+        o[0] = slot; o[1] = c.seed; o[2] = c.minx; o[3] = c.miny; o[4] = c.maxx - c.minx + 1; o[5] = c.maxy - c.miny + 1;
+    }
+}
+
+void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
+                    int *out, int cap, bool run_ccl)
+{
+    const TrkSlot *slots = (const TrkSlot *)d_slots;
+    const int n = w * h;
+    dim3 gp(((w + 3) / 4 + 255) / 256, h, batch);
+    if (vec4) hipLaunchKernelGGL(k_trk_pixel4, gp, dim3(256), 0, st, slots, w, h);
+    else hipLaunchKernelGGL(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h);
+    if (!run_ccl) return;
+    dim3 g1((n + 255) / 256, batch), g2((w + 255) / 256, h, batch);
+    hipLaunchKernelGGL(k_ccl_init, g1, dim3(256), 0, st, slots, labels, n);
+    hipLaunchKernelGGL(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h);
+    hipLaunchKernelGGL(k_ccl_flatten, g1, dim3(256), 0, st, labels, (CompAcc *)acc, n);
+    hipLaunchKernelGGL(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h);
+    hipLaunchKernelGGL(k_ccl_collect, g1, dim3(256), 0, st, (const int *)labels, (const CompAcc *)acc, n, out, cap);
+}
+
+
+} // namespace nvca

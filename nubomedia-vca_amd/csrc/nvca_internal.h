@@ -189,6 +189,23 @@ void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, in
                      const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
                      int batch);
 
+// ---- tracker (kernels_tracker.hip) ----
+struct TrkSlot {                // per tracker in the batch
+    const uint8_t *src;         // BGRA frame
+    uint8_t *prev;              // previous gray  [h][w]
+    float *mhi;                 // motion history [h][w]
+    float ts, delbound;         // (float)timestamp, (float)(timestamp - duration)
+    float seg;                  // (float)seg_thresh
+    int threshold;
+    int has_prev;               // num_frames > 0
+    int sstride;
+    int pad;
+};
+struct CompAcc { int minx, miny, maxx, maxy, seed, pad; };   // per root, stored at the root's pixel index
+// out: [0] = component count, [1] unused, then 6 ints per component: slot, first seed index, x, y, w, h
+void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
+                    int *out, int cap, bool run_ccl);
+
 struct CascadeArgs {
     const int *sum; const unsigned long long *sqsum;
     size_t sum_slot;               // elements between slots

@@ -1,18 +1,170 @@
-// tracker.cpp -- NuboTracker stream (placeholder until the device path lands in this file)
+// tracker.cpp -- NuboTracker stream objects: replaces gst_nubo_tracker_img_conf +
+// gst_nubo_tracker_process (TRK/gstnubotracker.cpp:202-237, 339-421).  Per stream the
+// device keeps the previous gray frame and the motion-history image; every frame runs
+// k_trk_pixel + the connected-component kernels, then __join_objects on the host.
 #include "nvca_internal.h"
+#include "host_logic.h"
+#include <algorithm>
+#include <cstring>
 
-struct nvca_tracker { nvca_ctx *ctx; nvca_tracker_params p; };
+using namespace nvca;
+
+struct nvca_tracker {
+    nvca_ctx *ctx;
+    nvca_tracker_params p;
+    int w = 0, h = 0, num_frames = 0;
+    DevBuf prev, mhi;
+};
+
+namespace {
+struct TrkWorkspace { DevBuf slots, labels, acc, out, staging; PinnedBuf h_slots, h_out; };
+TrkWorkspace &trk_ws(nvca_ctx *ctx)
+{
+    static std::map<nvca_ctx *, std::unique_ptr<TrkWorkspace>> all;      // freed with the process
+    auto &p = all[ctx];
+    if (!p) p.reset(new TrkWorkspace());
+    return *p;
+}
+constexpr int kCompCap = 1 << 18;
+}
 
 extern "C" {
+
 int nvca_tracker_create(nvca_ctx *ctx, const nvca_tracker_params *params, nvca_tracker **out)
 {
     if (!ctx || !out) return NVCA_ERR_ARG;
-    ctx->set_error("tracker: not implemented yet");
-    return NVCA_ERR_UNSUPPORTED;
+    nvca_tracker *t = new (std::nothrow) nvca_tracker();
+    if (!t) return NVCA_ERR_NOMEM;
+    t->ctx = ctx;
+    if (params) t->p = *params; else nvca_tracker_params_default(&t->p);
+    *out = t;
+    return NVCA_OK;
 }
-void nvca_tracker_destroy(nvca_tracker *t) { delete t; }
-int nvca_tracker_set_params(nvca_tracker *t, const nvca_tracker_params *params) { return NVCA_ERR_UNSUPPORTED; }
-int nvca_tracker_process(nvca_tracker *t, const nvca_frame *f, double ts, nvca_rect *out, int cap, int *n_out) { return NVCA_ERR_UNSUPPORTED; }
+
+void nvca_tracker_destroy(nvca_tracker *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    t->prev.release(); t->mhi.release();
+    delete t;
+}
+
+int nvca_tracker_set_params(nvca_tracker *t, const nvca_tracker_params *params)
+{
+    if (!t || !params) return NVCA_ERR_ARG;
+    t->p = *params;
+    return NVCA_OK;
+}
+
 int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *trackers, const nvca_frame *frames,
-                               const double *ts, nvca_rect *out, int cap, int *n_out) { return NVCA_ERR_UNSUPPORTED; }
+                               const double *ts, nvca_rect *out, int cap, int *n_out)
+{
+    if (!ctx || n < 0 || (n > 0 && (!trackers || !frames || !ts || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < n; i++) {
+        n_out[i] = 0;
+        const nvca_frame &f = frames[i];
+        if (!trackers[i] || trackers[i]->ctx != ctx || !f.data || f.width <= 0 || f.height <= 0 || f.stride < f.width * 4 ||
+            (f.mem != NVCA_MEM_HOST && f.mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
+        for (int j = 0; j < i; j++) if (trackers[j] == trackers[i]) { ctx->set_error("a tracker may appear once per batch"); return NVCA_ERR_ARG; }
+    }
+    TrkWorkspace &ws = trk_ws(ctx);
+    std::vector<char> done(n, 0);
+    for (int i0 = 0; i0 < n; i0++) {
+        if (done[i0]) continue;
+        const int W = frames[i0].width, H = frames[i0].height;
+        std::vector<int> idx;
+        for (int j = i0; j < n; j++) if (!done[j] && frames[j].width == W && frames[j].height == H) { idx.push_back(j); done[j] = 1; }
+        const int batch = (int)idx.size();
+        const size_t N = (size_t)W * H;
+        // per-stream state (gst_nubo_tracker_img_conf: MHI re-created zeroed on a size change)
+        size_t stage_bytes = 0;
+        bool any_ccl = false, vec4 = (W % 4) == 0;
+        for (int b = 0; b < batch; b++) {
+            nvca_tracker *t = trackers[idx[b]];
+            if (t->w != W || t->h != H) {
+                if (t->prev.ensure(N + 64) || t->mhi.ensure(N * sizeof(float) + 64)) { ctx->set_error("tracker state allocation failed"); return NVCA_ERR_NOMEM; }
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->mhi.p, 0, N * sizeof(float), ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->prev.p, 0, N, ctx->stream));
+                t->w = W; t->h = H;
+            }
+            const nvca_frame &f = frames[idx[b]];
+            if (f.mem == NVCA_MEM_HOST) stage_bytes += ((size_t)f.stride * H + 255) / 256 * 256;
+            if ((f.stride & 15) || (f.mem == NVCA_MEM_DEVICE && ((uintptr_t)f.data & 15))) vec4 = false;
+            if (t->num_frames > 0) any_ccl = true;
+        }
+        if (ws.slots.ensure(sizeof(TrkSlot) * batch) || ws.h_slots.ensure(sizeof(TrkSlot) * batch) ||
+            ws.labels.ensure(sizeof(int) * N * batch) || ws.acc.ensure(sizeof(CompAcc) * N * batch) ||
+            ws.out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) || ws.h_out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) ||
+            (stage_bytes && ws.staging.ensure(stage_bytes))) { ctx->set_error("tracker workspace allocation failed"); return NVCA_ERR_NOMEM; }
+        TrkSlot *hs = ws.h_slots.as<TrkSlot>();
+        size_t off = 0;
+        for (int b = 0; b < batch; b++) {
+            nvca_tracker *t = trackers[idx[b]];
+            const nvca_frame &f = frames[idx[b]];
+            TrkSlot &s = hs[b];
+            memset(&s, 0, sizeof(s));
+            if (f.mem == NVCA_MEM_HOST) {
+                uint8_t *d = ws.staging.as<uint8_t>() + off;
+                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (H - 1) + (size_t)W * 4, hipMemcpyHostToDevice, ctx->stream));
+                s.src = d; off += ((size_t)f.stride * H + 255) / 256 * 256;
+            } else s.src = (const uint8_t *)f.data;
+            s.prev = t->prev.as<uint8_t>(); s.mhi = t->mhi.as<float>();
+            const double timestamp = ts[idx[b]];
+            s.ts = (float)timestamp; s.delbound = (float)(timestamp - t->p.mhi_duration);    // cvUpdateMotionHistory
+            s.seg = (float)t->p.seg_thresh; s.threshold = t->p.threshold;
+            s.has_prev = t->num_frames > 0; s.sstride = f.stride;
+        }
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->stream));
+        { TimedLaunch tl(ctx, NVCA_K_TRACKER);
+          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl); }
+        NVCA_HIP_CHECK(ctx, hipGetLastError());
+        int *ho = ws.h_out.as<int>();
+        int total = 0;
+        if (any_ccl) {
+            const int first = 1024;
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->stream));
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            total = ho[0];
+            if (total > kCompCap) { ctx->set_error("tracker: more motion components than the list holds"); return NVCA_ERR_OVERFLOW; }
+            if (total > first) {
+                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho + 2 + 6 * (size_t)first, ws.out.as<int>() + 2 + 6 * (size_t)first,
+                                                   sizeof(int) * 6 * (size_t)(total - first), hipMemcpyDeviceToHost, ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        } else
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        // seed order (raster order of each component's first seed pixel) = cvSegmentMotion's output order
+        std::vector<std::vector<std::pair<int, nvca_rect>>> comps(batch);
+        for (int k = 0; k < total; k++) {
+            const int *o = ho + 2 + (size_t)k * 6;
+            comps[o[0]].push_back({o[1], nvca_rect{o[2], o[3], o[4], o[5]}});
+        }
+        for (int b = 0; b < batch; b++) {
+            nvca_tracker *t = trackers[idx[b]];
+            if (t->num_frames > 0) {
+                auto &c = comps[b];
+                std::sort(c.begin(), c.end(), [](const std::pair<int, nvca_rect> &x, const std::pair<int, nvca_rect> &y) { return x.first < y.first; });
+                std::vector<nvca_rect> sb;
+                sb.reserve(c.size());
+                for (auto &e : c) sb.push_back(e.second);
+                join_objects(sb, t->p.min_area, t->p.max_area, t->p.distance);      // __join_objects :380
+                n_out[idx[b]] = (int)sb.size();
+                for (int k = 0; k < std::min<int>(cap, (int)sb.size()); k++) out[(size_t)idx[b] * cap + k] = sb[k];
+            }
+            t->num_frames++;
+        }
+    }
+    return NVCA_OK;
 }
+
+int nvca_tracker_process(nvca_tracker *t, const nvca_frame *f, double ts, nvca_rect *out, int cap, int *n_out)
+{
+    if (!t || !f) return NVCA_ERR_ARG;
+    nvca_tracker *arr[1] = {t};
+    return nvca_tracker_batch_process(t->ctx, 1, arr, f, &ts, out, cap, n_out);
+}
+
+} // extern "C"

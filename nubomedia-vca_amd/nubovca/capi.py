@@ -363,3 +363,56 @@ class FaceStream:
             self.close()
         except Exception:
             pass
+
+
+class Tracker:
+    """nvca_tracker: mirrors one `nubotracker` element instance (properties of
+    TRK/gstnubotracker.cpp:504-542 by their reference names)."""
+
+    PROPS = {"set_threshold": "threshold", "set_min_area": "min_area", "set_max_area": "max_area",
+             "set_distance": "distance", "mhi_duration": "mhi_duration", "seg_thresh": "seg_thresh"}
+
+    def __init__(self, ctx, **props):
+        self.ctx = ctx
+        self.p = TrackerParams()
+        ctx.L.nvca_tracker_params_default(C.byref(self.p))
+        for k, v in props.items():
+            setattr(self.p, self.PROPS[k], v)
+        h = C.c_void_p()
+        ctx.check(ctx.L.nvca_tracker_create(ctx.h, C.byref(self.p), C.byref(h)))
+        self.h = h
+
+    def set_property(self, name, value):
+        setattr(self.p, self.PROPS[name], value)
+        self.ctx.check(self.ctx.L.nvca_tracker_set_params(self.h, C.byref(self.p)))
+
+    def process(self, bgra, timestamp_ms, cap=4096):
+        return tracker_batch_process(self.ctx, [self], [make_frame(np.ascontiguousarray(bgra, np.uint8))],
+                                     [timestamp_ms], cap)[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.nvca_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
+    n = len(frames)
+    th = (C.c_void_p * n)(*[t.h for t in trackers])
+    fr = (Frame * n)(*frames)
+    ts = (C.c_double * n)(*[float(t) for t in timestamps])
+    out = (Rect * (n * cap))()
+    cnt = (C.c_int * n)()
+    ctx.check(ctx.L.nvca_tracker_batch_process(ctx.h, n, th, fr, ts, out, cap, cnt))
+    res = []
+    for i in range(n):
+        k = min(cnt[i], cap)
+        res.append(np.array([[out[i * cap + j].x, out[i * cap + j].y, out[i * cap + j].w, out[i * cap + j].h]
+                             for j in range(k)], np.int32).reshape(k, 4))
+    return res
