@@ -176,24 +176,27 @@ static int upload_tab(nvca_ctx *ctx, GeomPlan &gp)
 
 // ---- launch sequences ----------------------------------------------------
 
-// integral planes for `batch` slots of ws.gray (lut == nullptr -> identity)
-static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int batch)
+// integral planes for `batch` slots (lut == nullptr -> identity); gray / sum / sq default to the workspace planes
+static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int batch, const uint8_t *gray = nullptr,
+                         int *sum = nullptr, unsigned long long *sq = nullptr)
 {
     Workspace &ws = *ctx->ws;
+    if (!gray) gray = ws.gray.as<uint8_t>();
+    if (!sum) sum = ws.sum.as<int>();
+    if (!sq) sq = ws.sqsum.as<unsigned long long>();
     { TimedLaunch t(ctx, NVCA_K_COLSUM);
-      launch_colsum(ctx->stream, ws.gray.as<uint8_t>(), lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
+      launch_colsum(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_BANDSCAN);
       launch_bandscan(ctx->stream, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
-      launch_integral(ctx->stream, ws.gray.as<uint8_t>(), lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(),
-                      ws.sum.as<int>(), ws.sqsum.as<unsigned long long>(), batch); }
+      launch_integral(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), sum, sq, batch); }
 }
 
 // cascade scan over the integral planes; fills raw[b] (canonical scale,y,x order)
-static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::vector<nvca_rect>> &raw)
+static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, int batch,
+                       std::vector<std::vector<nvca_rect>> &raw)
 {
     Workspace &ws = *ctx->ws;
-    DetectPlan &dp = gp.det;
     raw.assign(batch, {});
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * batch + 64, 1u << 28);   // every window may survive
@@ -207,7 +210,7 @@ static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::
     if (!dp.tasks.empty()) {
         CascadeArgs a;
         a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
-        a.sum_slot = gp.g.sum_slot; a.spitch = gp.g.spitch;
+        a.sum_slot = sum_slot; a.spitch = spitch;
         a.scales = dp.d_scales.as<ScaleRec>(); a.stumps = dp.d_stumps.as<StumpRec>();
         a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
@@ -245,10 +248,7 @@ static int run_cascade(nvca_ctx *ctx, GeomPlan &gp, int batch, std::vector<std::
     for (unsigned long long i = 0; i < total; i++) {
         const unsigned long long e = hh[1 + i];
         const int slot = (int)(e >> 32);
-        const unsigned key = (unsigned)e;
-        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
-        const ScaleRec &sc = dp.scales[s];
-        raw[slot].push_back(nvca_rect{dp.pos[sc.xpos_off + ix], dp.pos[sc.ypos_off + iy], sc.winw, sc.winh});
+        raw[slot].push_back(dp.hit_rect((unsigned)e));
     }
     return NVCA_OK;
 }
@@ -613,16 +613,172 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
 // =========================================================================
 // detectMultiScale
 // =========================================================================
+// cvHaarDetectObjectsForROC, CV_HAAR_SCALE_IMAGE branch (EYE/kmseyedetect.cpp:991-993, NOSE/kmsnosedetect.cpp:843-846,
+// MOUTH/kmsmouthdetect.cpp:845-848, EAR/kmseardetect.cpp:656-659): per factor the image is resized, integrated and
+// scanned with the unscaled window on a fixed grid.  All pyramid levels are evaluated by one launch set.
+static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int cols, int rows, int stride,
+                              int mem, double sf, int min_neighbors, int minw, int minh, int maxw, int maxh, bool raw_only,
+                              std::vector<nvca_rect> &out)
+{
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    const Cascade &c = casc->c;
+    struct Level { double f; int szw, szh, winw, winh; size_t gray_off; int gpitch; int plane_off; };
+    std::vector<Level> lv;
+    const int P = (int)round_up(cols + 1, 8);
+    size_t gray_total = 0, plane_total = 0;
+    for (double factor = 1;; factor *= sf) {
+        const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
+        const int szw = cv_round(cols / factor), szh = cv_round(rows / factor);
+        if (szw - c.ow + 1 <= 0 || szh - c.oh + 1 <= 0) break;
+        if (winw > maxw || winh > maxh) break;
+        if (winw < minw || winh < minh) continue;
+        if (szw + 1 <= 1 + c.ow) continue;                   // HaarDetectObjects_ScaleImage_Invoker's early return
+        Level L; L.f = factor; L.szw = szw; L.szh = szh; L.winw = winw; L.winh = winh;
+        L.gpitch = (int)round_up(szw, 64); L.gray_off = gray_total; L.plane_off = (int)plane_total;
+        gray_total += round_up((size_t)L.gpitch * szh, 256);
+        plane_total += round_up((size_t)P * (szh + 1), 64);
+        lv.push_back(L);
+        if (lv.size() > 62) break;
+    }
+    out.clear();
+    if (lv.empty()) return NVCA_OK;
+    PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
+    int rc;
+    if ((rc = ensure_ws(ctx, g0, 1))) return rc;
+    if (ws.aux.ensure(gray_total + 64) || ws.sum.ensure(plane_total * sizeof(int)) || ws.sqsum.ensure(plane_total * sizeof(unsigned long long))) {
+        ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
+    }
+    if ((rc = stage_2d(ctx, ws.gray.p, g0.gpitch, gray, stride, cols, rows, mem))) return rc;
+    std::vector<ScaleSpec> specs;
+    std::vector<std::unique_ptr<GeomPlan>> tabs;             // resize tables stay alive until the stream drains
+    for (const Level &L : lv) {
+        std::unique_ptr<GeomPlan> gp(new GeomPlan());
+        build_resize_tab(cols, rows, L.szw, L.szh, gp->tab);
+        if ((rc = upload_tab(ctx, *gp))) return rc;
+        uint8_t *lg = ws.aux.as<uint8_t>() + L.gray_off;
+        { TimedLaunch t(ctx, NVCA_K_RESIZE1);               // cvResize(img, &img1, CV_INTER_LINEAR)
+          launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
+                         gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax, lg, L.szw,
+                         L.szh, L.gpitch, nullptr); }
+        tabs.push_back(std::move(gp));
+        PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
+        g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
+        run_integral(ctx, g, nullptr, 1, lg, ws.sum.as<int>() + L.plane_off, ws.sqsum.as<unsigned long long>() + L.plane_off);
+        ScaleSpec sp;
+        sp.table_factor = 1.; sp.plane_off = L.plane_off; sp.pitch = P; sp.plane_rows = L.szh + 1; sp.adaptive = 0;
+        sp.out_factor = L.f; sp.out_w = L.winw; sp.out_h = L.winh;
+        const int ystep = L.f > 2 ? 1 : 2;
+        for (int x = 0; x < L.szw - c.ow; x += ystep) sp.xs.push_back(x);
+        for (int y = 0; y < L.szh - c.oh; y += ystep) sp.ys.push_back(y);
+        specs.push_back(std::move(sp));
+    }
+    DetectPlan dp;
+    std::string err;
+    if ((rc = dp.build_custom(c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
+    if ((rc = dp.upload(ctx))) return rc;
+    std::vector<std::vector<nvca_rect>> raw;
+    rc = run_cascade(ctx, dp, plane_total, P, 1, raw);      // synchronises: tables may be released afterwards
+    if (rc) return rc;
+    if (!raw_only) group_all(raw, min_neighbors);
+    out.swap(raw[0]);
+    return NVCA_OK;
+}
+
+// cvHaarDetectObjectsForROC with CV_HAAR_FIND_BIGGEST_OBJECT (NOSE/kmsnosedetect.cpp:870-873, MOUTH/kmsmouthdetect.cpp:870-873,
+// EAR/kmseardetect.cpp:712-715): scale-cascade scan from the largest factor down; after the first grouped detection
+// the scan narrows to a region of interest and a minimum size.  Sequential across scales by definition, so the host
+// drives one launch set per scale.
+static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int cols, int rows, int stride,
+                               int mem, double scaleFactor, int minNeighbors, int flags, int minw, int minh, int maxw,
+                               int maxh, std::vector<nvca_rect> &out)
+{
+    (void)hipSetDevice(ctx->device);
+    const Cascade &c = casc->c;
+    const bool rough = (flags & NVCA_HAAR_DO_ROUGH_SEARCH) != 0;
+    PreGeom g; make_geom(g, cols, rows, stride, 1, cols, rows);
+    int rc;
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, gray, stride, cols, rows, mem))) return rc;
+    run_integral(ctx, g, nullptr, 1);
+    std::vector<nvca_rect> all;
+    nvca_rect scanROI{0, 0, 0, 0};
+    int n_factors = 0; double factor;
+    for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= scaleFactor)
+        ;
+    scaleFactor = 1. / scaleFactor; factor *= scaleFactor;
+    for (; n_factors-- > 0; factor *= scaleFactor) {
+        const double ystep = std::max(2., factor);
+        const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
+        int startX = 0, startY = 0;
+        int endX = cv_round((cols - winw) / ystep), endY = cv_round((rows - winh) / ystep);
+        if (winw < minw || winh < minh) break;
+        if (winw > maxw || winh > maxh) continue;
+        if (scanROI.w * scanROI.h > 0) {
+            startY = cv_round(scanROI.y / ystep); endY = cv_round((scanROI.y + scanROI.h - winh) / ystep);
+            startX = cv_round(scanROI.x / ystep); endX = cv_round((scanROI.x + scanROI.w - winw) / ystep);
+        }
+        if (endX > startX && endY > startY) {
+            ScaleSpec sp;
+            sp.table_factor = factor; sp.plane_off = 0; sp.pitch = g.spitch; sp.plane_rows = rows + 1; sp.adaptive = 1;
+            sp.out_factor = 0; sp.out_w = winw; sp.out_h = winh;
+            for (int ix = startX; ix < endX; ix++) sp.xs.push_back(cv_round(ix * ystep));
+            for (int iy = startY; iy < endY; iy++) sp.ys.push_back(cv_round(iy * ystep));
+            // cvRunHaarClassifierCascadeSum returns -1 (no hit, step 1) outside the image: drop such grid points
+            while (!sp.xs.empty() && (sp.xs.back() + winw >= cols + 1)) sp.xs.pop_back();
+            while (!sp.ys.empty() && (sp.ys.back() + winh >= rows + 1)) sp.ys.pop_back();
+            bool neg = (!sp.xs.empty() && sp.xs.front() < 0) || (!sp.ys.empty() && sp.ys.front() < 0);
+            if (!sp.xs.empty() && !sp.ys.empty() && !neg) {
+                std::vector<ScaleSpec> one; one.push_back(std::move(sp));
+                DetectPlan dp; std::string err;
+                if ((rc = dp.build_custom(c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
+                if ((rc = dp.upload(ctx))) return rc;
+                std::vector<std::vector<nvca_rect>> raw;
+                if ((rc = run_cascade(ctx, dp, g.sum_slot, g.spitch, 1, raw))) return rc;
+                all.insert(all.end(), raw[0].begin(), raw[0].end());
+            }
+        }
+        if (!all.empty() && scanROI.w * scanROI.h == 0) {
+            std::vector<nvca_rect> tmp(all);
+            group_rectangles(tmp, std::max(minNeighbors, 1), 0.2);
+            if (!tmp.empty()) {
+                nvca_rect maxRect{0, 0, 0, 0};
+                for (const nvca_rect &r : tmp) if (r.w * r.h > maxRect.w * maxRect.h) maxRect = r;
+                all.push_back(maxRect);
+                scanROI = maxRect;
+                const int dx = cv_round(maxRect.w * 0.2), dy = cv_round(maxRect.h * 0.2);
+                scanROI.x = std::max(scanROI.x - dx, 0); scanROI.y = std::max(scanROI.y - dy, 0);
+                scanROI.w = std::min(scanROI.w + dx * 2, cols - 1 - scanROI.x);
+                scanROI.h = std::min(scanROI.h + dy * 2, rows - 1 - scanROI.y);
+                const double minScale = rough ? 0.6 : 0.4;
+                minw = cv_round(maxRect.w * minScale); minh = cv_round(maxRect.h * minScale);
+            }
+        }
+    }
+    group_rectangles(all, std::max(minNeighbors, 1), 0.2);
+    out.clear();
+    if (!all.empty()) {
+        nvca_rect best{0, 0, 0, 0};
+        for (const nvca_rect &r : all) if (r.w * r.h > best.w * best.h) best = r;
+        out.push_back(best);
+    }
+    return NVCA_OK;
+}
+
 static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
                        double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only,
                        std::vector<nvca_rect> &out)
 {
     int rc = check_img(ctx, gray, w, h, stride, 1, mem);
     if (rc || !casc || !(sf > 1.0)) return NVCA_ERR_ARG;
-    if (flags & (NVCA_HAAR_SCALE_IMAGE | NVCA_HAAR_FIND_BIGGEST_OBJECT)) {
-        ctx->set_error("detectMultiScale: SCALE_IMAGE / FIND_BIGGEST_OBJECT variants are not implemented yet");
-        return NVCA_ERR_UNSUPPORTED;
+    if (maxw == 0 || maxh == 0) { maxw = w; maxh = h; }
+    if (flags & NVCA_HAAR_FIND_BIGGEST_OBJECT) {
+        flags &= ~(NVCA_HAAR_SCALE_IMAGE | NVCA_HAAR_DO_CANNY_PRUNING);
+        if (raw_only) return NVCA_ERR_ARG;
+        return detect_find_biggest(ctx, casc, gray, w, h, stride, mem, sf, min_neighbors, flags, minw, minh, maxw, maxh, out);
     }
+    if (flags & NVCA_HAAR_SCALE_IMAGE)
+        return detect_scale_image(ctx, casc, gray, w, h, stride, mem, sf, min_neighbors, minw, minh, maxw, maxh, raw_only, out);
     (void)hipSetDevice(ctx->device);
     GeomPlan *gp = nullptr;
     if ((rc = get_face_plan(ctx, casc, w, h, stride, 1, w, h, sf, minw, minh, maxw, maxh, &gp))) return rc;
@@ -630,7 +786,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
     if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, gray, stride, w, h, mem))) return rc;
     run_integral(ctx, gp->g, nullptr, 1);
     std::vector<std::vector<nvca_rect>> raw;
-    if ((rc = run_cascade(ctx, *gp, 1, raw))) return rc;
+    if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, 1, raw))) return rc;
     if (!raw_only) group_all(raw, min_neighbors);
     out.swap(raw[0]);
     return NVCA_OK;
@@ -807,7 +963,7 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
           launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), batch); }
         run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), batch);
         std::vector<std::vector<nvca_rect>> raw;
-        if ((rc = run_cascade(ctx, *gp, batch, raw))) return rc;       // detectMultiScale :809-811
+        if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, batch, raw))) return rc;   // detectMultiScale :809-811
         for (int b = 0; b < batch; b++) {
             const int mn = streams[idx[b]]->p.min_neighbors;
             if (mn != 0) group_rectangles(raw[b], std::max(mn, 1), 0.2);

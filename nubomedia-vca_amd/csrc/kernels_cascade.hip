@@ -100,12 +100,12 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
     const ScaleRec &sc = a.scales[s];
     const int ix = k * 64 + lane;
     const bool active = ix < sc.endX;
-    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
-    const unsigned long long *__restrict__ sq = a.sqsum + (size_t)slot * a.sum_slot;
+    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+    const unsigned long long *__restrict__ sq = a.sqsum + (size_t)slot * a.sum_slot + sc.plane_off;
     bool pass0 = false;
     double vnf = 1.;
     if (active) {
-        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * a.spitch + a.pos[sc.xpos_off + ix]);
+        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
         const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
         const int ws = sum[e0] - sum[e1] - sum[e2] + sum[e3];
         const double mean = (double)ws * sc.inv_area;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     const StripRec strip = a.strips[sidx];
     const ScaleRec &sc = a.scales[strip.scale];
     const int endX = sc.endX, nwin = strip.nrows * endX;
-    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
+    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
     const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
     const int *__restrict__ xpos = a.pos + sc.xpos_off;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + strip.iy0;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
         if (w < nwin) {
             const int r = w / endX, ix = w - r * endX;
             const unsigned long long *rb = bits + (size_t)r * sc.wpr;
-            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = visited(rb, ix);
+            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
         }
         const unsigned long long km = __ballot(keep);
         if (km) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
             if (i < n) {
                 w = q[cur][i];
                 const int r = w / endX, ix = w - r * endX;
-                const unsigned off = (unsigned)(ypos[r] * a.spitch + xpos[ix]);
+                const unsigned off = (unsigned)(ypos[r] * sc.pitch + xpos[ix]);
                 const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
                 pass = run_stage(sum, off, vnf, recs, st, a.pair_policy);
             }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
 
     if (tid < 2) qn[tid] = 0;
     {   // stage the footprint
-        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + (size_t)t.y0 * a.spitch + t.x0a;
+        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off + (size_t)t.y0 * a.spitch + t.x0a;
         // 64 threads across a row (rw4 <= 49 groups), 8 rows in flight per pass, 4 passes unrolled
         const int c4 = tid & 63, r0 = tid >> 6;
         if (c4 < t.rw4) {
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
         const unsigned key = (unsigned)e;
         const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
         const ScaleRec &sc = a.scales[s];
-        const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot;
-        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * a.spitch + a.pos[sc.xpos_off + ix]);
+        const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
         const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
         const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
         bool alive = true;

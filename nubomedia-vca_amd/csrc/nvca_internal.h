@@ -57,13 +57,15 @@ struct StageRec {
 
 struct ScaleRec {           // one evaluated scale
     int    winw, winh;
-    int    startX, startY, endX, endY;   // ix / iy ranges
+    int    plane_off;       // element offset of this scale's sum/sqsum planes inside a slot (0: the full-image planes)
+    int    pitch;           // row pitch of those planes (elements)
+    int    endX, endY;      // scan grid: ix in [0,endX), iy in [0,endY)
     int    eq[4];           // equRect corner offsets
     int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
     int    stump_off;       // first StumpRec of this scale
     int    task_off;        // first stage-0 wave task (64 windows) of this scale
     int    wpr;             // wave tasks (64-bit reject words) per scan row
-    int    pad;
+    int    adaptive;        // 1: OpenCV's adaptive x step applies (scale-cascade scan); 0: every grid point is visited
     double inv_area;
     double factor;
 };

@@ -170,37 +170,50 @@ static int build_xcd_order(const std::vector<long long> &weight, std::vector<int
     return 8 * maxlen;
 }
 
-int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
-                                    int minw, int minh, int maxw, int maxh, std::string &err)
+nvca_rect DetectPlan::hit_rect(unsigned key) const
+{
+    const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+    const ScaleSpec &sp = specs[s];
+    const int x = sp.xs[ix], y = sp.ys[iy];
+    if (sp.out_factor != 0) return nvca_rect{cv_round(x * sp.out_factor), cv_round(y * sp.out_factor), sp.out_w, sp.out_h};
+    return nvca_rect{x, y, sp.out_w, sp.out_h};
+}
+
+int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool allow_tiles, std::string &err)
 {
     if (!c.stump_based) { err = "tree weak classifiers are not supported by the device evaluator yet"; return NVCA_ERR_UNSUPPORTED; }
-    std::vector<double> factors;
-    scale_grid(c.ow, c.oh, cols, rows, scaleFactor, minw, minh, maxw, maxh, false, factors);
+    specs = std::move(in);
     nstumps = (int)c.cls.size();
-    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps_lds.clear();
+    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps_lds.clear(); stumps.clear();
     if (const char *e = getenv("NVCA_DEEP_STAGE")) deep_stage = std::max(1, atoi(e));
     // LDS-staged tiles (k_tile) are kept as an option: on MI355X the row-strip kernel is faster for this
     // workload ("what was tried"), so they are off unless NVCA_TILES=1
     bool use_tiles = false;
     if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
-    if (factors.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
-    stumps.assign(factors.size() * (size_t)nstumps, StumpRec());
+    use_tiles = use_tiles && allow_tiles;
+    if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
     build_stage_recs(c, stages);
     std::vector<long long> strip_w, tile_w;
-    for (size_t s = 0; s < factors.size(); s++) {
-        double factor = factors[s];
-        const double ystep = std::max(2., factor);
+    double last_tf = -1; int last_pitch = -1, last_off = 0;
+    for (size_t s = 0; s < specs.size(); s++) {
+        const ScaleSpec &sp = specs[s];
+        const int pitch = sp.pitch;
         ScaleRec sr; memset(&sr, 0, sizeof(sr));
-        build_scale_tables(c, factor, pitch, sr, &stumps[s * (size_t)nstumps]);
-        sr.stump_off = (int)(s * (size_t)nstumps);
-        sr.startX = sr.startY = 0;
-        sr.endX = cv_round((cols - sr.winw) / ystep);
-        sr.endY = cv_round((rows - sr.winh) / ystep);
+        if (sp.table_factor == last_tf && pitch == last_pitch) {      // pyramid levels share one table
+            std::vector<StumpRec> tmp(nstumps);
+            build_scale_tables(c, sp.table_factor, pitch, sr, tmp.data());
+            sr.stump_off = last_off;
+        } else {
+            sr.stump_off = (int)stumps.size();
+            stumps.resize(stumps.size() + nstumps);
+            build_scale_tables(c, sp.table_factor, pitch, sr, &stumps[sr.stump_off]);
+            last_tf = sp.table_factor; last_pitch = pitch; last_off = sr.stump_off;
+        }
+        sr.plane_off = sp.plane_off; sr.pitch = pitch; sr.adaptive = sp.adaptive;
+        sr.endX = (int)sp.xs.size(); sr.endY = (int)sp.ys.size();
         if (sr.endX > 8191 || sr.endY > 8191) { err = "image too large for the candidate key"; return NVCA_ERR_ARG; }
-        sr.xpos_off = (int)pos.size();
-        for (int ix = 0; ix < std::max(sr.endX, 0); ix++) pos.push_back(cv_round(ix * ystep));
-        sr.ypos_off = (int)pos.size();
-        for (int iy = 0; iy < std::max(sr.endY, 0); iy++) pos.push_back(cv_round(iy * ystep));
+        sr.xpos_off = (int)pos.size(); pos.insert(pos.end(), sp.xs.begin(), sp.xs.end());
+        sr.ypos_off = (int)pos.size(); pos.insert(pos.end(), sp.ys.begin(), sp.ys.end());
         sr.task_off = (int)tasks.size();
         sr.wpr = sr.endX > 0 ? (sr.endX + 63) / 64 : 0;
         if (sr.wpr > 128) { err = "scan row too long for the task key"; return NVCA_ERR_ARG; }
@@ -210,20 +223,16 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
         scales.push_back(sr);
         if (sr.endX <= 0 || sr.endY <= 0) continue;
         const int *xp = &pos[sr.xpos_off], *yp = &pos[sr.ypos_off];
-        // cvRunHaarClassifierCascadeSum's own bound: windows must satisfy x + w < cols + 1
-        // (always true inside the loop limits; checked so the kernels need no test)
-        if (xp[sr.endX - 1] + sr.winw >= cols + 1 || yp[sr.endY - 1] + sr.winh >= rows + 1) {
-            err = "scan grid leaves the image"; return NVCA_ERR_ARG;
-        }
+        const StumpRec *tab = &stumps[sr.stump_off];
         // ---- LDS tiles for the small scales: a tw x tw block of windows reads a footprint of
         // ((tw-1)*ystep + reach)^2 integral samples; stage it once in LDS when it fits and is reused enough
-        int reach_x = 0, reach_y = 0;          // furthest corner any stump reads, relative to the window origin
-        for (int k = 0; k < nstumps; k++) {
-            const StumpRec &r = stumps[s * (size_t)nstumps + k];
-            for (int q = 0; q < r.nrect; q++) { reach_x = std::max(reach_x, r.p[q][3] % pitch); reach_y = std::max(reach_y, r.p[q][3] / pitch); }
-        }
-        int tw = 0;
-        if (use_tiles && (int)stages.size() > 1 && deep_stage > 1) {
+        int tw = 0, reach_x = 0, reach_y = 0;
+        if (use_tiles && sp.adaptive && sp.plane_off == 0 && (int)stages.size() > 1 && deep_stage > 1) {
+            for (int k = 0; k < nstumps; k++)
+                for (int q = 0; q < tab[k].nrect; q++) {
+                    reach_x = std::max(reach_x, tab[k].p[q][3] % pitch); reach_y = std::max(reach_y, tab[k].p[q][3] / pitch);
+                }
+            const double ystep = sr.endX > 1 ? (double)(xp[sr.endX - 1] - xp[0]) / (sr.endX - 1) : 2.;
             const int budget = std::min(kTileRows, kTilePitch - 4);
             tw = (int)std::floor((budget - 2 - std::max(reach_x, reach_y) - 1) / ystep) + 1;
             tw = std::min(tw, 16);
@@ -247,11 +256,12 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
         if (tw) {
             const int lds_off = (int)stumps_lds.size();
             for (int k = 0; k < nstumps; k++) {          // same records, offsets re-based to the LDS pitch
-                StumpRec r = stumps[s * (size_t)nstumps + k];
+                StumpRec r = tab[k];
                 for (int q = 0; q < r.nrect; q++)
                     for (int e = 0; e < 4; e++) r.p[q][e] = (r.p[q][e] / pitch) * kTilePitch + (r.p[q][e] % pitch);
                 stumps_lds.push_back(r);
             }
+            const int plane_rows = sp.plane_rows;
             for (int iy0 = 0; iy0 < sr.endY; iy0 += tw)
                 for (int ix0 = 0; ix0 < sr.endX; ix0 += tw) {
                     TileRec t; memset(&t, 0, sizeof(t));
@@ -260,7 +270,7 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
                     t.x0a = xp[ix0] & ~3; t.y0 = yp[iy0];
                     const int xend = std::min(xp[ix0 + t.tw - 1] + reach_x + 1, pitch);
                     t.rw4 = (xend - t.x0a + 3) / 4;
-                    t.rh = std::min(yp[iy0 + t.th - 1] + reach_y + 1, rows + 1) - t.y0;
+                    t.rh = std::min(yp[iy0 + t.th - 1] + reach_y + 1, plane_rows) - t.y0;
                     t.stump_off = lds_off;
                     tiles.push_back(t);
                     tile_w.push_back((long long)t.tw * t.th + 64);
@@ -278,6 +288,31 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
     blocks_per_frame = build_xcd_order(strip_w, order);
     tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
     return NVCA_OK;
+}
+
+// cvHaarDetectObjectsForROC, scale-cascade branch (flags without SCALE_IMAGE): one pair of integral planes,
+// features scaled by each factor, stride max(2, factor), adaptive x step.
+int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
+                                    int minw, int minh, int maxw, int maxh, std::string &err)
+{
+    std::vector<double> factors;
+    scale_grid(c.ow, c.oh, cols, rows, scaleFactor, minw, minh, maxw, maxh, false, factors);
+    std::vector<ScaleSpec> sp;
+    for (double factor : factors) {
+        const double ystep = std::max(2., factor);
+        ScaleSpec s;
+        s.table_factor = factor; s.plane_off = 0; s.pitch = pitch; s.plane_rows = rows + 1; s.adaptive = 1;
+        s.out_factor = 0; s.out_w = cv_round(c.ow * factor); s.out_h = cv_round(c.oh * factor);
+        const int endX = cv_round((cols - s.out_w) / ystep), endY = cv_round((rows - s.out_h) / ystep);
+        for (int ix = 0; ix < endX; ix++) s.xs.push_back(cv_round(ix * ystep));
+        for (int iy = 0; iy < endY; iy++) s.ys.push_back(cv_round(iy * ystep));
+        // cvRunHaarClassifierCascadeSum's own bound (x + w < cols + 1) always holds inside the loop limits
+        if (!s.xs.empty() && !s.ys.empty() && (s.xs.back() + s.out_w >= cols + 1 || s.ys.back() + s.out_h >= rows + 1)) {
+            err = "scan grid leaves the image"; return NVCA_ERR_ARG;
+        }
+        sp.push_back(std::move(s));
+    }
+    return build_custom(c, std::move(sp), true, err);
 }
 
 } // namespace nvca

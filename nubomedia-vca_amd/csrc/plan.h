@@ -9,6 +9,18 @@ void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw
 void build_scale_tables(const Cascade &c, double factor, int pitch, ScaleRec &sr, StumpRec *out);
 void build_stage_recs(const Cascade &c, std::vector<StageRec> &out);
 
+// one scan grid handed to the evaluator
+struct ScaleSpec {
+    double table_factor;        // factor passed to cvSetImagesForHaarClassifierCascade (1 for pyramid levels)
+    int plane_off, pitch;       // where this scale's integral planes live inside a slot
+    int plane_rows;             // rows of those planes (image rows + 1)
+    std::vector<int> xs, ys;    // window origins (plane coordinates) of the scan grid
+    int adaptive;               // OpenCV's adaptive x step (scale-cascade branch) or plain grid (scale-image)
+    // how a hit maps back to an image rectangle
+    double out_factor;          // scale-image: Rect(cvRound(x*f), cvRound(y*f), out_w, out_h); 0: Rect(x, y, out_w, out_h)
+    int out_w, out_h;
+};
+
 struct DetectPlan {
     // geometry of the working (gray) image the detector runs on
     int cols = 0, rows = 0, spitch = 0;
@@ -28,6 +40,9 @@ struct DetectPlan {
     // device copies
     DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_stumps_lds;
 
+    std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
+    int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
+    nvca_rect hit_rect(unsigned key) const;
     int build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                             int minw, int minh, int maxw, int maxh, std::string &err);
     int upload(nvca_ctx *ctx);

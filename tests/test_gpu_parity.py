@@ -272,3 +272,57 @@ def test_face_stream_device_frames(ctx, casc, orc_cascade):
     for i in range(4):
         eb, eid = ofs.process(frames[i])
         assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid)
+
+
+# ------------------------------------------------------------------ SCALE_IMAGE / FIND_BIGGEST variants
+VARIANT_CASES = [
+    (200, 160, "natural", [(40, 30, 80)], 1.1, (20, 20), 9),
+    (97, 83, "natural", [(10, 8, 60)], 1.1, (3, 3), 4),
+    (320, 180, "natural", [(100, 20, 120), (10, 60, 50)], 1.25, (3, 3), 5),
+    (160, 120, "noise", [(30, 20, 70)], 1.1, (1, 1), 6),
+    (64, 48, "gradient", [(8, 4, 40)], 1.1, (0, 0), 7),
+    (25, 25, "natural", [], 1.1, (0, 0), 8),
+]
+
+
+@pytest.mark.parametrize("w,h,kind,faces,sf,ms,seed", VARIANT_CASES)
+def test_detect_scale_image(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed):
+    import orc
+    from nubovca import capi, synth
+    g = orc.equalize_hist(synth.make_gray(w, h, seed, kind, faces))
+    raw = ctx.detect_raw(casc, g, sf, capi.HAAR_SCALE_IMAGE, ms)
+    eraw = orc.detect_raw(orc_cascade, g, sf, orc.HAAR_SCALE_IMAGE, ms)
+    assert np.array_equal(raw, eraw), (len(raw), len(eraw))
+    for mn in (2, 3):
+        det = ctx.detect_multiscale(casc, g, sf, mn, capi.HAAR_SCALE_IMAGE, ms)
+        assert np.array_equal(det, orc.detect_multiscale(orc_cascade, g, sf, mn, orc.HAAR_SCALE_IMAGE, ms))
+
+
+@pytest.mark.parametrize("w,h,kind,faces,sf,ms,seed", VARIANT_CASES)
+def test_detect_find_biggest(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed):
+    import orc
+    from nubovca import capi, synth
+    g = orc.equalize_hist(synth.make_gray(w, h, seed, kind, faces))
+    for flags in (capi.HAAR_FIND_BIGGEST_OBJECT, capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_DO_ROUGH_SEARCH,
+                  capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_SCALE_IMAGE):
+        det = ctx.detect_multiscale(casc, g, sf, 3, flags, ms)
+        exp = orc.detect_multiscale(orc_cascade, g, sf, 3, flags, ms)
+        assert np.array_equal(det, exp), (flags, det, exp)
+
+
+def test_detect_roi_view(ctx, casc, orc_cascade):
+    """detectMultiScale on a sub-matrix (pointer + parent stride), as the part detectors call it"""
+    import ctypes as C
+    import orc
+    from nubovca import capi, synth
+    full = orc.equalize_hist(synth.make_gray(320, 240, 21, "natural", [(90, 60, 100)]))
+    x0, y0, rw, rh = 70, 40, 160, 150
+    roi = full[y0:y0 + rh, x0:x0 + rw]
+    exp = orc.detect_multiscale(orc_cascade, np.ascontiguousarray(roi), 1.1, 2, orc.HAAR_SCALE_IMAGE, (20, 20))
+    buf = (capi.Rect * 64)()
+    n = C.c_int()
+    ctx.check(ctx.L.nvca_detect_multiscale(ctx.h, casc.h, full.ctypes.data + y0 * full.strides[0] + x0, rw, rh,
+                                           full.strides[0], capi.MEM_HOST, 1.1, 2, capi.HAAR_SCALE_IMAGE, 20, 20, 0, 0,
+                                           buf, 64, C.byref(n)))
+    got = np.array([[buf[i].x, buf[i].y, buf[i].w, buf[i].h] for i in range(n.value)], np.int32).reshape(-1, 4)
+    assert len(exp) >= 1 and np.array_equal(got, exp)
