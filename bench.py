@@ -112,19 +112,12 @@ def main():
         frames = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
     torch.cuda.synchronize()
     streams = [stream] * F
-    gather_in = torch.zeros((F, 1 + 4 * MAX_BOXES), dtype=torch.int32, device=dev)
-    gather_out = torch.zeros((world * F, 1 + 4 * MAX_BOXES), dtype=torch.int32, device=dev) if world > 1 else None
-    host_tab = np.zeros((F, 1 + 4 * MAX_BOXES), np.int32)
+    from nubovca import sharding
 
     def step():
         res = ctx.face_batch_process(streams, frames, cap=MAX_BOXES)
-        if world > 1:           # result gather (the only collective): fixed-size box table per stream tick
-            host_tab[:] = 0
-            for i, (b, _) in enumerate(res):
-                host_tab[i, 0] = len(b)
-                host_tab[i, 1:1 + 4 * len(b)] = b.reshape(-1)
-            gather_in.copy_(torch.from_numpy(host_tab))
-            dist.all_gather_into_tensor(gather_out, gather_in)
+        if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL
+            sharding.gather_tables(sharding.pack_boxes(res, MAX_BOXES), device=dev)
         return res
 
     def fence():

@@ -1,0 +1,57 @@
+"""Builds the GStreamer shim (libgstnubovca.so) and its test harness against the GStreamer 1.14
+development files under /opt/conda.  Optional: skipped when they are absent."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+CONDA = os.environ.get("NVCA_GST_PREFIX", "/opt/conda")
+INC = ["-I%s/include/gstreamer-1.0" % CONDA, "-I%s/include/glib-2.0" % CONDA, "-I%s/lib/glib-2.0/include" % CONDA,
+       "-I%s/include" % ROOT]
+LIBS = ["-L%s/lib" % CONDA, "-lgstvideo-1.0", "-lgstbase-1.0", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0",
+        # system libstdc++ must win over conda's older copy (libnubovca_hip needs GLIBCXX_3.4.29)
+        "-Wl,--disable-new-dtags", "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:%s/lib" % CONDA]
+PLUGIN = os.path.join(HERE, "libgstnubovca.so")
+HARNESS = os.path.join(HERE, "gst_harness")
+
+
+def available():
+    return os.path.exists(os.path.join(CONDA, "include/gstreamer-1.0/gst/video/gstvideofilter.h"))
+
+
+def _stale(out, srcs):
+    return not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs)
+
+
+def build(required=True):
+    if not available():
+        if required:
+            raise RuntimeError("GStreamer development files not found under %s" % CONDA)
+        return None
+    src = os.path.join(HERE, "gstnubovca.cpp")
+    hdr = os.path.join(ROOT, "include", "nubovca.h")
+    if _stale(PLUGIN, [src, hdr, __file__]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-deprecated-declarations", src, "-o", PLUGIN]
+                              + INC + LIBS + ["-L" + PKG, "-lnubovca_hip", "-Wl,-rpath,$ORIGIN/.."])
+    hs = os.path.join(HERE, "gst_harness.cpp")
+    if _stale(HARNESS, [hs, __file__]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", hs, "-o", HARNESS] + INC + LIBS)
+    return PLUGIN
+
+
+def env():
+    """environment for running pipelines with the shim"""
+    e = dict(os.environ)
+    e["GST_PLUGIN_PATH"] = HERE
+    e["GST_PLUGIN_SYSTEM_PATH"] = os.path.join(CONDA, "lib", "gstreamer-1.0")
+    e["GST_REGISTRY"] = os.path.join("/tmp", "nubovca-gst-registry-%d.bin" % os.getuid())
+    sysstd = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sysstd):          # conda's gst tools would otherwise pull conda's older libstdc++ first
+        e["LD_PRELOAD"] = sysstd + (":" + e["LD_PRELOAD"] if e.get("LD_PRELOAD") else "")
+    return e
+
+
+if __name__ == "__main__":
+    print(build(required=True))

@@ -1,0 +1,82 @@
+// gst_harness.cpp -- test driver for the GStreamer shim: pushes raw frames from a file through
+//   filesrc ! rawvideoparse ! <element> ! fakesink
+// and prints what an unmodified downstream would observe: every CUSTOM_DOWNSTREAM "message" event
+// leaving the element (one line per frame: "event <pts> x,y,w,h;...") and every string signal
+// ("signal <payload>").  Usage:
+//   gst_harness <element> <format BGR|BGRA> <width> <height> <frames.raw> [prop=value ...]
+#include <gst/gst.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer)
+{
+    GstEvent *ev = GST_PAD_PROBE_INFO_EVENT(info);
+    if (GST_EVENT_TYPE(ev) != GST_EVENT_CUSTOM_DOWNSTREAM) return GST_PAD_PROBE_OK;
+    const GstStructure *m = gst_event_get_structure(ev);
+    if (!m || !gst_structure_has_name(m, "message")) return GST_PAD_PROBE_OK;
+    guint64 pts = 0;
+    std::string line;
+    const gint n = gst_structure_n_fields(m);
+    for (gint i = 0; i < n; i++) {
+        const gchar *name = gst_structure_nth_field_name(m, i);
+        GstStructure *sub = NULL;
+        if (!gst_structure_get(m, name, GST_TYPE_STRUCTURE, &sub, NULL) || !sub) continue;
+        if (!strcmp(name, "timestamp")) gst_structure_get(sub, "pts", G_TYPE_UINT64, &pts, NULL);
+        else {
+            guint x = 0, y = 0, w = 0, h = 0;
+            gst_structure_get(sub, "x", G_TYPE_UINT, &x, "y", G_TYPE_UINT, &y, "width", G_TYPE_UINT, &w, "height", G_TYPE_UINT, &h, NULL);
+            const gchar *type = gst_structure_get_string(sub, "type");
+            char b[128]; snprintf(b, sizeof(b), "%s:%u,%u,%u,%u;", type ? type : "?", x, y, w, h);
+            line += b;
+        }
+        gst_structure_free(sub);
+    }
+    printf("event %llu %s\n", (unsigned long long)pts, line.c_str());
+    fflush(stdout);
+    return GST_PAD_PROBE_OK;
+}
+static void on_signal(GstElement *, const gchar *payload, gpointer) { printf("signal %s\n", payload); fflush(stdout); }
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s element format width height file [prop=value...]\n", argv[0]); return 2; }
+    gst_init(&argc, &argv);
+    GstElement *pipe = gst_pipeline_new("p");
+    GstElement *src = gst_element_factory_make("filesrc", NULL), *parse = gst_element_factory_make("rawvideoparse", NULL);
+    GstElement *el = gst_element_factory_make(argv[1], "el"), *sink = gst_element_factory_make("fakesink", NULL);
+    if (!src || !parse || !el || !sink) { fprintf(stderr, "missing element (%s?)\n", argv[1]); return 3; }
+    const bool bgra = !strcmp(argv[2], "BGRA");
+    g_object_set(src, "location", argv[5], NULL);
+    gst_util_set_object_arg(G_OBJECT(parse), "format", bgra ? "bgra" : "bgr");
+    g_object_set(parse, "width", atoi(argv[3]), "height", atoi(argv[4]), NULL);
+    gst_util_set_object_arg(G_OBJECT(parse), "framerate", "30/1");
+    for (int i = 6; i < argc; i++) {
+        char *eq = strchr(argv[i], '=');
+        if (!eq) continue;
+        *eq = 0;
+        gst_util_set_object_arg(G_OBJECT(el), argv[i], eq + 1);
+    }
+    gst_bin_add_many(GST_BIN(pipe), src, parse, el, sink, NULL);
+    if (!gst_element_link_many(src, parse, el, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }
+    GstPad *sp = gst_element_get_static_pad(el, "src");
+    gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_EVENT_DOWNSTREAM, on_event, NULL, NULL);
+    gst_object_unref(sp);
+    const char *sig = !strcmp(argv[1], "nubotracker") ? "tracker-event" : "face-event";
+    if (g_signal_lookup(sig, G_OBJECT_TYPE(el))) g_signal_connect(el, sig, G_CALLBACK(on_signal), NULL);
+    gst_element_set_state(pipe, GST_STATE_PLAYING);
+    GstBus *bus = gst_element_get_bus(pipe);
+    GstMessage *msg = gst_bus_timed_pop_filtered(bus, 120 * GST_SECOND, (GstMessageType)(GST_MESSAGE_EOS | GST_MESSAGE_ERROR));
+    int rc = 0;
+    if (!msg) { fprintf(stderr, "timeout\n"); rc = 5; }
+    else if (GST_MESSAGE_TYPE(msg) == GST_MESSAGE_ERROR) {
+        GError *e = NULL; gst_message_parse_error(msg, &e, NULL);
+        fprintf(stderr, "pipeline error: %s\n", e ? e->message : "?"); rc = 6;
+    }
+    if (msg) gst_message_unref(msg);
+    gst_element_set_state(pipe, GST_STATE_NULL);
+    gst_object_unref(bus); gst_object_unref(pipe);
+    printf("done %d\n", rc);
+    return rc;
+}

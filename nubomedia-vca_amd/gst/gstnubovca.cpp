@@ -1,0 +1,398 @@
+// gstnubovca.cpp -- GStreamer shim: the reference's element surface
+// on top of libnubovca_hip's C ABI.  Written from scratch; it keeps, per element,
+//   factory name, GstVideoFilter base, in-place transform, caps, property names /
+//   ranges / initial values, the string signal and the downstream custom event
+// of the reference so that an unmodified pipeline (or Kurento's generic filter with
+// "filter-factory" = element name) keeps working:
+//   nubofacedetector  FACE/kmsfacedetect.cpp   (caps BGR  :129-133, props :1043-1102, signal "face-event" :1108-1113,
+//                                               event "message" :196-226, motion events :680-755)
+//   nubotracker       TRK/gstnubotracker.cpp   (caps BGRA :57-61,  props :504-542,  signal "tracker-event" :547-552)
+// All pixel work happens in the library (HIP); this file is glue only.  One plugin
+// ("nubovca") registers every factory; the reference ships one plugin per element.
+#include <gst/gst.h>
+#include <gst/video/video.h>
+#include <gst/video/gstvideofilter.h>
+#include <sys/time.h>
+#include <time.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <mutex>
+#include "nubovca.h"
+
+GST_DEBUG_CATEGORY_STATIC(nubovca_debug);
+#define GST_CAT_DEFAULT nubovca_debug
+
+#define OPENCV_CASCADE_DIR "/usr/share/opencv/haarcascades"     /* FACE/kmsfacedetect.cpp:40 */
+
+// ---------------------------------------------------------------- shared context (one per process / GPU)
+static std::mutex g_ctx_mutex;
+static nvca_ctx *g_ctx = nullptr;
+static nvca_ctx *shared_ctx()
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    if (!g_ctx) {
+        const char *dev = getenv("NVCA_DEVICE");
+        int rc = nvca_ctx_create(dev ? atoi(dev) : 0, &g_ctx);
+        if (rc != NVCA_OK) { GST_ERROR("nvca_ctx_create failed (%d): no HIP device; frames pass through untouched", rc); g_ctx = nullptr; }
+    }
+    return g_ctx;
+}
+static std::string cascade_path(const char *file)
+{
+    const char *dir = getenv("NVCA_CASCADE_DIR");
+    return std::string(dir ? dir : OPENCV_CASCADE_DIR) + "/" + file;
+}
+static double now_ms()
+{
+    struct timeval t; gettimeofday(&t, NULL);
+    return t.tv_sec * 1000.0 + t.tv_usec / 1000.0;
+}
+
+// =====================================================================================
+// nubofacedetector
+// =====================================================================================
+struct NvcaFace {
+    GstVideoFilter base;
+    GRecMutex mutex;
+    nvca_cascade *cascade; nvca_face_stream *stream;
+    nvca_face_params p;
+    int view_faces, send_meta_data, server_events, events_ms;
+    double time_events_ms;
+    GQueue *events_queue;
+    GstStructure *image_to_overlay;
+};
+struct NvcaFaceClass { GstVideoFilterClass parent; };
+G_DEFINE_TYPE(NvcaFace, nvca_face, GST_TYPE_VIDEO_FILTER)
+
+enum { FP_0, FP_VIEW, FP_DETECT_EVENT, FP_META, FP_WIDTH, FP_X_EVERY_4, FP_EUCLID, FP_TRACK, FP_AREA, FP_SCALE, FP_EVENTS,
+       FP_EVENTS_MS, FP_OVERLAY };
+static guint face_signal = 0;
+
+static void face_sync_params(NvcaFace *f) { if (f->stream) nvca_face_stream_set_params(f->stream, &f->p); }
+
+static void nvca_face_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
+{
+    NvcaFace *f = (NvcaFace *)o;
+    g_rec_mutex_lock(&f->mutex);
+    switch (id) {
+    case FP_VIEW: f->view_faces = g_value_get_int(v); break;
+    case FP_DETECT_EVENT: f->p.detect_event = g_value_get_int(v); break;
+    case FP_META: f->send_meta_data = g_value_get_int(v); break;
+    case FP_X_EVERY_4: f->p.process_x_every_4 = g_value_get_int(v); break;
+    case FP_WIDTH: f->p.width_to_process = g_value_get_int(v); break;
+    case FP_SCALE: f->p.scale_factor_pct = g_value_get_int(v); break;
+    case FP_EUCLID: f->p.euclidean_threshold = g_value_get_int(v); break;
+    case FP_TRACK: f->p.euclidean_threshold = g_value_get_int(v); break;   /* sic: FACE/kmsfacedetect.cpp:548-550 */
+    case FP_AREA: f->p.area_threshold = g_value_get_int(v); break;
+    case FP_EVENTS: f->server_events = g_value_get_int(v); f->time_events_ms = now_ms(); break;
+    case FP_EVENTS_MS: f->events_ms = g_value_get_int(v); break;
+    case FP_OVERLAY:
+        if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
+        f->image_to_overlay = (GstStructure *)g_value_dup_boxed(v);      /* accepted; overlay drawing is out of scope */
+        break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    face_sync_params(f);
+    g_rec_mutex_unlock(&f->mutex);
+}
+static void nvca_face_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
+{
+    NvcaFace *f = (NvcaFace *)o;
+    g_rec_mutex_lock(&f->mutex);
+    switch (id) {
+    case FP_VIEW: g_value_set_int(v, f->view_faces); break;
+    case FP_DETECT_EVENT: g_value_set_int(v, f->p.detect_event); break;
+    case FP_META: g_value_set_int(v, f->send_meta_data); break;
+    case FP_X_EVERY_4: g_value_set_int(v, f->p.process_x_every_4); break;
+    case FP_WIDTH: g_value_set_int(v, f->p.width_to_process); break;
+    case FP_SCALE: g_value_set_int(v, f->p.scale_factor_pct); break;
+    case FP_EUCLID: g_value_set_int(v, f->p.euclidean_threshold); break;
+    case FP_TRACK: g_value_set_int(v, f->p.track_threshold); break;
+    case FP_AREA: g_value_set_int(v, f->p.area_threshold); break;
+    case FP_EVENTS: g_value_set_int(v, f->server_events); break;
+    case FP_EVENTS_MS: g_value_set_int(v, f->events_ms); break;
+    case FP_OVERLAY: g_value_set_boxed(v, f->image_to_overlay); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    g_rec_mutex_unlock(&f->mutex);
+}
+
+// a queued upstream "message": does it carry a "motion" structure?  (FACE/kmsfacedetect.cpp:680-712)
+static bool message_has_motion(const GstStructure *m)
+{
+    const gint len = gst_structure_n_fields(m);
+    for (gint i = 0; i < len; i++) {
+        const gchar *name = gst_structure_nth_field_name(m, i);
+        if (g_strcmp0(name, "motion") == 0 && gst_structure_has_field_typed(m, name, GST_TYPE_STRUCTURE)) return true;
+    }
+    return false;
+}
+
+static gboolean nvca_face_sink_event(GstBaseTransform *trans, GstEvent *event)
+{
+    NvcaFace *f = (NvcaFace *)trans;
+    if (GST_EVENT_TYPE(event) == GST_EVENT_CUSTOM_DOWNSTREAM) {
+        const GstStructure *s = gst_event_get_structure(event);
+        if (s) { GST_OBJECT_LOCK(f); g_queue_push_tail(f->events_queue, gst_structure_copy(s)); GST_OBJECT_UNLOCK(f); }
+    }
+    return GST_BASE_TRANSFORM_CLASS(nvca_face_parent_class)->sink_event(trans, event);
+}
+
+static void face_lazy_init(NvcaFace *f)
+{
+    if (f->stream) return;
+    nvca_ctx *ctx = shared_ctx();
+    if (!ctx) return;
+    if (!f->cascade) {
+        const std::string path = cascade_path("haarcascade_frontalface_alt.xml");
+        if (nvca_cascade_load_xml(ctx, path.c_str(), &f->cascade) != NVCA_OK) {
+            GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));   /* :167-176: logged, not fatal */
+            f->cascade = nullptr;
+            return;
+        }
+    }
+    if (nvca_face_stream_create(ctx, f->cascade, &f->p, &f->stream) != NVCA_OK) f->stream = nullptr;
+}
+
+static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
+{
+    NvcaFace *f = (NvcaFace *)filter;
+    g_rec_mutex_lock(&f->mutex);
+    face_lazy_init(f);
+    if (f->stream && f->p.width_to_process > 0) {
+        // upstream "motion" messages arm the detector when detect-event = 1
+        GST_OBJECT_LOCK(f);
+        while (GstStructure *m = (GstStructure *)g_queue_pop_head(f->events_queue)) {
+            if (f->p.detect_event && message_has_motion(m)) nvca_face_stream_motion_event(f->stream);
+            gst_structure_free(m);
+        }
+        GST_OBJECT_UNLOCK(f);
+        nvca_frame nf;
+        nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+        nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);
+        nf.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
+        nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
+        nvca_rect boxes[256]; int n = 0;
+        const int rc = nvca_face_stream_process(f->stream, &nf, boxes, NULL, 256, &n);
+        if (rc != NVCA_OK) GST_ERROR("nvca_face_stream_process: %d", rc);
+        else {
+            if (n > 256) n = 256;
+            // kms_face_send_event :179-249
+            GstStructure *message = gst_structure_new_empty("message");
+            GstStructure *ts = gst_structure_new("time", "pts", G_TYPE_UINT64, GST_BUFFER_PTS(frame->buffer), NULL);
+            gst_structure_set(message, "timestamp", GST_TYPE_STRUCTURE, ts, NULL);
+            gst_structure_free(ts);
+            std::string faces_str;
+            for (int i = 0; i < n; i++) {
+                GstStructure *face = gst_structure_new("face", "type", G_TYPE_STRING, "face", "x", G_TYPE_UINT, (guint)boxes[i].x,
+                                                       "y", G_TYPE_UINT, (guint)boxes[i].y, "width", G_TYPE_UINT, (guint)boxes[i].w,
+                                                       "height", G_TYPE_UINT, (guint)boxes[i].h, NULL);
+                char id[16]; snprintf(id, sizeof(id), "%d", i);
+                gst_structure_set(message, id, GST_TYPE_STRUCTURE, face, NULL);
+                gst_structure_free(face);
+                faces_str += "x:" + std::to_string((guint)boxes[i].x) + ",y:" + std::to_string((guint)boxes[i].y) +
+                             ",width:" + std::to_string((guint)boxes[i].w) + ",height:" + std::to_string((guint)boxes[i].h) + ";";
+            }
+            gst_pad_push_event(GST_BASE_TRANSFORM(f)->srcpad, gst_event_new_custom(GST_EVENT_CUSTOM_DOWNSTREAM, message));
+            if (n > 0) {
+                const double t = now_ms();
+                if (1 == f->server_events && t - f->time_events_ms > f->events_ms) {
+                    f->time_events_ms = t;
+                    g_signal_emit(G_OBJECT(f), face_signal, 0, faces_str.c_str());
+                }
+            }
+        }
+    }
+    g_rec_mutex_unlock(&f->mutex);
+    return GST_FLOW_OK;                                     /* always: FACE/kmsfacedetect.cpp:897 */
+}
+
+static void nvca_face_finalize(GObject *o)
+{
+    NvcaFace *f = (NvcaFace *)o;
+    if (f->stream) nvca_face_stream_destroy(f->stream);
+    if (f->cascade) nvca_cascade_free(f->cascade);
+    if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
+    g_queue_free_full(f->events_queue, (GDestroyNotify)gst_structure_free);
+    g_rec_mutex_clear(&f->mutex);
+    G_OBJECT_CLASS(nvca_face_parent_class)->finalize(o);
+}
+
+static void nvca_face_init(NvcaFace *f)
+{
+    nvca_face_params_default(&f->p);                        /* defaults of FACE/kmsfacedetect.cpp:979-999 */
+    f->view_faces = 0; f->send_meta_data = 0; f->server_events = 0; f->events_ms = 30001; f->time_events_ms = 0;
+    f->cascade = nullptr; f->stream = nullptr; f->image_to_overlay = nullptr;
+    f->events_queue = g_queue_new();
+    g_rec_mutex_init(&f->mutex);
+}
+
+#define INT_PROP(klass, id, name, nick, blurb, lo, hi) \
+    g_object_class_install_property(klass, id, g_param_spec_int(name, nick, blurb, lo, hi, 0, (GParamFlags)G_PARAM_READWRITE))
+
+static void nvca_face_class_init(NvcaFaceClass *klass)
+{
+    GObjectClass *go = G_OBJECT_CLASS(klass);
+    GstVideoFilterClass *vf = GST_VIDEO_FILTER_CLASS(klass);
+    GstCaps *caps = gst_caps_from_string(GST_VIDEO_CAPS_MAKE("{ BGR }"));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, caps));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, caps));
+    gst_caps_unref(caps);
+    gst_element_class_set_static_metadata(GST_ELEMENT_CLASS(klass), "face detection filter element", "Video/Filter",
+                                          "Haar face detector (MI355X / HIP implementation of NuboFaceDetector)", "nubovca-hip");
+    go->set_property = nvca_face_set_property; go->get_property = nvca_face_get_property; go->finalize = nvca_face_finalize;
+    INT_PROP(go, FP_VIEW, "view-faces", "view faces", "draw or hide the detected faces on the stream", 0, 1);
+    INT_PROP(go, FP_DETECT_EVENT, "detect-event", "detect event", "0 => always; 1 => only after a motion event", 0, 1);
+    INT_PROP(go, FP_META, "send-meta-data", "send meta data", "0 (default) => no meta data; 1 => send the face boxes as metadata", 0, 1);
+    INT_PROP(go, FP_WIDTH, "width-to-process", "width to process", "width of the image the algorithm processes", 0, 640);
+    INT_PROP(go, FP_X_EVERY_4, "process-x-every-4-frames", "process x every 4 frames", "1,2,3,4 (default)", 0, 4);
+    INT_PROP(go, FP_EUCLID, "euclidean-distance", "euclidean distance", "0 - 20 (8 default)", 0, 20);
+    INT_PROP(go, FP_TRACK, "track-threshold", "track threshold", "0 - 100 (30 default)", 0, 100);
+    INT_PROP(go, FP_AREA, "area-threshold", "area threshold", "0 - 1000 (500 default)", 0, 1000);
+    INT_PROP(go, FP_SCALE, "multi-scale-factor", "multi scale factor", "5-50 (25 default)", 0, 51);
+    INT_PROP(go, FP_EVENTS, "activate-events", "Activate Events", "0 (default) => no events to the server; 1 => send events", 0, 1);
+    INT_PROP(go, FP_EVENTS_MS, "events-ms", "Activate Events", "the time, it takes to send events to the servers", 0, 30000);
+    g_object_class_install_property(go, FP_OVERLAY, g_param_spec_boxed("image-to-overlay", "image to overlay",
+                                    "set the url of the image to overlay the faces", GST_TYPE_STRUCTURE,
+                                    (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
+    vf->transform_frame_ip = GST_DEBUG_FUNCPTR(nvca_face_transform_frame_ip);
+    GST_BASE_TRANSFORM_CLASS(klass)->sink_event = GST_DEBUG_FUNCPTR(nvca_face_sink_event);
+    face_signal = g_signal_new("face-event", G_TYPE_FROM_CLASS(klass), G_SIGNAL_RUN_LAST, 0, NULL, NULL, NULL, G_TYPE_NONE, 1,
+                               G_TYPE_STRING);
+}
+
+// =====================================================================================
+// nubotracker
+// =====================================================================================
+struct NvcaTrk {
+    GstVideoFilter base;
+    GRecMutex mutex;
+    nvca_tracker *trk;
+    nvca_tracker_params p;
+    int visual_mode, server_events, events_ms;
+    double time_events_ms;
+};
+struct NvcaTrkClass { GstVideoFilterClass parent; };
+G_DEFINE_TYPE(NvcaTrk, nvca_trk, GST_TYPE_VIDEO_FILTER)
+enum { TP_0, TP_THRESHOLD, TP_MIN_AREA, TP_MAX_AREA, TP_DISTANCE, TP_VISUAL, TP_EVENTS, TP_EVENTS_MS };
+static guint trk_signal = 0;
+
+static void nvca_trk_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
+{
+    NvcaTrk *t = (NvcaTrk *)o;
+    g_rec_mutex_lock(&t->mutex);
+    switch (id) {
+    case TP_THRESHOLD: t->p.threshold = g_value_get_int(v); break;
+    case TP_MIN_AREA: t->p.min_area = g_value_get_int(v); break;
+    case TP_MAX_AREA: t->p.max_area = g_value_get_long(v); break;
+    case TP_DISTANCE: t->p.distance = g_value_get_int(v); break;
+    case TP_VISUAL: t->visual_mode = g_value_get_int(v); break;
+    case TP_EVENTS: t->server_events = g_value_get_int(v); t->time_events_ms = now_ms(); break;
+    case TP_EVENTS_MS: t->events_ms = g_value_get_int(v); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    if (t->trk) nvca_tracker_set_params(t->trk, &t->p);
+    g_rec_mutex_unlock(&t->mutex);
+}
+static void nvca_trk_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
+{
+    NvcaTrk *t = (NvcaTrk *)o;
+    g_rec_mutex_lock(&t->mutex);
+    switch (id) {
+    case TP_THRESHOLD: g_value_set_int(v, t->p.threshold); break;
+    case TP_MIN_AREA: g_value_set_int(v, t->p.min_area); break;
+    case TP_MAX_AREA: g_value_set_long(v, t->p.max_area); break;
+    case TP_DISTANCE: g_value_set_int(v, t->p.distance); break;
+    case TP_VISUAL: g_value_set_int(v, t->visual_mode); break;
+    case TP_EVENTS: g_value_set_int(v, t->server_events); break;
+    case TP_EVENTS_MS: g_value_set_int(v, t->events_ms); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    g_rec_mutex_unlock(&t->mutex);
+}
+
+static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
+{
+    NvcaTrk *t = (NvcaTrk *)filter;
+    g_rec_mutex_lock(&t->mutex);
+    if (!t->trk) { nvca_ctx *ctx = shared_ctx(); if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
+    if (t->trk) {
+        nvca_frame nf;
+        nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+        nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);
+        nf.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
+        nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
+        const double timestamp = 1000.0 * clock() / CLOCKS_PER_SEC;          /* TRK/gstnubotracker.cpp:349 */
+        int n = 0;
+        nvca_rect *bx = (nvca_rect *)g_malloc(sizeof(nvca_rect) * 4096);
+        const int rc = nvca_tracker_process(t->trk, &nf, timestamp, bx, 4096, &n);
+        if (rc != NVCA_OK) GST_ERROR("nvca_tracker_process: %d", rc);
+        else if (n > 0) {
+            if (n > 4096) n = 4096;
+            std::string s;
+            if (1 == t->server_events)
+                for (int i = 0; i < n; i++)
+                    s += "x:" + std::to_string((guint)bx[i].x) + ",y:" + std::to_string((guint)bx[i].y) + ",width:" +
+                         std::to_string((guint)bx[i].w) + ",height:" + std::to_string((guint)bx[i].h) + ";";
+            const double now = now_ms();
+            if (1 == t->server_events && now - t->time_events_ms > t->events_ms) {   /* :402-414 */
+                t->time_events_ms = now;
+                g_signal_emit(G_OBJECT(t), trk_signal, 0, s.c_str());
+            }
+        }
+        g_free(bx);
+    }
+    g_rec_mutex_unlock(&t->mutex);
+    return GST_FLOW_OK;
+}
+
+static void nvca_trk_finalize(GObject *o)
+{
+    NvcaTrk *t = (NvcaTrk *)o;
+    if (t->trk) nvca_tracker_destroy(t->trk);
+    g_rec_mutex_clear(&t->mutex);
+    G_OBJECT_CLASS(nvca_trk_parent_class)->finalize(o);
+}
+static void nvca_trk_init(NvcaTrk *t)
+{
+    nvca_tracker_params_default(&t->p);                     /* TRK/gstnubotracker.cpp:457-466 */
+    t->visual_mode = 0; t->server_events = 0; t->events_ms = 30001; t->time_events_ms = 0; t->trk = nullptr;
+    g_rec_mutex_init(&t->mutex);
+}
+static void nvca_trk_class_init(NvcaTrkClass *klass)
+{
+    GObjectClass *go = G_OBJECT_CLASS(klass);
+    GstCaps *caps = gst_caps_from_string(GST_VIDEO_CAPS_MAKE("{ BGRA }"));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, caps));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, caps));
+    gst_caps_unref(caps);
+    gst_element_class_set_static_metadata(GST_ELEMENT_CLASS(klass), "motion tracker filter element", "Video/Filter",
+                                          "Motion-history tracker (MI355X / HIP implementation of NuboTracker)", "nubovca-hip");
+    go->set_property = nvca_trk_set_property; go->get_property = nvca_trk_get_property; go->finalize = nvca_trk_finalize;
+    INT_PROP(go, TP_THRESHOLD, "set_threshold", "threshold", "motion threshold (20 default)", 0, 255);
+    INT_PROP(go, TP_MIN_AREA, "set_min_area", "min area", "minimum object area (50 default)", 0, 10000);
+    g_object_class_install_property(go, TP_MAX_AREA, g_param_spec_long("set_max_area", "max area", "maximum object area (30000 default)",
+                                                                       0, 300000, 0, (GParamFlags)G_PARAM_READWRITE));
+    INT_PROP(go, TP_DISTANCE, "set_distance", "distance", "merge distance (35 default)", 0, 2000);
+    INT_PROP(go, TP_VISUAL, "set_visual_mode", "visual mode", "draw the objects (0 default)", 0, 4);
+    INT_PROP(go, TP_EVENTS, "activate-events", "Activate Events", "0 (default) => no events to the server", 0, 1);
+    INT_PROP(go, TP_EVENTS_MS, "events-ms", "Activate Events", "the time, it takes to send events to the servers", 0, 30000);
+    GST_VIDEO_FILTER_CLASS(klass)->transform_frame_ip = GST_DEBUG_FUNCPTR(nvca_trk_transform_frame_ip);
+    trk_signal = g_signal_new("tracker-event", G_TYPE_FROM_CLASS(klass), G_SIGNAL_RUN_LAST, 0, NULL, NULL, NULL, G_TYPE_NONE, 1,
+                              G_TYPE_STRING);
+}
+
+// =====================================================================================
+static gboolean plugin_init(GstPlugin *plugin)
+{
+    GST_DEBUG_CATEGORY_INIT(nubovca_debug, "nubovca", 0, "NUBOMEDIA-VCA Haar path on MI355X");
+    return gst_element_register(plugin, "nubofacedetector", GST_RANK_NONE, nvca_face_get_type()) &&
+           gst_element_register(plugin, "nubotracker", GST_RANK_NONE, nvca_trk_get_type());
+}
+
+#ifndef PACKAGE
+#define PACKAGE "nubovca"
+#endif
+GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, nubovca, "NUBOMEDIA-VCA detection filters on MI355X (HIP)", plugin_init,
+                  "0.1", "LGPL", "nubovca-hip", "https://github.com/nubomedia/NUBOMEDIA-VCA")

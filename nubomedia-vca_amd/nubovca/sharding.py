@@ -1,0 +1,48 @@
+"""Multi-GPU frontend plumbing: media streams are the independent units (each has private temporal
+state -- Faces list, MHI, previous gray), so they are sharded statically over ranks and never migrate;
+the only collective is the per-tick gather of a fixed-size box table.
+Works with any torch.distributed backend ("nccl" == RCCL on the GPU box, "gloo" in CPU tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def streams_of_rank(n_streams, world, rank):
+    """static assignment stream_id % world == rank"""
+    return [s for s in range(n_streams) if s % world == rank]
+
+
+def pack_boxes(results, max_boxes):
+    """results: list of (boxes[n,4], ids[n]) per local stream -> int32 [n_local, 1 + 4*max_boxes]"""
+    tab = np.zeros((len(results), 1 + 4 * max_boxes), np.int32)
+    for i, (b, _) in enumerate(results):
+        n = min(len(b), max_boxes)
+        tab[i, 0] = n
+        tab[i, 1:1 + 4 * n] = np.asarray(b[:n], np.int32).reshape(-1)
+    return tab
+
+
+def unpack_boxes(tab):
+    return [np.asarray(row[1:1 + 4 * int(row[0])], np.int32).reshape(-1, 4) for row in np.asarray(tab)]
+
+
+def gather_tables(local_tab, device=None):
+    """all_gather of equally shaped tables; returns [world, n_local, cols] (numpy) on every rank"""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    t = torch.from_numpy(np.ascontiguousarray(local_tab))
+    if device is not None:
+        t = t.to(device)
+    if world == 1:
+        return t.cpu().numpy()[None]
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().reshape((world,) + tuple(t.shape))
+
+
+def merge_by_stream(gathered, n_streams, world):
+    """gathered[r][j] belongs to stream streams_of_rank(...)[j]; returns per-stream list of boxes"""
+    res = [None] * n_streams
+    for r in range(world):
+        for j, s in enumerate(streams_of_rank(n_streams, world, r)):
+            res[s] = unpack_boxes(gathered[r][j:j + 1])[0]
+    return res

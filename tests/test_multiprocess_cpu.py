@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks shard four streams (stream_id % world), run their share, all_gather the
+fixed-size box tables and reproduce the single-process result.  The detector itself needs a GPU, so the CPU
+oracle stands in for it here (test infrastructure); what is under test is sharding + gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_STREAMS, N_FRAMES, W, H, MAXB = 4, 3, 320, 240, 16
+
+
+def _frames(stream):
+    from nubovca import synth
+    return [synth.make_bgr(W, H, synth.frame_seed(stream, i), "natural", [(40 + 10 * i + 20 * stream, 40, 120)]) for i in range(N_FRAMES)]
+
+
+def _run_streams(streams, xml):
+    import orc
+    oc = orc.parse_cascade_xml(xml)
+    out = {}
+    for s in streams:
+        fs = orc.FaceStream(oc, width_to_process=320, scale_factor_pct=10)
+        out[s] = [fs.process(f) for f in _frames(s)]
+    return out
+
+
+def _worker(rank, world, port, xml, q):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "nubomedia-vca_amd")):
+        sys.path.insert(0, p)
+    from nubovca import sharding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    mine = sharding.streams_of_rank(N_STREAMS, world, rank)
+    res = _run_streams(mine, xml)
+    merged = []
+    for i in range(N_FRAMES):
+        tab = sharding.pack_boxes([res[s][i] for s in mine], MAXB)
+        g = sharding.gather_tables(tab)
+        merged.append(sharding.merge_by_stream(g, N_STREAMS, world))
+    dist.barrier()
+    if rank == 0:
+        q.put([[b.tolist() for b in tick] for tick in merged])
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process(synth_xml):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, synth_xml, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    merged, t0 = None, time.time()
+    while merged is None and time.time() - t0 < 240:
+        try:
+            merged = q.get(timeout=2)
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert merged is not None
+    single = _run_streams(range(N_STREAMS), synth_xml)
+    seen = 0
+    for i in range(N_FRAMES):
+        for st in range(N_STREAMS):
+            assert merged[i][st] == single[st][i][0].tolist()
+            seen += len(merged[i][st])
+    assert seen > 0
+
+
+def test_pack_unpack_roundtrip():
+    from nubovca import sharding
+    rng = np.random.default_rng(0)
+    res = [(rng.integers(0, 1000, size=(n, 4)).astype(np.int32), np.arange(n)) for n in (0, 1, 5, 16, 20)]
+    tab = sharding.pack_boxes(res, 16)
+    back = sharding.unpack_boxes(tab)
+    for (b, _), r in zip(res, back):
+        assert np.array_equal(r, b[:16])
+    assert sharding.streams_of_rank(10, 4, 1) == [1, 5, 9]
