@@ -124,6 +124,9 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
 /* cv::equalizeHist FACE/kmsfacedetect.cpp:807 */
 int nvca_equalize_hist(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
                        void *dst_gray, int dst_stride);
+/* cv::flip(src, dst, 1) EAR/kmseardetect.cpp:800 */
+int nvca_flip_horizontal(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
+                         void *dst_gray, int dst_stride);
 /* cv::integral as used inside detectMultiScale: sum int32 and sqsum float64,
  * both dense (h+1)*(w+1) */
 int nvca_integral(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
@@ -183,6 +186,39 @@ int  nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca
 int  nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams,
                              const nvca_frame *frames, nvca_rect *out, int *ids, int cap,
                              int *n_out);
+
+/* ---- part detectors: NuboEyeDetector / NuboNoseDetector / NuboMouthDetector / NuboEarDetector ----
+ * One handle == one element instance.  Replaces kms_{eye,nose,mouth,ear}_detect_conf_images +
+ * _process_frame (EYE/kmseyedetect.cpp:310-341,915-1064; NOSE/kmsnosedetect.cpp:275-308,792-868;
+ * MOUTH/kmsmouthdetect.cpp:285-315,798-873; EAR/kmseardetect.cpp:292-319,644-729,767-812): gray (+equalize) at
+ * full resolution, a face pass on the 160-px image (or faces handed over by an upstream element), then per face
+ * the reference's ROI geometry and part cascades; the per-frame merging heuristics stay on the host. */
+#define NVCA_PART_EYE   0
+#define NVCA_PART_NOSE  1
+#define NVCA_PART_MOUTH 2
+#define NVCA_PART_EAR   3
+typedef struct nvca_part_stream nvca_part_stream;
+typedef struct nvca_part_params {
+    int kind;                /* NVCA_PART_*                                                  */
+    int width_to_process;    /* "width-to-process", 320 (EYE/kmseyedetect.cpp:25)            */
+    int process_x_every_4;   /* "process-x-every-4-frames", 4                                */
+    int scale_factor_pct;    /* "multi-scale-factor", 25 (face pass)                         */
+    int detect_event;        /* "detect-event": 1 = faces come from nvca_part_stream_push_faces */
+} nvca_part_params;
+void nvca_part_params_default(nvca_part_params *p, int kind);
+/* cascades: face (frontalface_alt; profileface for EAR); a and b:
+ *   EYE  a = mcs_righteye, b = mcs_lefteye (EYE/kmseyedetect.cpp:28-29)
+ *   EAR  a = LEFT_SIDE cascade (mcs_rightear, sic), b = RIGHT_SIDE cascade (EAR/kmseardetect.cpp:29-31,796,801)
+ *   NOSE / MOUTH  a only (b may be NULL) */
+int  nvca_part_stream_create(nvca_ctx *ctx, const nvca_part_params *params, const nvca_cascade *face,
+                             const nvca_cascade *a, const nvca_cascade *b, nvca_part_stream **out);
+void nvca_part_stream_destroy(nvca_part_stream *s);
+int  nvca_part_stream_set_params(nvca_part_stream *s, const nvca_part_params *params);
+/* one upstream "message" worth of faces, original-frame pixels (EYE/kmseyedetect.cpp:680-764) */
+int  nvca_part_stream_push_faces(nvca_part_stream *s, const nvca_rect *faces, int n);
+/* One transform_frame_ip.  List A: eyes_r / noses / mouths / left ears; list B: eyes_l / right ears. */
+int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, nvca_rect *out_a, int cap_a,
+                              int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
 
 /* ---- NuboTracker stream -------------------------------------------------
  * Replaces gst_nubo_tracker_img_conf + gst_nubo_tracker_process

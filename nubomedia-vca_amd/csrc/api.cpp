@@ -588,6 +588,20 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
 }
 
+int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
+{
+    int rc = check_img(ctx, src, w, h, stride, 1, mem);
+    if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    PreGeom g; make_geom(g, w, h, stride, 1, w, h);
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    launch_flip_h(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.aux.as<uint8_t>(), g.gpitch);
+    return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
+}
+
 int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *sum, double *sqsum)
 {
     int rc = check_img(ctx, src, w, h, stride, 1, mem);

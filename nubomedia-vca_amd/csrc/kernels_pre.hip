@@ -283,6 +283,22 @@ void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spit
     hipLaunchKernelGGL(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch);
 }
 
+// ---- cv::flip(src, dst, 1) (EAR/kmseardetect.cpp:800)
+__global__ __launch_bounds__(256) void k_flip_h(const uint8_t *__restrict__ src, int w, int h, int spitch,
+                                                uint8_t *__restrict__ dst, int dpitch)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y < h && x < w) dst[(size_t)y * dpitch + x] = src[(size_t)y * spitch + (w - 1 - x)];
+    }
+}
+void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch)
+{
+    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
+    hipLaunchKernelGGL(k_flip_h, grid, dim3(256), 0, st, src, w, h, spitch, dst, dpitch);
+}
+
 // ---- K3a: per-band column sums of lut[gray] and its square
 __global__ __launch_bounds__(256) void k_colsum(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut,
                                                 int lut_stride, PreGeom g, unsigned *__restrict__ bandsum,

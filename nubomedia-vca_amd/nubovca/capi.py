@@ -41,6 +41,14 @@ class FaceParams(C.Structure):
                 ("min_neighbors", C.c_int), ("detect_event", C.c_int)]
 
 
+class PartParams(C.Structure):
+    _fields_ = [("kind", C.c_int), ("width_to_process", C.c_int), ("process_x_every_4", C.c_int),
+                ("scale_factor_pct", C.c_int), ("detect_event", C.c_int)]
+
+
+PART_EYE, PART_NOSE, PART_MOUTH, PART_EAR = 0, 1, 2, 3
+
+
 class TrackerParams(C.Structure):
     _fields_ = [("threshold", C.c_int), ("min_area", C.c_int), ("max_area", C.c_long), ("distance", C.c_int),
                 ("mhi_duration", C.c_double), ("seg_thresh", C.c_double)]
@@ -56,7 +64,9 @@ SYMBOLS = [
     "nvca_face_params_default", "nvca_face_stream_create", "nvca_face_stream_destroy",
     "nvca_face_stream_set_params", "nvca_face_stream_motion_event", "nvca_face_stream_process",
     "nvca_face_batch_process", "nvca_tracker_params_default", "nvca_tracker_create", "nvca_tracker_destroy",
-    "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process",
+    "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process", "nvca_flip_horizontal",
+    "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
+    "nvca_part_stream_push_faces", "nvca_part_stream_process",
 ]
 
 _lib = None
@@ -140,6 +150,15 @@ def load():
     L.nvca_tracker_process.argtypes = [vp, C.POINTER(Frame), C.c_double, C.POINTER(Rect), C.c_int, ip]
     L.nvca_tracker_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(C.c_double),
                                              C.POINTER(Rect), C.c_int, ip]
+    L.nvca_flip_horizontal.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.nvca_part_params_default.argtypes = [C.POINTER(PartParams), C.c_int]
+    L.nvca_part_params_default.restype = None
+    L.nvca_part_stream_create.argtypes = [vp, C.POINTER(PartParams), vp, vp, vp, C.POINTER(vp)]
+    L.nvca_part_stream_destroy.argtypes = [vp]
+    L.nvca_part_stream_destroy.restype = None
+    L.nvca_part_stream_set_params.argtypes = [vp, C.POINTER(PartParams)]
+    L.nvca_part_stream_push_faces.argtypes = [vp, C.POINTER(Rect), C.c_int]
+    L.nvca_part_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     _lib = L
     return L
 
@@ -416,3 +435,46 @@ def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
         res.append(np.array([[out[i * cap + j].x, out[i * cap + j].y, out[i * cap + j].w, out[i * cap + j].h]
                              for j in range(k)], np.int32).reshape(k, 4))
     return res
+
+
+class PartStream:
+    """nvca_part_stream: mirrors one nuboeyedetector / nubonosedetector / nubomouthdetector / nuboeardetector instance."""
+
+    PROPS = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4",
+             "multi_scale_factor": "scale_factor_pct", "detect_event": "detect_event"}
+
+    def __init__(self, ctx, kind, face, a, b=None, **props):
+        self.ctx = ctx
+        self.p = PartParams()
+        ctx.L.nvca_part_params_default(C.byref(self.p), kind)
+        for k, v in props.items():
+            setattr(self.p, self.PROPS[k], int(v))
+        h = C.c_void_p()
+        ctx.check(ctx.L.nvca_part_stream_create(ctx.h, C.byref(self.p), face.h, a.h, b.h if b is not None else None, C.byref(h)))
+        self.h = h
+        self._keep = (face, a, b)
+
+    def push_faces(self, faces):
+        faces = np.asarray(faces, np.int32).reshape(-1, 4)
+        buf = (Rect * max(len(faces), 1))()
+        for i, r in enumerate(faces):
+            buf[i] = Rect(*[int(v) for v in r])
+        self.ctx.check(self.ctx.L.nvca_part_stream_push_faces(self.h, buf, len(faces)))
+
+    def process(self, bgr, cap=64):
+        f = make_frame(np.ascontiguousarray(bgr, np.uint8))
+        a, b = (Rect * cap)(), (Rect * cap)()
+        na, nb = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.L.nvca_part_stream_process(self.h, C.byref(f), a, cap, C.byref(na), b, cap, C.byref(nb)))
+        return _rects(a, min(na.value, cap)), _rects(b, min(nb.value, cap))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.nvca_part_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

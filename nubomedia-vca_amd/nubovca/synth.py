@@ -96,8 +96,18 @@ def _norm_values(coefs, windows):
     return vals / std[:, None]
 
 
+def part_template(name, win=WIN):
+    """20x20 crop of the 4x up-sampled face TEMPLATE around a face part: what the synthetic
+    stand-ins for haarcascade_mcs_{righteye,lefteye,nose,mouth,leftear,rightear} respond to.
+    (x0, y0) are in the 80x80 face; a part therefore spans a quarter of the face width."""
+    big = template(4 * win)
+    x0, y0 = {"righteye": (12, 18), "lefteye": (44, 18), "nose": (28, 32), "mouth": (28, 50),
+              "leftear": (0, 28), "rightear": (60, 28)}[name]
+    return big[y0:y0 + win, x0:x0 + win].copy()
+
+
 def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open_stages=4,
-                 agree_lo=0.52, agree_hi=0.60):
+                 agree_lo=0.52, agree_hi=0.60, tmpl=None):
     """Returns a dict describing a stump cascade (see cascade_to_xml).
 
     Every stump separates TEMPLATE's normalised feature value v_T from zero
@@ -109,7 +119,7 @@ def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open
     """
     stages = list(FRONTALFACE_ALT_STAGES if stages is None else stages)
     rng = np.random.default_rng(seed)
-    T = template(win)
+    T = template(win) if tmpl is None else np.asarray(tmpl, np.float64)
     negs = rng.integers(0, 256, size=(n_mc, win, win)).astype(np.float64)
     Tn = T[None]
     out_stages = []
@@ -175,6 +185,16 @@ def cascade_to_xml(casc):
 
 def synthetic_cascade_xml(seed=2016, stages=None):
     return cascade_to_xml(make_cascade(seed=seed, stages=stages))
+
+
+PART_STAGES = [3, 9, 14, 19, 20, 27, 31, 34, 37, 42, 47, 50]     # a shorter cascade, like the mcs_* files
+
+
+def synthetic_part_cascade_xml(name, seed=None):
+    seed = {"righteye": 101, "lefteye": 102, "nose": 103, "mouth": 104, "leftear": 105, "rightear": 106}[name] if seed is None else seed
+    c = make_cascade(seed=seed, stages=PART_STAGES, tmpl=part_template(name))
+    c["name"] = "synthetic_" + name
+    return cascade_to_xml(c)
 
 
 # ------------------------------------------------------------------ frames

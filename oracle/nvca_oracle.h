@@ -159,6 +159,32 @@ int  orc_segment_motion(float *mhi, int w, int h, double ts, double seg_thresh,
                         orc_rect *out, int cap);
 int  orc_join_objects(orc_rect *r, int n, int min_area, long max_area, int distance);
 
+/* ---- part detectors (EYE/ NOSE/ MOUTH/ EAR/ kms*detect.cpp process_frame) -- */
+#define ORC_PART_EYE   0
+#define ORC_PART_NOSE  1
+#define ORC_PART_MOUTH 2
+#define ORC_PART_EAR   3
+typedef struct orc_part_stream orc_part_stream;
+typedef struct {
+    int kind;
+    int width_to_process;    /* 320 (EYE_WIDTH etc.)          */
+    int process_x_every_4;   /* 4                             */
+    int scale_factor_pct;    /* 25                            */
+    int detect_event;        /* 0                             */
+    int policy;
+} orc_part_params;
+void orc_part_params_default(orc_part_params *p, int kind);
+/* cascades: face (frontalface_alt; profileface for EAR), a, b:
+ *   EYE: a = righteye, b = lefteye;  EAR: a = LEFT_SIDE cascade, b = RIGHT_SIDE cascade;  NOSE/MOUTH: a only */
+orc_part_stream *orc_part_stream_create(const orc_part_params *p, const orc_cascade *face, const orc_cascade *a,
+                                        const orc_cascade *b);
+void orc_part_stream_destroy(orc_part_stream *s);
+/* detect-event mode: one upstream "message" worth of faces (original-frame pixels) */
+void orc_part_stream_push_faces(orc_part_stream *s, const orc_rect *faces, int n);
+/* one transform_frame_ip; list A: eyes_r / noses / mouths / lear, list B: eyes_l / rear */
+int orc_part_stream_process(orc_part_stream *s, const uint8_t *bgr, int w, int h, int stride,
+                            orc_rect *out_a, int cap_a, int *n_a, orc_rect *out_b, int cap_b, int *n_b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,14 @@ class FaceParams(C.Structure):
                 ("full_res", C.c_int), ("min_neighbors", C.c_int), ("policy", C.c_int)]
 
 
+class PartParams(C.Structure):
+    _fields_ = [("kind", C.c_int), ("width_to_process", C.c_int), ("process_x_every_4", C.c_int),
+                ("scale_factor_pct", C.c_int), ("detect_event", C.c_int), ("policy", C.c_int)]
+
+
+PART_EYE, PART_NOSE, PART_MOUTH, PART_EAR = 0, 1, 2, 3
+
+
 class TrackerParams(C.Structure):
     _fields_ = [("threshold", C.c_int), ("min_area", C.c_int), ("max_area", C.c_long),
                 ("distance", C.c_int), ("mhi_duration", C.c_double), ("seg_thresh", C.c_double)]
@@ -59,7 +67,7 @@ class TrackerParams(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libnvca_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_imgproc.c", "orc_haar.c", "orc_pipe.c",
+    srcs = [os.path.join(_HERE, f) for f in ("orc_imgproc.c", "orc_haar.c", "orc_pipe.c", "orc_parts.c",
                                              "nvca_oracle.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -102,6 +110,13 @@ def lib():
         L.orc_segment_motion.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_double,
                                          C.POINTER(Rect), C.c_int]
         L.orc_join_objects.argtypes = [C.POINTER(Rect), C.c_int, C.c_int, C.c_long, C.c_int]
+        L.orc_part_params_default.argtypes = [C.POINTER(PartParams), C.c_int]
+        L.orc_part_stream_create.argtypes = [C.POINTER(PartParams), C.POINTER(CCascade), C.POINTER(CCascade), C.POINTER(CCascade)]
+        L.orc_part_stream_create.restype = C.c_void_p
+        L.orc_part_stream_destroy.argtypes = [C.c_void_p]
+        L.orc_part_stream_push_faces.argtypes = [C.c_void_p, C.POINTER(Rect), C.c_int]
+        L.orc_part_stream_process.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int,
+                                              C.POINTER(C.c_int), C.POINTER(Rect), C.c_int, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -381,3 +396,30 @@ def join_objects(rects, min_area=50, max_area=30000, distance=35):
     buf = np_to_rects(rects)
     n = lib().orc_join_objects(buf, len(rects), min_area, max_area, distance)
     return rects_to_np(buf, n)
+
+
+class PartStream:
+    def __init__(self, kind, face, a, b=None, **kw):
+        p = PartParams()
+        lib().orc_part_params_default(C.byref(p), kind)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._keep = (face, a, b)
+        self.h = lib().orc_part_stream_create(C.byref(p), C.byref(face.c), C.byref(a.c), C.byref(b.c) if b is not None else None)
+
+    def push_faces(self, faces):
+        faces = np.asarray(faces, np.int32).reshape(-1, 4)
+        lib().orc_part_stream_push_faces(self.h, np_to_rects(faces), len(faces))
+
+    def process(self, bgr, cap=64):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W, _ = bgr.shape
+        a, b = (Rect * cap)(), (Rect * cap)()
+        na, nb = C.c_int(), C.c_int()
+        lib().orc_part_stream_process(self.h, _u8(bgr), W, H, bgr.strides[0], a, cap, C.byref(na), b, cap, C.byref(nb))
+        return rects_to_np(a, na.value), rects_to_np(b, nb.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_part_stream_destroy(self.h)
+            self.h = None

@@ -1,0 +1,117 @@
+"""GPU parity of the part detectors (BASELINE config 3: face -> eye / nose / mouth / ear
+ROI chain): NuboEyeDetector, NuboNoseDetector, NuboMouthDetector, NuboEarDetector streams against the CPU oracle,
+bit-exact box lists over multi-frame sequences (the merging heuristics carry state from frame to frame)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PARTS = ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")
+
+
+@pytest.fixture(scope="module")
+def env(synth_xml):
+    import orc
+    from nubovca import capi, synth
+    ctx = capi.Context(0)
+    xml = {n: synth.synthetic_part_cascade_xml(n) for n in PARTS}
+    dev = {n: ctx.load_cascade_xml(x) for n, x in xml.items()}
+    cpu = {n: orc.parse_cascade_xml(x) for n, x in xml.items()}
+    dev["face"] = ctx.load_cascade_xml(synth_xml)
+    cpu["face"] = orc.parse_cascade_xml(synth_xml)
+    yield ctx, dev, cpu
+    ctx.close()
+
+
+KINDS = {"eye": (0, "righteye", "lefteye"), "nose": (1, "nose", None), "mouth": (2, "mouth", None), "ear": (3, "leftear", "rightear")}
+
+
+def _streams(env, kind, **props):
+    import orc
+    from nubovca import capi
+    ctx, dev, cpu = env
+    k, a, b = KINDS[kind]
+    names = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4",
+             "multi_scale_factor": "scale_factor_pct", "detect_event": "detect_event"}
+    g = capi.PartStream(ctx, k, dev["face"], dev[a], dev[b] if b else None, **props)
+    o = orc.PartStream(k, cpu["face"], cpu[a], cpu[b] if b else None, **{names[n]: v for n, v in props.items()})
+    return g, o
+
+
+def _scene(W, H, n, seed, two_faces=False):
+    from nubovca import synth
+    frames = []
+    s = int(H * 0.5)
+    for i in range(n):
+        faces = [] if i % 6 == 4 else [(W // 5 + 5 * i, H // 5, s)]
+        if two_faces and faces:
+            faces.append((W // 2 + 30, H // 3 + 3 * i, int(s * 0.7)))
+        frames.append(synth.make_bgr(W, H, seed + i, "natural", faces))
+    return frames
+
+
+@pytest.mark.parametrize("kind", ["eye", "nose", "mouth", "ear"])
+@pytest.mark.parametrize("W,H,props,two", [
+    (640, 480, {}, False),
+    (1280, 720, {}, True),
+    (800, 600, {}, False),                                   # width / 320 = 2.5: the int-scale truncation quirk
+    (640, 480, {"process_x_every_4_frames": 2, "multi_scale_factor": 15}, False),
+    (640, 480, {"width_to_process": 640}, False),
+])
+def test_part_stream_sequence(env, kind, W, H, props, two):
+    g, o = _streams(env, kind, **props)
+    seen = 0
+    for i, f in enumerate(_scene(W, H, 9, 700 + W, two)):
+        ga, gb = g.process(f)
+        ea, eb = o.process(f)
+        assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (kind, i, ga, ea, gb, eb)
+        seen += len(ea) + len(eb)
+    assert seen > 0
+    g.close()
+
+
+@pytest.mark.parametrize("kind", ["eye", "nose", "mouth"])
+def test_part_stream_detect_event_mode(env, kind):
+    """faces arrive from an upstream nubofacedetector (original-frame pixels) instead of the own face pass"""
+    import orc
+    from nubovca import capi
+    ctx, dev, cpu = env
+    g, o = _streams(env, kind, detect_event=1)
+    fs = capi.FaceStream(ctx, dev["face"])
+    seen = 0
+    for i, f in enumerate(_scene(640, 480, 8, 900)):
+        boxes, _ = fs.process(f)
+        if i % 3 != 2 and len(boxes):        # some frames come without an upstream message
+            g.push_faces(boxes)
+            o.push_faces(boxes)
+        ga, gb = g.process(f)
+        ea, eb = o.process(f)
+        assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (kind, i)
+        seen += len(ea) + len(eb)
+    assert seen > 0
+
+
+def test_roi_chain_1080p(env):
+    """BASELINE config 3: 1080p frame through the eye / nose / mouth / ear chain"""
+    from nubovca import synth
+    frames = [synth.make_bgr(1920, 1080, 40 + i, "natural", [(500 + 10 * i, 200, 600)]) for i in range(3)]
+    for kind in ("eye", "nose", "mouth", "ear"):
+        g, o = _streams(env, kind)
+        tot = 0
+        for f in frames:
+            ga, gb = g.process(f)
+            ea, eb = o.process(f)
+            assert np.array_equal(ga, ea) and np.array_equal(gb, eb), kind
+            tot += len(ea) + len(eb)
+        assert tot > 0, kind
+
+
+def test_flip_primitive(env):
+    import ctypes as C
+    import orc
+    from nubovca import capi
+    ctx = env[0]
+    img = np.random.default_rng(3).integers(0, 256, size=(37, 101), dtype=np.uint8)
+    out = np.empty_like(img)
+    ctx.check(ctx.L.nvca_flip_horizontal(ctx.h, img.ctypes.data, 101, 37, 101, capi.MEM_HOST, out.ctypes.data, 101))
+    assert np.array_equal(out, orc.flip_h(img))
