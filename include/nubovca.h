@@ -216,6 +216,9 @@ void nvca_part_stream_destroy(nvca_part_stream *s);
 int  nvca_part_stream_set_params(nvca_part_stream *s, const nvca_part_params *params);
 /* one upstream "message" worth of faces, original-frame pixels (EYE/kmseyedetect.cpp:680-764) */
 int  nvca_part_stream_push_faces(nvca_part_stream *s, const nvca_rect *faces, int n);
+/* the face list the last processed frame worked with (working-image pixels of the face pass, or the pushed
+ * faces): what kms_mouth_send_event / kms_ear_send_event put into their events */
+int  nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, int *n_out);
 /* One transform_frame_ip.  List A: eyes_r / noses / mouths / left ears; list B: eyes_l / right ears. */
 int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, nvca_rect *out_a, int cap_a,
                               int *n_a, nvca_rect *out_b, int cap_b, int *n_b);

@@ -202,6 +202,14 @@ int nvca_part_stream_push_faces(nvca_part_stream *s, const nvca_rect *faces, int
     return NVCA_OK;
 }
 
+int nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, int *n_out)
+{
+    if (!s || !n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    *n_out = (int)s->faces.size();
+    for (int i = 0; i < std::min(*n_out, cap); i++) out[i] = s->faces[i];
+    return NVCA_OK;
+}
+
 int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b,
                              int cap_b, int *n_b)
 {

@@ -15,7 +15,7 @@ static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer)
     GstEvent *ev = GST_PAD_PROBE_INFO_EVENT(info);
     if (GST_EVENT_TYPE(ev) != GST_EVENT_CUSTOM_DOWNSTREAM) return GST_PAD_PROBE_OK;
     const GstStructure *m = gst_event_get_structure(ev);
-    if (!m || !gst_structure_has_name(m, "message")) return GST_PAD_PROBE_OK;
+    if (!m || !(gst_structure_has_name(m, "message") || gst_structure_has_name(m, "noses"))) return GST_PAD_PROBE_OK;
     guint64 pts = 0;
     std::string line;
     const gint n = gst_structure_n_fields(m);
@@ -28,7 +28,7 @@ static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer)
             guint x = 0, y = 0, w = 0, h = 0;
             gst_structure_get(sub, "x", G_TYPE_UINT, &x, "y", G_TYPE_UINT, &y, "width", G_TYPE_UINT, &w, "height", G_TYPE_UINT, &h, NULL);
             const gchar *type = gst_structure_get_string(sub, "type");
-            char b[128]; snprintf(b, sizeof(b), "%s:%u,%u,%u,%u;", type ? type : "?", x, y, w, h);
+            char b[160]; snprintf(b, sizeof(b), "%s/%s:%u,%u,%u,%u;", gst_structure_get_name(sub), type ? type : "?", x, y, w, h);
             line += b;
         }
         gst_structure_free(sub);
@@ -45,7 +45,18 @@ int main(int argc, char **argv)
     gst_init(&argc, &argv);
     GstElement *pipe = gst_pipeline_new("p");
     GstElement *src = gst_element_factory_make("filesrc", NULL), *parse = gst_element_factory_make("rawvideoparse", NULL);
-    GstElement *el = gst_element_factory_make(argv[1], "el"), *sink = gst_element_factory_make("fakesink", NULL);
+    // argv[1]: a factory name, or a bin description ("a ! b name=el ...") whose element named "el" is observed
+    GstElement *sink = gst_element_factory_make("fakesink", NULL);
+    GstElement *el = NULL, *chain = NULL;
+    if (strchr(argv[1], '!')) {
+        GError *err = NULL;
+        chain = gst_parse_bin_from_description(argv[1], TRUE, &err);
+        if (!chain) { fprintf(stderr, "bad description: %s\n", err ? err->message : "?"); return 3; }
+        el = gst_bin_get_by_name(GST_BIN(chain), "el");
+    } else {
+        el = gst_element_factory_make(argv[1], "el");
+        chain = el;
+    }
     if (!src || !parse || !el || !sink) { fprintf(stderr, "missing element (%s?)\n", argv[1]); return 3; }
     const bool bgra = !strcmp(argv[2], "BGRA");
     g_object_set(src, "location", argv[5], NULL);
@@ -58,13 +69,14 @@ int main(int argc, char **argv)
         *eq = 0;
         gst_util_set_object_arg(G_OBJECT(el), argv[i], eq + 1);
     }
-    gst_bin_add_many(GST_BIN(pipe), src, parse, el, sink, NULL);
-    if (!gst_element_link_many(src, parse, el, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }
+    gst_bin_add_many(GST_BIN(pipe), src, parse, chain, sink, NULL);
+    if (!gst_element_link_many(src, parse, chain, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }
     GstPad *sp = gst_element_get_static_pad(el, "src");
     gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_EVENT_DOWNSTREAM, on_event, NULL, NULL);
     gst_object_unref(sp);
-    const char *sig = !strcmp(argv[1], "nubotracker") ? "tracker-event" : "face-event";
-    if (g_signal_lookup(sig, G_OBJECT_TYPE(el))) g_signal_connect(el, sig, G_CALLBACK(on_signal), NULL);
+    const char *sigs[] = {"face-event", "tracker-event", "eye-event", "nose-event", "mouth-event", "ear-event"};
+    for (const char *sig : sigs)
+        if (g_signal_lookup(sig, G_OBJECT_TYPE(el))) g_signal_connect(el, sig, G_CALLBACK(on_signal), NULL);
     gst_element_set_state(pipe, GST_STATE_PLAYING);
     GstBus *bus = gst_element_get_bus(pipe);
     GstMessage *msg = gst_bus_timed_pop_filtered(bus, 120 * GST_SECOND, (GstMessageType)(GST_MESSAGE_EOS | GST_MESSAGE_ERROR));

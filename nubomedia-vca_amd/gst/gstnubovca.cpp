@@ -7,6 +7,10 @@
 //   nubofacedetector  FACE/kmsfacedetect.cpp   (caps BGR  :129-133, props :1043-1102, signal "face-event" :1108-1113,
 //                                               event "message" :196-226, motion events :680-755)
 //   nubotracker       TRK/gstnubotracker.cpp   (caps BGRA :57-61,  props :504-542,  signal "tracker-event" :547-552)
+//   nuboeyedetector / nubonosedetector / nubomouthdetector / nuboeardetector
+//                     EYE/kmseyedetect.cpp:1274-1320 (props), :220-308 (event: eye_left*, eye_right*), :192-218,680-764 (faces in)
+//                     NOSE/kmsnosedetect.cpp:1089-1135, :212-273 (event "noses")   MOUTH/kmsmouthdetect.cpp:205-282 (faces + mouths)
+//                     EAR/kmseardetect.cpp:994-1038 ("meta-data"), :196-290 (signal only: the event is built but never pushed)
 // All pixel work happens in the library (HIP); this file is glue only.  One plugin
 // ("nubovca") registers every factory; the reference ships one plugin per element.
 #include <gst/gst.h>
@@ -383,12 +387,258 @@ static void nvca_trk_class_init(NvcaTrkClass *klass)
                               G_TYPE_STRING);
 }
 
+
+// =====================================================================================
+// nuboeyedetector / nubonosedetector / nubomouthdetector / nuboeardetector  (one implementation, four GTypes)
+// =====================================================================================
+struct PartDesc {
+    int kind; const char *factory, *type_name, *view_prop, *meta_prop, *signal, *face_file, *a_file, *b_file, *longname;
+    guint signal_id; gpointer parent_class;
+};
+static PartDesc part_descs[4] = {
+    {NVCA_PART_EYE, "nuboeyedetector", "NvcaEyeDetect", "view-eyes", "send-meta-data", "eye-event", "haarcascade_frontalface_alt.xml",
+     "haarcascade_mcs_righteye.xml", "haarcascade_mcs_lefteye.xml", "eye detection filter element", 0, NULL},
+    {NVCA_PART_NOSE, "nubonosedetector", "NvcaNoseDetect", "view-noses", "send-meta-data", "nose-event", "haarcascade_frontalface_alt.xml",
+     "haarcascade_mcs_nose.xml", NULL, "nose detection filter element", 0, NULL},
+    {NVCA_PART_MOUTH, "nubomouthdetector", "NvcaMouthDetect", "view-mouths", "send-meta-data", "mouth-event", "haarcascade_frontalface_alt.xml",
+     "haarcascade_mcs_mouth.xml", NULL, "mouth detection filter element", 0, NULL},
+    /* EAR: LEFT_SIDE uses mcs_rightear.xml, RIGHT_SIDE mcs_leftear.xml (sic, EAR/kmseardetect.cpp:29-31,796,801); property "meta-data" */
+    {NVCA_PART_EAR, "nuboeardetector", "NvcaEarDetect", "view-ears", "meta-data", "ear-event", "haarcascade_profileface.xml",
+     "haarcascade_mcs_rightear.xml", "haarcascade_mcs_leftear.xml", "ear detection filter element", 0, NULL},
+};
+struct NvcaPart {
+    GstVideoFilter base;
+    GRecMutex mutex;
+    PartDesc *desc;
+    nvca_cascade *cf, *ca, *cb; nvca_part_stream *stream;
+    nvca_part_params p;
+    int view, meta_data, server_events, events_ms;
+    double time_events_ms;
+    GstStructure *image_to_overlay;
+};
+struct NvcaPartClass { GstVideoFilterClass parent; PartDesc *desc; };
+enum { PP_0, PP_VIEW, PP_DETECT_EVENT, PP_META, PP_WIDTH, PP_X_EVERY_4, PP_SCALE, PP_EVENTS, PP_EVENTS_MS, PP_OVERLAY };
+
+static void nvca_part_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
+{
+    NvcaPart *f = (NvcaPart *)o;
+    g_rec_mutex_lock(&f->mutex);
+    switch (id) {
+    case PP_VIEW: f->view = g_value_get_int(v); break;
+    case PP_DETECT_EVENT: f->p.detect_event = g_value_get_int(v); break;
+    case PP_META: f->meta_data = g_value_get_int(v); break;
+    case PP_WIDTH: f->p.width_to_process = g_value_get_int(v); break;
+    case PP_X_EVERY_4: f->p.process_x_every_4 = g_value_get_int(v); break;
+    case PP_SCALE: f->p.scale_factor_pct = g_value_get_int(v); break;
+    case PP_EVENTS: f->server_events = g_value_get_int(v); f->time_events_ms = now_ms(); break;
+    case PP_EVENTS_MS: f->events_ms = g_value_get_int(v); break;
+    case PP_OVERLAY:
+        if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
+        f->image_to_overlay = (GstStructure *)g_value_dup_boxed(v);
+        break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    if (f->stream) nvca_part_stream_set_params(f->stream, &f->p);
+    g_rec_mutex_unlock(&f->mutex);
+}
+static void nvca_part_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
+{
+    NvcaPart *f = (NvcaPart *)o;
+    g_rec_mutex_lock(&f->mutex);
+    switch (id) {
+    case PP_VIEW: g_value_set_int(v, f->view); break;
+    case PP_DETECT_EVENT: g_value_set_int(v, f->p.detect_event); break;
+    case PP_META: g_value_set_int(v, f->meta_data); break;
+    case PP_WIDTH: g_value_set_int(v, f->p.width_to_process); break;
+    case PP_X_EVERY_4: g_value_set_int(v, f->p.process_x_every_4); break;
+    case PP_SCALE: g_value_set_int(v, f->p.scale_factor_pct); break;
+    case PP_EVENTS: g_value_set_int(v, f->server_events); break;
+    case PP_EVENTS_MS: g_value_set_int(v, f->events_ms); break;
+    case PP_OVERLAY: g_value_set_boxed(v, f->image_to_overlay); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
+    }
+    g_rec_mutex_unlock(&f->mutex);
+}
+
+static void part_lazy_init(NvcaPart *f)
+{
+    if (f->stream) return;
+    nvca_ctx *ctx = shared_ctx();
+    if (!ctx) return;
+    struct { nvca_cascade **c; const char *file; } need[3] = {{&f->cf, f->desc->face_file}, {&f->ca, f->desc->a_file}, {&f->cb, f->desc->b_file}};
+    for (auto &n : need) {
+        if (!n.file || *n.c) continue;
+        const std::string path = cascade_path(n.file);
+        if (nvca_cascade_load_xml(ctx, path.c_str(), n.c) != NVCA_OK) {
+            GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));
+            *n.c = nullptr;
+            return;
+        }
+    }
+    if (nvca_part_stream_create(ctx, &f->p, f->cf, f->ca, f->cb, &f->stream) != NVCA_OK) f->stream = nullptr;
+}
+
+// faces handed over by an upstream element (EYE/kmseyedetect.cpp:680-724): sub-structures whose type == "face"
+static gboolean nvca_part_sink_event(GstBaseTransform *trans, GstEvent *event)
+{
+    NvcaPart *f = (NvcaPart *)trans;
+    if (GST_EVENT_TYPE(event) == GST_EVENT_CUSTOM_DOWNSTREAM && f->desc->kind != NVCA_PART_EAR) {
+        const GstStructure *m = gst_event_get_structure(event);
+        g_rec_mutex_lock(&f->mutex);
+        if (m && f->p.detect_event) {
+            part_lazy_init(f);
+            nvca_rect faces[64]; int n = 0;
+            const gint len = gst_structure_n_fields(m);
+            for (gint i = 0; i < len && n < 64; i++) {
+                const gchar *name = gst_structure_nth_field_name(m, i);
+                if (g_strcmp0(name, "timestamp") == 0) continue;
+                GstStructure *d = NULL;
+                if (!gst_structure_get(m, name, GST_TYPE_STRUCTURE, &d, NULL) || !d) continue;
+                const gchar *type = gst_structure_get_string(d, "type");
+                if (g_strcmp0(type, "face") == 0) {
+                    guint x = 0, y = 0, w = 0, h = 0;
+                    gst_structure_get(d, "x", G_TYPE_UINT, &x, "y", G_TYPE_UINT, &y, "width", G_TYPE_UINT, &w, "height", G_TYPE_UINT, &h, NULL);
+                    faces[n++] = nvca_rect{(int)x, (int)y, (int)w, (int)h};
+                }
+                gst_structure_free(d);
+            }
+            if (f->stream) nvca_part_stream_push_faces(f->stream, faces, n);
+        }
+        g_rec_mutex_unlock(&f->mutex);
+    }
+    return GST_BASE_TRANSFORM_CLASS(f->desc->parent_class)->sink_event(trans, event);
+}
+
+static void add_box(GstStructure *message, const char *sname, const char *type, int idx, const nvca_rect &r, int mul)
+{
+    GstStructure *st = gst_structure_new(sname, "type", G_TYPE_STRING, type, "x", G_TYPE_UINT, (guint)r.x * mul, "y", G_TYPE_UINT,
+                                         (guint)r.y * mul, "width", G_TYPE_UINT, (guint)r.w * mul, "height", G_TYPE_UINT, (guint)r.h * mul, NULL);
+    char id[16]; snprintf(id, sizeof(id), "%d", idx);
+    gst_structure_set(message, id, GST_TYPE_STRUCTURE, st, NULL);
+    gst_structure_free(st);
+}
+static std::string box_str(const nvca_rect &r)
+{
+    return "x:" + std::to_string((guint)r.x) + ",y:" + std::to_string((guint)r.y) + ",width:" + std::to_string((guint)r.w) +
+           ",height:" + std::to_string((guint)r.h) + ";";
+}
+
+static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
+{
+    NvcaPart *f = (NvcaPart *)filter;
+    g_rec_mutex_lock(&f->mutex);
+    part_lazy_init(f);
+    if (f->stream && f->p.width_to_process > 0) {
+        nvca_frame nf;
+        nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+        nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);
+        nf.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
+        nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
+        nvca_rect a[64], b[64], faces[64]; int na = 0, nb = 0, nfaces = 0;
+        const int rc = nvca_part_stream_process(f->stream, &nf, a, 64, &na, b, 64, &nb);
+        if (rc != NVCA_OK) GST_ERROR("nvca_part_stream_process: %d", rc);
+        else {
+            na = MIN(na, 64); nb = MIN(nb, 64);
+            nvca_part_stream_faces(f->stream, faces, 64, &nfaces); nfaces = MIN(nfaces, 64);
+            const int kind = f->desc->kind;
+            std::string str; int i = 0;
+            GstStructure *message = gst_structure_new_empty(kind == NVCA_PART_NOSE ? "noses" : "message");
+            if (kind != NVCA_PART_NOSE) {
+                GstStructure *ts = gst_structure_new("time", "pts", G_TYPE_UINT64, GST_BUFFER_PTS(frame->buffer), NULL);
+                gst_structure_set(message, "timestamp", GST_TYPE_STRUCTURE, ts, NULL);
+                gst_structure_free(ts);
+            }
+            if (kind == NVCA_PART_EYE) {                 // left eyes first, then right eyes (EYE :245-284)
+                for (int k = 0; k < nb; k++, i++) { add_box(message, "eye_left", "eye", i, b[k], 1); str += box_str(b[k]); }
+                for (int k = 0; k < na; k++, i++) { add_box(message, "eye_right", "eye", i, a[k], 1); str += box_str(a[k]); }
+            } else if (kind == NVCA_PART_NOSE) {
+                for (int k = 0; k < na; k++, i++) { add_box(message, "noses", "nose", i, a[k], 1); str += box_str(a[k]); }
+            } else if (kind == NVCA_PART_MOUTH) {        // faces x norm_faces (int of scale_o2f), then mouths (MOUTH :221-255)
+                const int norm_faces = f->p.detect_event ? 1 : (int)(((float)nf.width) / ((float)160));
+                for (int k = 0; k < nfaces; k++, i++) add_box(message, "face", "face", i, faces[k], norm_faces);
+                for (int k = 0; k < na; k++, i++) { add_box(message, "mouth", "mouth", i, a[k], 1); str += box_str(a[k]); }
+            } else {                                     // EAR: right list then left list; the event is never pushed (:196-290)
+                for (int k = 0; k < nb; k++) str += box_str(b[k]);
+                for (int k = 0; k < na; k++) str += box_str(a[k]);
+            }
+            if (kind == NVCA_PART_EAR) gst_structure_free(message);
+            else gst_pad_push_event(GST_BASE_TRANSFORM(f)->srcpad, gst_event_new_custom(GST_EVENT_CUSTOM_DOWNSTREAM, message));
+            if (na > 0 || nb > 0) {
+                const double t = now_ms();
+                if (1 == f->server_events && t - f->time_events_ms > f->events_ms) {
+                    f->time_events_ms = t;
+                    g_signal_emit(G_OBJECT(f), f->desc->signal_id, 0, str.c_str());
+                }
+            }
+        }
+    }
+    g_rec_mutex_unlock(&f->mutex);
+    return GST_FLOW_OK;
+}
+
+static void nvca_part_finalize(GObject *o)
+{
+    NvcaPart *f = (NvcaPart *)o;
+    if (f->stream) nvca_part_stream_destroy(f->stream);
+    if (f->cf) nvca_cascade_free(f->cf);
+    if (f->ca) nvca_cascade_free(f->ca);
+    if (f->cb) nvca_cascade_free(f->cb);
+    if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
+    g_rec_mutex_clear(&f->mutex);
+    G_OBJECT_CLASS(f->desc->parent_class)->finalize(o);
+}
+static void nvca_part_instance_init(GTypeInstance *inst, gpointer klass)
+{
+    NvcaPart *f = (NvcaPart *)inst;
+    f->desc = ((NvcaPartClass *)klass)->desc;
+    nvca_part_params_default(&f->p, f->desc->kind);      /* width-to-process 320, process 4 of 4, scale factor 25 */
+    f->view = 0; f->meta_data = 0; f->server_events = 0; f->events_ms = 30001; f->time_events_ms = 0;
+    f->cf = f->ca = f->cb = nullptr; f->stream = nullptr; f->image_to_overlay = nullptr;
+    g_rec_mutex_init(&f->mutex);
+}
+static void nvca_part_class_init(gpointer klass, gpointer class_data)
+{
+    PartDesc *d = (PartDesc *)class_data;
+    ((NvcaPartClass *)klass)->desc = d;
+    d->parent_class = g_type_class_peek_parent(klass);
+    GObjectClass *go = G_OBJECT_CLASS(klass);
+    GstCaps *caps = gst_caps_from_string(GST_VIDEO_CAPS_MAKE("{ BGR }"));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, caps));
+    gst_element_class_add_pad_template(GST_ELEMENT_CLASS(klass), gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, caps));
+    gst_caps_unref(caps);
+    gst_element_class_set_static_metadata(GST_ELEMENT_CLASS(klass), d->longname, "Video/Filter",
+                                          "Haar part detector (MI355X / HIP implementation)", "nubovca-hip");
+    go->set_property = nvca_part_set_property; go->get_property = nvca_part_get_property; go->finalize = nvca_part_finalize;
+    INT_PROP(go, PP_VIEW, d->view_prop, "view", "draw or hide the detections on the stream", 0, 1);
+    INT_PROP(go, PP_DETECT_EVENT, "detect-event", "detect event", "0 => own face pass; 1 => faces come from upstream events", 0, 1);
+    INT_PROP(go, PP_META, d->meta_prop, "send meta data", "0 (default) => no meta data", 0, 1);
+    INT_PROP(go, PP_WIDTH, "width-to-process", "width to process", "width of the image the part cascade processes (320 default)", 0, 640);
+    INT_PROP(go, PP_X_EVERY_4, "process-x-every-4-frames", "process x every 4 frames", "1,2,3,4 (default)", 0, 4);
+    INT_PROP(go, PP_SCALE, "multi-scale-factor", "multi scale factor", "5-50 (25 default)", 0, 51);
+    INT_PROP(go, PP_EVENTS, "activate-events", "Activate Events", "0 (default) => no events to the server", 0, 1);
+    INT_PROP(go, PP_EVENTS_MS, "events-ms", "Activate Events", "the time, it takes to send events to the servers", 0, 30000);
+    g_object_class_install_property(go, PP_OVERLAY, g_param_spec_boxed("image-to-overlay", "image to overlay", "set the url of the image to overlay",
+                                    GST_TYPE_STRUCTURE, (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
+    GST_VIDEO_FILTER_CLASS(klass)->transform_frame_ip = GST_DEBUG_FUNCPTR(nvca_part_transform_frame_ip);
+    if (d->kind != NVCA_PART_EAR) GST_BASE_TRANSFORM_CLASS(klass)->sink_event = GST_DEBUG_FUNCPTR(nvca_part_sink_event);   /* ear: not overridden */
+    d->signal_id = g_signal_new(d->signal, G_TYPE_FROM_CLASS(klass), G_SIGNAL_RUN_LAST, 0, NULL, NULL, NULL, G_TYPE_NONE, 1, G_TYPE_STRING);
+}
+static GType nvca_part_type(PartDesc *d)
+{
+    GTypeInfo info; memset(&info, 0, sizeof(info));
+    info.class_size = sizeof(NvcaPartClass); info.class_init = nvca_part_class_init; info.class_data = d;
+    info.instance_size = sizeof(NvcaPart); info.instance_init = nvca_part_instance_init;
+    return g_type_register_static(GST_TYPE_VIDEO_FILTER, d->type_name, &info, (GTypeFlags)0);
+}
+
 // =====================================================================================
 static gboolean plugin_init(GstPlugin *plugin)
 {
     GST_DEBUG_CATEGORY_INIT(nubovca_debug, "nubovca", 0, "NUBOMEDIA-VCA Haar path on MI355X");
-    return gst_element_register(plugin, "nubofacedetector", GST_RANK_NONE, nvca_face_get_type()) &&
-           gst_element_register(plugin, "nubotracker", GST_RANK_NONE, nvca_trk_get_type());
+    gboolean ok = gst_element_register(plugin, "nubofacedetector", GST_RANK_NONE, nvca_face_get_type()) &&
+                  gst_element_register(plugin, "nubotracker", GST_RANK_NONE, nvca_trk_get_type());
+    for (PartDesc &d : part_descs) ok = ok && gst_element_register(plugin, d.factory, GST_RANK_NONE, nvca_part_type(&d));
+    return ok;
 }
 
 #ifndef PACKAGE

@@ -66,7 +66,7 @@ SYMBOLS = [
     "nvca_face_batch_process", "nvca_tracker_params_default", "nvca_tracker_create", "nvca_tracker_destroy",
     "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process", "nvca_flip_horizontal",
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
-    "nvca_part_stream_push_faces", "nvca_part_stream_process",
+    "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
 ]
 
 _lib = None
@@ -158,6 +158,7 @@ def load():
     L.nvca_part_stream_destroy.restype = None
     L.nvca_part_stream_set_params.argtypes = [vp, C.POINTER(PartParams)]
     L.nvca_part_stream_push_faces.argtypes = [vp, C.POINTER(Rect), C.c_int]
+    L.nvca_part_stream_faces.argtypes = [vp, C.POINTER(Rect), C.c_int, ip]
     L.nvca_part_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     _lib = L
     return L

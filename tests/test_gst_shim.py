@@ -48,7 +48,7 @@ def test_tracker_element_surface(shim):
     assert "Range: 0 - 255 Default: 20" in out and "Range: 0 - 300000 Default: 30000" in out
 
 
-def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None):
+def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None):
     with tempfile.TemporaryDirectory() as td:
         raw = os.path.join(td, "frames.raw")
         with open(raw, "wb") as f:
@@ -58,6 +58,9 @@ def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None):
         if cascade_xml is not None:
             with open(os.path.join(td, "haarcascade_frontalface_alt.xml"), "w") as f:
                 f.write(cascade_xml)
+            for name, xml in (extra_cascades or {}).items():
+                with open(os.path.join(td, name), "w") as f:
+                    f.write(xml)
             env["NVCA_CASCADE_DIR"] = td
         r = subprocess.run([build_gst.HARNESS, element, fmt, str(W), str(H), raw] + list(props), env=env,
                            capture_output=True, text=True, timeout=300)
@@ -91,7 +94,7 @@ def test_face_pipeline_events_match_oracle(shim, synth_xml, orc_cascade):
     n_boxes = 0
     for fr, line in zip(frames, events):
         boxes, _ = ofs.process(fr)
-        exp = "".join("face:%d,%d,%d,%d;" % tuple(b) for b in boxes)
+        exp = "".join("face/face:%d,%d,%d,%d;" % tuple(b) for b in boxes)
         got = line.split(" ", 2)[2] if len(line.split(" ", 2)) > 2 else ""
         assert got == exp, (line, exp)
         n_boxes += len(boxes)
@@ -111,3 +114,80 @@ def test_tracker_pipeline_runs(shim):
     assert r.returncode == 0, r.stderr[-2000:]
     sig = [l for l in r.stdout.splitlines() if l.startswith("signal ")]
     assert len(sig) >= 3 and all("width:" in s for s in sig)
+
+
+@pytest.mark.parametrize("factory,view,signal,meta", [
+    ("nuboeyedetector", "view-eyes", "eye-event", "send-meta-data"),
+    ("nubonosedetector", "view-noses", "nose-event", "send-meta-data"),
+    ("nubomouthdetector", "view-mouths", "mouth-event", "send-meta-data"),
+    ("nuboeardetector", "view-ears", "ear-event", "meta-data"),
+])
+def test_part_element_surface(shim, factory, view, signal, meta):
+    out = _inspect(factory)
+    for prop in (view, "detect-event", meta, "width-to-process", "process-x-every-4-frames", "multi-scale-factor",
+                 "activate-events", "events-ms", "image-to-overlay"):
+        assert "  " + prop in out, prop
+    assert '"%s"' % signal in out and "BGR" in out
+    assert "Range: 0 - 640 Default: 320" in out
+
+
+def _part_files():
+    from nubovca import synth
+    names = {"righteye": "haarcascade_mcs_righteye.xml", "lefteye": "haarcascade_mcs_lefteye.xml", "nose": "haarcascade_mcs_nose.xml",
+             "mouth": "haarcascade_mcs_mouth.xml"}
+    return {fn: synth.synthetic_part_cascade_xml(n) for n, fn in names.items()}
+
+
+def _scene(n):
+    from nubovca import synth
+    return [synth.make_bgr(640, 480, 800 + i, "natural", [] if i % 5 == 3 else [(130 + 5 * i, 100, 240)]) for i in range(n)]
+
+
+@pytest.mark.gpu
+def test_face_to_eye_chain_matches_oracle(shim, synth_xml, orc_cascade):
+    """`nubofacedetector ! nuboeyedetector detect-event=1`: the eye element consumes the face element's downstream
+    events and emits eye_left* / eye_right* exactly as the oracle chain predicts"""
+    import orc
+    from nubovca import synth
+    frames = _scene(8)
+    files = _part_files()
+    r = _run_harness("nubofacedetector ! nuboeyedetector name=el detect-event=1", "BGR", 640, 480, frames, cascade_xml=synth_xml,
+                     extra_cascades=files)
+    assert r.returncode == 0, r.stderr[-2000:]
+    events = [l for l in r.stdout.splitlines() if l.startswith("event ") and "face/face" not in l]
+    ofs = orc.FaceStream(orc_cascade)
+    oe = orc.PartStream(orc.PART_EYE, orc_cascade, orc.parse_cascade_xml(files["haarcascade_mcs_righteye.xml"]),
+                        orc.parse_cascade_xml(files["haarcascade_mcs_lefteye.xml"]), detect_event=1)
+    exp_lines, seen = [], 0
+    for fr in frames:
+        boxes, _ = ofs.process(fr)
+        oe.push_faces(boxes)              # the face element pushes one message per frame, before the buffer
+        a, b = oe.process(fr)
+        exp_lines.append("".join("eye_left/eye:%d,%d,%d,%d;" % tuple(x) for x in b) + "".join("eye_right/eye:%d,%d,%d,%d;" % tuple(x) for x in a))
+        seen += len(a) + len(b)
+    got = [l.split(" ", 2)[2] if len(l.split(" ", 2)) > 2 else "" for l in events]
+    assert got == exp_lines, (got, exp_lines)
+    assert seen > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factory,kind,a_file,fmt", [
+    ("nubomouthdetector", 2, "haarcascade_mcs_mouth.xml", "mouth/mouth"),
+    ("nubonosedetector", 1, "haarcascade_mcs_nose.xml", "noses/nose"),
+])
+def test_part_pipeline_matches_oracle(shim, synth_xml, orc_cascade, factory, kind, a_file, fmt):
+    import orc
+    frames = _scene(6)
+    files = _part_files()
+    r = _run_harness(factory, "BGR", 640, 480, frames, cascade_xml=synth_xml, extra_cascades=files)
+    assert r.returncode == 0, r.stderr[-2000:]
+    events = [l for l in r.stdout.splitlines() if l.startswith("event ")]
+    o = orc.PartStream(kind, orc_cascade, orc.parse_cascade_xml(files[a_file]))
+    assert len(events) == len(frames)
+    seen = 0
+    for fr, line in zip(frames, events):
+        a, _ = o.process(fr)
+        got = [t for t in (line.split(" ", 2)[2] if len(line.split(" ", 2)) > 2 else "").split(";") if t.startswith(fmt)]
+        assert got == ["%s:%d,%d,%d,%d" % ((fmt,) + tuple(x)) for x in a]
+        seen += len(a)
+    assert seen > 0
