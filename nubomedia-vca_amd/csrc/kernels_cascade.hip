@@ -140,6 +140,7 @@ __device__ __forceinline__ bool visited(const unsigned long long *__restrict__ r
 __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
 {
     __shared__ unsigned short q[2][kStripMaxWin];
+    __shared__ double psum[256];
     __shared__ int qn[2];
     __shared__ unsigned gbase_s;
 
@@ -187,6 +188,50 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
         if (tid == 0) qn[cur ^ 1] = 0;
         __syncthreads();
         const StageRec st = a.stages[s];
+        if ((st.flags & 2) && n <= 128) {
+            // Few survivors: most lanes would idle while one wave walks the whole stage.  The votes of this stage may be
+            // summed in any order (flag bit 1), so spread its stumps over the idle lanes: thread = (window slot i,
+            // stump partition p); partition p takes stumps p, p+P, ...; partial sums meet in LDS.
+            int lg = 0;
+            while ((1 << lg) < n) lg++;
+            const int npad = 1 << lg;
+            int P = 256 >> lg;
+            if (P > st.count) P = st.count;
+            const int i = tid & (npad - 1), p = tid >> lg;
+            double part = 0.0;
+            int w = 0;
+            if (i < n && p < P) {
+                w = q[cur][i];
+                const int r = w / endX, ix = w - r * endX;
+                const unsigned off = (unsigned)(ypos[r] * sc.pitch + xpos[ix]);
+                const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+                const bool pair = a.pair_policy && (st.flags & 1);
+                if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
+                    const int pu = __builtin_amdgcn_readfirstlane(p);
+                    for (int j = pu; j < st.count; j += P)
+                        part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
+                } else {
+                    for (int j = p; j < st.count; j += P)
+                        part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
+                }
+            }
+            psum[tid] = part;
+            __syncthreads();
+            bool pass = false;
+            if (tid < n) {
+                double tot = 0.0;
+                for (int pp = 0; pp < P; pp++) tot += psum[(pp << lg) + tid];
+                pass = !(tot < (double)st.thr);
+                w = q[cur][tid];
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
+                wbase = __shfl(wbase, 0);
+                if (pass) q[cur ^ 1][wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
+            }
+        } else
         for (int base = 0; base < n; base += 256) {
             const int i = base + tid;
             bool pass = false; int w = 0;
