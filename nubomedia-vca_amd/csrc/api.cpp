@@ -372,6 +372,7 @@ int nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy)
 }
 int nvca_ctx_synchronize(nvca_ctx *ctx)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return NVCA_OK;
@@ -380,6 +381,7 @@ void *nvca_ctx_stream(nvca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullpt
 
 int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     (void)hipStreamSynchronize(ctx->stream);
     drain_timer(ctx);
@@ -389,6 +391,7 @@ int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
 }
 int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     drain_timer(ctx);
@@ -412,6 +415,7 @@ const char *nvca_kernel_name(int k)
 // =========================================================================
 int nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || !xml || len <= 0 || !out) return NVCA_ERR_ARG;
     *out = nullptr;
     std::unique_ptr<nvca_cascade> c(new nvca_cascade());
@@ -440,6 +444,7 @@ void nvca_cascade_free(nvca_cascade *c)
     if (!c) return;
     // drop cached plans that reference this cascade
     if (c->ctx) {
+        std::lock_guard<std::recursive_mutex> lk(c->ctx->mu);
         char pre[64];
         for (auto it = c->ctx->plans.begin(); it != c->ctx->plans.end();) {
             const std::string &k = it->first;
@@ -531,6 +536,7 @@ static bool frames_aligned4(const nvca_frame *frames, const int *idx, int n)
 
 int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int channels, int mem, void *dst, int dst_stride)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (channels != 3 && channels != 4) return NVCA_ERR_ARG;
     int rc = check_img(ctx, src, w, h, stride, channels, mem);
     if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
@@ -548,6 +554,7 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
 int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstride, int channels, int mem, void *dst,
                        int dw, int dh, int dstride)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (channels != 1) {
         if (ctx) ctx->set_error("nvca_resize_linear: only the 8UC1 form is exposed; the 8UC3 form is fused with BGR2GRAY "
                                 "inside the face stream (FACE/kmsfacedetect.cpp:805-806)");
@@ -573,6 +580,7 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
 
 int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
@@ -590,6 +598,7 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
 
 int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
@@ -604,6 +613,7 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int strid
 
 int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *sum, double *sqsum)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !sum) return NVCA_ERR_ARG;
     if (mem != NVCA_MEM_HOST) { ctx->set_error("nvca_integral: host output only"); return NVCA_ERR_ARG; }
@@ -783,6 +793,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
                        double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only,
                        std::vector<nvca_rect> &out)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, gray, w, h, stride, 1, mem);
     if (rc || !casc || !(sf > 1.0)) return NVCA_ERR_ARG;
     if (maxw == 0 || maxh == 0) { maxw = w; maxh = h; }
@@ -836,6 +847,7 @@ int nvca_detect_raw(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray
 
 int nvca_group_rectangles(nvca_ctx *ctx, nvca_rect *rects, int n, int group_threshold, double eps, int *n_out)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && !rects) || !n_out) return NVCA_ERR_ARG;
     std::vector<nvca_rect> v(rects, rects + n);
     group_rectangles(v, group_threshold, eps);
@@ -926,6 +938,7 @@ int nvca_face_stream_motion_event(nvca_face_stream *s)
 int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames,
                             nvca_rect *out, int *ids, int cap, int *n_out)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     std::vector<FrameWork> work(n);

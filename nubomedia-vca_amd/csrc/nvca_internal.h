@@ -6,6 +6,7 @@
 #include <vector>
 #include <map>
 #include <memory>
+#include <mutex>
 #include "../../include/nubovca.h"
 
 namespace nvca {
@@ -148,10 +149,13 @@ struct nvca_ctx {
     std::map<std::string, std::unique_ptr<nvca::GeomPlan>> plans;
     std::unique_ptr<nvca::Workspace> ws;
     void *identity_lut = nullptr;     // 256 B on device
+    std::recursive_mutex mu;          // serialises entry points: elements on different streaming threads share one context
     void set_error(const std::string &s) { err = s; }
     nvca_ctx();
     ~nvca_ctx();
 };
+
+#define NVCA_LOCK_OR_FAIL(ctx) if (!(ctx)) return NVCA_ERR_ARG; std::lock_guard<std::recursive_mutex> nvca_lock__((ctx)->mu)
 
 namespace nvca {
 

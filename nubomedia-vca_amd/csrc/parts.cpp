@@ -216,6 +216,7 @@ int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect
     if (!s || !f || !f->data || f->width <= 0 || f->height <= 0 || f->stride < f->width * 3 || !n_a || !n_b || cap_a < 0 || cap_b < 0 ||
         (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b) || s->p.width_to_process <= 0) return NVCA_ERR_ARG;
     nvca_ctx *ctx = s->ctx;
+    NVCA_LOCK_OR_FAIL(ctx);
     (void)hipSetDevice(ctx->device);
     const int kind = s->p.kind, W = f->width, H = f->height;
     // conf_images: float arithmetic (EYE/kmseyedetect.cpp:331-339 and siblings)

@@ -60,6 +60,7 @@ int nvca_tracker_set_params(nvca_tracker *t, const nvca_tracker_params *params)
 int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *trackers, const nvca_frame *frames,
                                const double *ts, nvca_rect *out, int cap, int *n_out)
 {
+    NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!trackers || !frames || !ts || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < n; i++) {
