@@ -38,7 +38,7 @@ def algorithmic_bytes(W, H, w, h, n_boxes=0):
     gray = 3 * W * H + w * h                           # BGR in, gray out
     integral = w * h + 12 * (w + 1) * (h + 1)          # gray in, sum i32 + sqsum 8 B out
     cascade = 12 * (w + 1) * (h + 1) + 16 * n_boxes    # integral pair read once, boxes out
-    return {"gray_resize_hist": gray, "integral": integral, "cascade": cascade,
+    return {"gray_resize_hist": gray, "integral": integral, "cascade": cascade, "tracker": 15 * W * H,
             "total": gray + integral + cascade}
 
 
@@ -76,6 +76,11 @@ def main():
     ap.add_argument("--faces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
+    ap.add_argument("--workload", default="face1080p", choices=["face1080p", "streams720p", "face_tracker"],
+                    help="face1080p: BASELINE configs[1] (default, the headline metric); streams720p: configs[3], "
+                         "--streams-per-gpu 720p streams, one frame each per step; face_tracker: configs[4], "
+                         "--streams-per-gpu 1080p streams through NuboFaceDetector and NuboTracker")
+    ap.add_argument("--streams-per-gpu", type=int, default=0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,6 +92,12 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from nubovca import capi, synth
+    if args.workload == "streams720p":
+        args.width, args.height = 1280, 720
+        args.frames_per_step = args.streams_per_gpu or 32
+    elif args.workload == "face_tracker":
+        args.frames_per_step = args.streams_per_gpu or 8
+    multi_stream = args.workload != "face1080p"
     W, H, F = args.width, args.height, args.frames_per_step
     w2p = args.width_to_process or W
     xml = synth.synthetic_cascade_xml()
@@ -97,25 +108,49 @@ def main():
     scale = W // w2p
     w, h = int(np.rint(W / scale)), int(np.rint(H / scale))
 
-    # F consecutive synthetic frames of this rank's stream (stream id = rank), faces drifting 8 px/frame
     base_faces = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)][:args.faces]
     sx, sy = W / 1920.0, H / 1080.0
-    frames_np = []
-    for i in range(F):
-        faces = [(int((x + 8 * i) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in base_faces]
-        frames_np.append(synth.make_bgr(W, H, synth.frame_seed(rank, i), args.content, faces))
+    TICKS = 4 if multi_stream else 1
+    frames_np = []          # [tick][slot]
+    if not multi_stream:
+        # F consecutive synthetic frames of this rank's stream (stream id = rank), faces drifting 8 px/frame
+        row = []
+        for i in range(F):
+            faces = [(int((x + 8 * i) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in base_faces]
+            row.append(synth.make_bgr(W, H, synth.frame_seed(rank, i), args.content, faces))
+        frames_np.append(row)
+    else:
+        # F streams (ids rank*F..), static per-stream background, templates moving 8 px per tick
+        bgs = [synth.make_gray(W, H, synth.frame_seed(rank * F + s, 0), args.content) for s in range(F)]
+        for t in range(TICKS):
+            row = []
+            for s in range(F):
+                faces = [(int((x + 8 * t + 16 * (s % 7)) * sx), int(y * sy), int(sz * min(sx, sy))) for (x, y, sz) in base_faces]
+                row.append(synth.gray_to_bgr(synth.paste_faces(bgs[s], faces, s), synth.frame_seed(rank * F + s, 0)))
+            frames_np.append(row)
     if args.host_frames:
-        frames = [capi.make_frame(f) for f in frames_np]
+        frames_t = [[capi.make_frame(f) for f in row] for row in frames_np]
         keep = frames_np
     else:
-        keep = [torch.from_numpy(f).to(dev) for f in frames_np]
-        frames = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
+        keep = [[torch.from_numpy(f).to(dev) for f in row] for row in frames_np]
+        frames_t = [[capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in row] for row in keep]
     torch.cuda.synchronize()
-    streams = [stream] * F
+    streams = [capi.FaceStream(ctx, casc, **props) for _ in range(F)] if multi_stream else [stream] * F
+    trackers, bgra_frames, bgra_keep = None, None, None
+    if args.workload == "face_tracker":     # the same RGB field as BGRA for the tracker
+        trackers = [capi.Tracker(ctx) for _ in range(F)]
+        bgra_keep = [[torch.cat([torch.as_tensor(t, device=dev), torch.full((H, W, 1), 255, dtype=torch.uint8, device=dev)], dim=2).contiguous()
+                      for t in row] for row in keep]
+        bgra_frames = [[capi.make_frame(t.data_ptr(), W, H, W * 4, capi.MEM_DEVICE) for t in row] for row in bgra_keep]
+        torch.cuda.synchronize()
+    tick = [0]
     from nubovca import sharding
 
     def step():
-        res = ctx.face_batch_process(streams, frames, cap=MAX_BOXES)
+        tick[0] += 1
+        res = ctx.face_batch_process(streams, frames_t[tick[0] % TICKS], cap=MAX_BOXES)
+        if trackers is not None:
+            capi.tracker_batch_process(ctx, trackers, bgra_frames[tick[0] % TICKS], [33.3 * tick[0]] * F, cap=256)
         if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL
             sharding.gather_tables(sharding.pack_boxes(res, MAX_BOXES), device=dev)
         return res
@@ -150,7 +185,7 @@ def main():
         ab = algorithmic_bytes(W, H, w, h, n_boxes)
         groups = {"gray_resize_hist": ["gray_resize_hist"], "equalize_lut": ["equalize_lut"],
                   "integral": ["integral_colsum", "integral_bandscan", "integral_rows"],
-                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep"]}
+                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep", "cascade_tile"], "tracker": ["tracker"]}
         kern = {}
         for gname, members in groups.items():
             ms = sum(ktimes.get(m, (0.0, 0))[0] for m in members)
@@ -185,14 +220,17 @@ def main():
             "vs_baseline": None, "dtype": "i32 rect sums / f32 products / f64 stage sums (u8 pixels)",
             "data": "synthetic (%s field + %d pasted templates; seeded synthetic stump cascade shaped like "
                     "haarcascade_frontalface_alt: 22 stages, 2135 stumps)" % (args.content, args.faces),
-            "config": {"workload": "NuboFaceDetector %dx%d single stream per GPU, working image %dx%d, scaleFactor %.2f, "
-                                   "minNeighbors 3, minSize (w/20,h/20)" % (W, H, w, h, 1 + args.scale_factor_pct / 100.0),
-                       "frames_per_step": F, "streams": world, "frames_resident": "host" if args.host_frames else "hbm",
+            "config": {"workload": ("NuboFaceDetector %dx%d single stream per GPU" if not multi_stream else
+                                    ("NuboFaceDetector %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F) if trackers is None else
+                                     "NuboFaceDetector + NuboTracker %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F))
+                                    ) % ((W, H) if not multi_stream else ()) +
+                                   ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
+                       "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": "host" if args.host_frames else "hbm",
                        "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(xml, frames_np, props)
+            out["cpu_baseline"] = cpu_baseline(xml, frames_np[0], props)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -328,7 +328,8 @@ class Cascade:
 
     def free(self):
         if self.h:
-            self.ctx.L.nvca_cascade_free(self.h)
+            if self.ctx.h:
+                self.ctx.L.nvca_cascade_free(self.h)
             self.h = None
 
 
@@ -375,7 +376,8 @@ class FaceStream:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.nvca_face_stream_destroy(self.h)
+            if self.ctx.h:                    # a closed context took its device state with it
+                self.ctx.L.nvca_face_stream_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -412,7 +414,8 @@ class Tracker:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.nvca_tracker_destroy(self.h)
+            if self.ctx.h:
+                self.ctx.L.nvca_tracker_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -471,7 +474,8 @@ class PartStream:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.nvca_part_stream_destroy(self.h)
+            if self.ctx.h:
+                self.ctx.L.nvca_part_stream_destroy(self.h)
             self.h = None
 
     def __del__(self):

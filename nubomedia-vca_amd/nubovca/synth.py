@@ -241,6 +241,15 @@ def make_gray(W, H, seed, kind="noise", faces=()):
         g = np.full((H, W), 128.0)
     else:
         raise ValueError(kind)
+    g = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    return paste_faces(g, faces, seed) if len(faces) else g
+
+
+def paste_faces(gray, faces, seed=0):
+    """copy of `gray` with TEMPLATE pasted at every (x, y, size)"""
+    rng = np.random.default_rng(seed ^ 0xFACE)
+    g = gray.astype(np.float64)
+    H, W = g.shape
     T = template()
     for (x, y, size) in faces:
         patch = _resize_bilinear_f(T, int(size)) + rng.normal(0, 2.0, size=(int(size), int(size)))
@@ -250,7 +259,11 @@ def make_gray(W, H, seed, kind="noise", faces=()):
 
 def make_bgr(W, H, seed, kind="noise", faces=(), channels=3):
     """BGR (or BGRA) frame whose BGR2GRAY is close to make_gray's field."""
-    g = make_gray(W, H, seed, kind, faces)
+    return gray_to_bgr(make_gray(W, H, seed, kind, faces), seed, channels)
+
+
+def gray_to_bgr(g, seed, channels=3):
+    H, W = g.shape
     rng = np.random.default_rng(seed ^ 0x5EED)
     out = np.empty((H, W, channels), np.uint8)
     jitter = rng.integers(-6, 7, size=(H, W, 2))
