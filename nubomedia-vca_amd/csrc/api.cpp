@@ -79,13 +79,13 @@ static inline int cv_round(double v)
 }
 
 struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
     PinnedBuf h_hits, h_srcptrs;
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
         sqsum.release(); hits.release(); srcptrs.release(); staging.release(); aux.release();
-        failbits.release(); vnf.release(); deep.release();
+        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
         h_hits.release(); h_srcptrs.release();
     }
 };
@@ -102,7 +102,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_stumps_lds.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_stumps_lds.release(); d_list_off.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -222,8 +222,32 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.stumps_lds = dp.d_stumps_lds.as<StumpRec>();
-        { TimedLaunch t(ctx, NVCA_K_TILE); launch_cascade_sc(ctx->stream, a, batch, 3); }
-        { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
+        a.list_from = 0;
+        a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
+        const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
+        const bool lists = dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
+        if (lists) {
+            // per-scale segment offsets depend on the batch (segment = windows of the scale x batch)
+            const size_t cap_l = (size_t)dp.list_windows * batch;
+            if (dp.list_off_batch != batch) {
+                std::vector<unsigned> off(dp.scales.size());
+                for (size_t i = 0; i < off.size(); i++) off[i] = dp.list_off[i] * (unsigned)batch;
+                if (dp.d_list_off.ensure(sizeof(unsigned) * 64)) { ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM; }
+                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipMemcpy(dp.d_list_off.p, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                dp.list_off_batch = batch;
+            }
+            if (ws.list_cnt.ensure(sizeof(unsigned) * 64 * (dp.stages.size() + 1)) || ws.list_ent.ensure(sizeof(unsigned) * 2 * cap_l + 64)) {
+                ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM;
+            }
+            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.list_cnt.p, 0, sizeof(unsigned) * 64 * (dp.stages.size() + 1), ctx->stream));
+            a.list_cnt = ws.list_cnt.as<unsigned>(); a.list_ent = ws.list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
+            a.list_cap = (unsigned)cap_l; a.list_from = dp.list_from;
+            TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 4);
+        } else {
+            { TimedLaunch t(ctx, NVCA_K_TILE); launch_cascade_sc(ctx->stream, a, batch, 3); }
+            { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
+        }
         { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());

@@ -222,6 +222,12 @@ struct CascadeArgs {
     const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
     const StumpRec *stumps_lds;
+    // global survivor lists (k_list_*): per-scale segments; counts per stage
+    unsigned *list_cnt;            // [nstages][64]
+    unsigned *list_ent;            // [2][list_cap]
+    const unsigned *list_off;      // [nscales] segment offsets
+    unsigned list_cap; int nscales;
+    int list_from;                 // first stage run on the lists (0: lists unused; 1: all early stages)
     const unsigned *tasks; int ntasks;        // k_stage0 wave tasks: scale << 20 | iy << 7 | word
     unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
@@ -232,7 +238,7 @@ struct CascadeArgs {
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
 };
-// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile
+// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
 
 } // namespace nvca

@@ -35,10 +35,15 @@ struct DetectPlan {
     std::vector<TileRec> tiles;  // LDS-staged tiles (small scales)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;
     std::vector<StumpRec> stumps_lds;
+    std::vector<unsigned> list_off;   // per-scale offsets (windows per frame) into the survivor lists
+    unsigned list_windows = 0;        // windows per frame
+    bool use_lists = true;
+    int list_from = 3;                // strips run stages 1..list_from-1, the lists the rest of the early stages
+    int list_off_batch = 0;           // batch size d_list_off was built for
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_stumps_lds;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_stumps_lds, d_list_off;
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);

@@ -326,3 +326,21 @@ def test_detect_roi_view(ctx, casc, orc_cascade):
                                            buf, 64, C.byref(n)))
     got = np.array([[buf[i].x, buf[i].y, buf[i].w, buf[i].h] for i in range(n.value)], np.int32).reshape(-1, 4)
     assert len(exp) >= 1 and np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------ optional evaluator paths stay correct
+@pytest.mark.parametrize("env", [{"NVCA_TILES": "1", "NVCA_TILE_MIN_TW": "6"}, {"NVCA_LISTS": "1", "NVCA_LIST_FROM": "1"},
+                                 {"NVCA_LISTS": "1", "NVCA_LIST_FROM": "3"}, {"NVCA_DEEP_STAGE": "2"}, {"NVCA_DEEP_STAGE": "30"}])
+def test_optional_evaluator_paths(ctx, casc, orc_cascade, env, monkeypatch):
+    """k_tile (LDS-staged footprints), k_list_* (global survivor lists) and other deep-stage splits are kept as
+    measured alternatives; plans read the switches when they are built, so new geometries pick them up"""
+    import orc
+    from nubovca import synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tag = sum(ord(c) for c in "".join(sorted(env)) + "".join(env.values())) % 17
+    w, h = 1000 + tag, 600 + tag                      # a geometry no other test uses -> a fresh plan
+    g = orc.equalize_hist(synth.make_gray(w, h, 77, "natural", [(200, 100, 260), (600, 300, 120)]))
+    raw = ctx.detect_raw(casc, g, 1.1, 0, (40, 40))
+    eraw = orc.detect_raw(orc_cascade, g, 1.1, 0, (40, 40))
+    assert len(eraw) > 0 and np.array_equal(raw, eraw)
