@@ -579,11 +579,22 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
                        int dw, int dh, int dstride)
 {
     NVCA_LOCK_OR_FAIL(ctx);
-    if (channels != 1) {
-        if (ctx) ctx->set_error("nvca_resize_linear: only the 8UC1 form is exposed; the 8UC3 form is fused with BGR2GRAY "
-                                "inside the face stream (FACE/kmsfacedetect.cpp:805-806)");
-        return NVCA_ERR_UNSUPPORTED;
+    if (channels == 3) {
+        int rc3 = check_img(ctx, src, sw, sh, sstride, 3, mem);
+        if (rc3 || !dst || dw <= 0 || dh <= 0 || dstride < dw * 3) return NVCA_ERR_ARG;
+        (void)hipSetDevice(ctx->device);
+        Workspace &w3 = *ctx->ws;
+        const size_t sp = round_up((size_t)sw * 3, 64), dp3 = round_up((size_t)dw * 3, 64);
+        if (w3.staging.ensure(sp * sh + 64) || w3.aux.ensure(dp3 * dh + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+        if ((rc3 = stage_2d(ctx, w3.staging.p, sp, src, sstride, (size_t)sw * 3, sh, mem))) return rc3;
+        GeomPlan gp3; build_resize_tab(sw, sh, dw, dh, gp3.tab);
+        if ((rc3 = upload_tab(ctx, gp3))) return rc3;
+        { TimedLaunch t(ctx, NVCA_K_RESIZE1);
+          launch_resize3(ctx->stream, w3.staging.as<uint8_t>(), sw, sh, (int)sp, gp3.tab.mode, gp3.d_xofs.as<int>(), gp3.d_ialpha.as<short>(),
+                         gp3.d_yofs.as<int>(), gp3.d_ibeta.as<short>(), gp3.tab.xmax, w3.aux.as<uint8_t>(), dw, dh, (int)dp3); }
+        return unstage_2d(ctx, dst, dstride, w3.aux.p, dp3, (size_t)dw * 3, dh, mem);
     }
+    if (channels != 1) return NVCA_ERR_ARG;
     int rc = check_img(ctx, src, sw, sh, sstride, 1, mem);
     if (rc || !dst || dw <= 0 || dh <= 0 || dstride < dw) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);

@@ -198,6 +198,52 @@ __global__ __launch_bounds__(256) void k_resize1(
     if (hist) hist_flush(lh, hist, tid);
 }
 
+// ---- 8UC3 resize (cv::resize on the BGR frame, FACE/kmsfacedetect.cpp:805, as a stand-alone primitive;
+// the face stream fuses it with BGR2GRAY in k_gray_generic)
+__global__ __launch_bounds__(256) void k_resize3(
+    const uint8_t *__restrict__ src, int sw, int sh, int sstride, int mode,
+    const int *__restrict__ xofs, const short *__restrict__ ialpha,
+    const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax,
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y >= dh || x >= dw) continue;
+        uint8_t *d = dst + (size_t)y * dstride + (size_t)x * 3;
+        if (mode == 0) {
+            const uint8_t *s = src + (size_t)y * sstride + (size_t)x * 3;
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        } else if (mode == 2) {
+            const uint8_t *s0 = src + (size_t)(2 * y) * sstride + (size_t)(2 * x) * 3, *s1 = s0 + sstride;
+#pragma unroll
+            for (int k = 0; k < 3; k++) d[k] = (uint8_t)((s0[k] + s0[3 + k] + s1[k] + s1[3 + k] + 2) >> 2);
+        } else {
+            int sy0 = yofs[y], sy1 = sy0 + 1;
+            sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+            sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+            const int sx = xofs[x] * 3;
+            const uint8_t *s0 = src + (size_t)sy0 * sstride + sx, *s1 = src + (size_t)sy1 * sstride + sx;
+            const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+            const bool inner = x < xmax;
+            const int a0 = inner ? ialpha[2 * x] : 2048, a1 = inner ? ialpha[2 * x + 1] : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int h0 = s0[k] * a0 + (inner ? s0[3 + k] * a1 : 0), h1 = s1[k] * a0 + (inner ? s1[3 + k] * a1 : 0);
+                d[k] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+}
+void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
+                    const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride)
+{
+    dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, 1);
+    hipLaunchKernelGGL(k_resize3, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs, d_ibeta, xmax,
+                       dst, dw, dh, dstride);
+}
+
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist)

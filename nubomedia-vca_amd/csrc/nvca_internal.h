@@ -184,6 +184,9 @@ void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, 
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist);
+void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
+                    const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride);
 void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch);
 void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist);
 void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch);

@@ -235,10 +235,11 @@ class Context:
 
     def resize_linear(self, img, dw, dh):
         img = np.ascontiguousarray(img, np.uint8)
-        h, w = img.shape
-        out = np.empty((dh, dw), np.uint8)
-        self.check(self.L.nvca_resize_linear(self.h, img.ctypes.data, w, h, img.strides[0], 1, MEM_HOST, out.ctypes.data,
-                                             dw, dh, dw))
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((dh, dw) if cn == 1 else (dh, dw, cn), np.uint8)
+        self.check(self.L.nvca_resize_linear(self.h, img.ctypes.data, w, h, img.strides[0], cn, MEM_HOST, out.ctypes.data,
+                                             dw, dh, dw * cn))
         return out
 
     def equalize_hist(self, img):

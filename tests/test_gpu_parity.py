@@ -64,6 +64,14 @@ def test_resize_gray(ctx, sw, sh, dw, dh):
     assert np.array_equal(ctx.resize_linear(img, dw, dh), orc.resize_linear(img, dw, dh))
 
 
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 160, 120), (1920, 1080, 160, 90), (322, 242, 161, 121), (97, 61, 41, 29),
+                                         (50, 40, 120, 90), (64, 48, 64, 48)])
+def test_resize_bgr(ctx, sw, sh, dw, dh):
+    import orc
+    img = np.random.default_rng(sw * dw).integers(0, 256, size=(sh, sw, 3), dtype=np.uint8)
+    assert np.array_equal(ctx.resize_linear(img, dw, dh), orc.resize_linear(img, dw, dh))
+
+
 @pytest.mark.parametrize("w,h,kind", [(160, 90, "natural"), (640, 480, "noise"), (1920, 1080, "natural"),
                                       (333, 77, "gradient"), (64, 64, "flat"), (5, 3, "noise")])
 def test_equalize_hist(ctx, w, h, kind):
