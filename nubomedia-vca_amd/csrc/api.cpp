@@ -207,7 +207,8 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
     }
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hits.p, 0, sizeof(unsigned long long), ctx->stream));
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
-    if (!dp.tasks.empty()) {
+    static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
+    if (!dp.tasks.empty() && !skip_cascade) {
         CascadeArgs a;
         a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
         a.sum_slot = sum_slot; a.spitch = spitch;
@@ -660,11 +661,14 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     run_integral(ctx, g, nullptr, 1);
     rc = unstage_2d(ctx, sum, (size_t)(w + 1) * 4, ws.sum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
     if (rc) return rc;
-    if (sqsum) {
-        std::vector<unsigned long long> tmp((size_t)(w + 1) * (h + 1));
-        rc = unstage_2d(ctx, tmp.data(), (size_t)(w + 1) * 8, ws.sqsum.p, (size_t)g.spitch * 8, (size_t)(w + 1) * 8, h + 1, NVCA_MEM_HOST);
+    if (sqsum) {                                       // device layout: low-word plane, then high-word plane
+        const size_t n = (size_t)(w + 1) * (h + 1);
+        std::vector<unsigned> lo(n), hi(n);
+        rc = unstage_2d(ctx, lo.data(), (size_t)(w + 1) * 4, ws.sqsum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
         if (rc) return rc;
-        for (size_t i = 0; i < tmp.size(); i++) sqsum[i] = (double)tmp[i];
+        rc = unstage_2d(ctx, hi.data(), (size_t)(w + 1) * 4, ws.sqsum.as<unsigned>() + g.sum_slot, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+        if (rc) return rc;
+        for (size_t i = 0; i < n; i++) sqsum[i] = (double)(((unsigned long long)hi[i] << 32) | lo[i]);
     }
     return NVCA_OK;
 }
@@ -723,7 +727,8 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         tabs.push_back(std::move(gp));
         PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
-        run_integral(ctx, g, nullptr, 1, lg, ws.sum.as<int>() + L.plane_off, ws.sqsum.as<unsigned long long>() + L.plane_off);
+        run_integral(ctx, g, nullptr, 1, lg, ws.sum.as<int>() + L.plane_off,
+                     (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
         ScaleSpec sp;
         sp.table_factor = 1.; sp.plane_off = L.plane_off; sp.pitch = P; sp.plane_rows = L.szh + 1; sp.adaptive = 0;
         sp.out_factor = L.f; sp.out_w = L.winw; sp.out_h = L.winh;

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
     const int ix = k * 64 + lane;
     const bool active = ix < sc.endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-    const unsigned long long *__restrict__ sq = a.sqsum + (size_t)slot * a.sum_slot + sc.plane_off;
+    // squared integral: two u32 planes (low / high word) per slot, see k_integral
+    const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
+    const unsigned *__restrict__ sqh = sql + a.sum_slot;
     bool pass0 = false;
     double vnf = 1.;
     if (active) {
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
         const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
         const int ws = sum[e0] - sum[e1] - sum[e2] + sum[e3];
         const double mean = (double)ws * sc.inv_area;
-        vnf = (double)sq[e0] - (double)sq[e1] - (double)sq[e2] + (double)sq[e3];
+        const unsigned long long q0 = ((unsigned long long)sqh[e0] << 32) | sql[e0], q1 = ((unsigned long long)sqh[e1] << 32) | sql[e1];
+        const unsigned long long q2 = ((unsigned long long)sqh[e2] << 32) | sql[e2], q3 = ((unsigned long long)sqh[e3] << 32) | sql[e3];
+        vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
         vnf = vnf * sc.inv_area - mean * mean;
         vnf = vnf >= 0. ? sqrt(vnf) : 1.;
         pass0 = run_stage(sum, off, vnf, a.stumps + sc.stump_off, a.stages[0], a.pair_policy);

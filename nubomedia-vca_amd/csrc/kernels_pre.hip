@@ -402,26 +402,47 @@ void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsign
     hipLaunchKernelGGL(k_bandscan, dim3((bpitch + 255) / 256, batch), dim3(256), 0, st, g, bandsum, bandsq);
 }
 
-// ---- K3c: integral + squared integral.  One block per band of rows; a block
-// scans whole rows (8 integral columns per thread, 2048 per pass), keeps the
-// vertical running sums in registers and writes 32 B / 64 B aligned vectors.
-// Thread t owns integral columns X in [8t, 8t+8): value(X) = prefix up to pixel X-1
-// = exclusive base of the thread (X = 8t) or base + local inclusive (X > 8t).
-__global__ __launch_bounds__(256) void k_integral(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut,
-                                                  int lut_stride, PreGeom g, const unsigned *__restrict__ bandsum,
-                                                  const unsigned *__restrict__ bandsq, int *__restrict__ sum,
-                                                  unsigned long long *__restrict__ sqsum)
+// wave64 inclusive add-scan on the VALU (DPP row shifts inside each row of 16 lanes, then the three row totals
+// through readlane): no LDS traffic, unlike ds_bpermute-based __shfl_up
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v, int lane)
+{
+    unsigned x = v;
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);   // row_shr:3
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, true);   // row_shr:4, lanes 4..15 of a row
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, true);   // row_shr:8, lanes 8..15
+    const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)x, 15), t1 = (unsigned)__builtin_amdgcn_readlane((int)x, 31),
+                   t2 = (unsigned)__builtin_amdgcn_readlane((int)x, 47);
+    const int row = lane >> 4;
+    return x + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
+}
+
+// ---- K3c: integral + squared integral.  One block (512 threads) per band of rows; a block scans whole
+// rows (4 integral columns per thread, 2048 per pass), keeps the vertical running sums in registers and
+// writes one fully contiguous 16-byte vector per thread and plane: sum (i32) and the squared integral as
+// two u32 planes (low / high word) -- 64-bit values written 8 B per column would leave every store
+// instruction touching a quarter of each 64-byte sector (measured: 2.7 TB/s vs 3.7 TB/s for the sum plane).
+// Thread t owns integral columns X in [4t, 4t+4): value(X) = prefix up to pixel X-1
+// = exclusive base of the thread (X = 4t) or base + local inclusive (X > 4t).
+static constexpr int kIntThreads = 512;
+static constexpr int kIntWaves = kIntThreads / 64;
+
+__global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut,
+                                                          int lut_stride, PreGeom g, const unsigned *__restrict__ bandsum,
+                                                          const unsigned *__restrict__ bandsq, int *__restrict__ sum,
+                                                          unsigned *__restrict__ sq32)
 {
     __shared__ uint8_t sl[256];
-    __shared__ unsigned ws_s[2][4], ws_q[2][4];
-    __shared__ unsigned wb_s[4];
-    __shared__ unsigned long long wb_q[4];
+    __shared__ unsigned ws_s[2][kIntWaves], ws_q[2][kIntWaves];
+    __shared__ unsigned wb_s[kIntWaves];
+    __shared__ unsigned long long wb_q[kIntWaves];
     __shared__ unsigned carry_s[kIntegralBand], carry_q[kIntegralBand];
     __shared__ unsigned cbase_s;
     __shared__ unsigned long long cbase_q;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int band = blockIdx.x, slot = blockIdx.y;
-    sl[tid] = lut ? lut[(size_t)slot * lut_stride + tid] : (uint8_t)tid;
+    if (tid < 256) sl[tid] = lut ? lut[(size_t)slot * lut_stride + tid] : (uint8_t)tid;
     if (tid < kIntegralBand) { carry_s[tid] = 0; carry_q[tid] = 0; }
     if (tid == 0) { cbase_s = 0; cbase_q = 0; }
     __syncthreads();
@@ -429,94 +450,81 @@ __global__ __launch_bounds__(256) void k_integral(const uint8_t *__restrict__ gr
     const int bpitch = (int)(g.band_slot / g.nbands);
     const uint8_t *gbase = gray + (size_t)slot * g.gray_slot;
     int *sbase = sum + (size_t)slot * g.sum_slot;
-    unsigned long long *qbase = sqsum + (size_t)slot * g.sum_slot;
+    unsigned *lbase = sq32 + (size_t)slot * 2 * g.sum_slot, *hbase = lbase + g.sum_slot;
     const unsigned *bs = bandsum + (size_t)slot * g.band_slot + (size_t)band * bpitch;
     const unsigned *bq = bandsq + (size_t)slot * g.band_slot + (size_t)band * bpitch;
     const int nchunks = (g.w + 1 + 2047) / 2048;
 
     for (int c = 0; c < nchunks; c++) {
-        const int X0 = c * 2048 + tid * 8;
+        const int X0 = c * 2048 + tid * 4;
         const bool in_pitch = X0 < g.spitch;
         // ---- base row: prefix over x of the column sums above this band
-        unsigned ps[8]; unsigned long long pq[8];
+        unsigned ps[4]; unsigned long long pq[4];
         {
-            unsigned vs[8], vq[8];
-            if (X0 + 8 <= bpitch) {
-                const uint4 a = *(const uint4 *)(bs + X0), b = *(const uint4 *)(bs + X0 + 4);
-                const uint4 e = *(const uint4 *)(bq + X0), f = *(const uint4 *)(bq + X0 + 4);
-                vs[0] = a.x; vs[1] = a.y; vs[2] = a.z; vs[3] = a.w; vs[4] = b.x; vs[5] = b.y; vs[6] = b.z; vs[7] = b.w;
-                vq[0] = e.x; vq[1] = e.y; vq[2] = e.z; vq[3] = e.w; vq[4] = f.x; vq[5] = f.y; vq[6] = f.z; vq[7] = f.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) { vs[k] = 0; vq[k] = 0; }
-            }
+            uint4 a = make_uint4(0, 0, 0, 0), e = make_uint4(0, 0, 0, 0);
+            if (X0 + 4 <= bpitch) { a = *(const uint4 *)(bs + X0); e = *(const uint4 *)(bq + X0); }
+            const unsigned vs[4] = {a.x, a.y, a.z, a.w}, vq[4] = {e.x, e.y, e.z, e.w};
             unsigned rs = 0; unsigned long long rq = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 4; k++) {
                 const bool ok = X0 + k < g.w;
                 rs += ok ? vs[k] : 0u; rq += ok ? vq[k] : 0u;
                 ps[k] = rs; pq[k] = rq;
             }
         }
-        unsigned ts = ps[7]; unsigned long long tq = pq[7];
-        unsigned is = ts + (tid == 0 ? cbase_s : 0u);
+        const unsigned ts = ps[3]; const unsigned long long tq = pq[3];
+        unsigned is = wave_incl_scan_u32(ts + (tid == 0 ? cbase_s : 0u), lane);
         unsigned long long iq = tq + (tid == 0 ? cbase_q : 0ull);
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned a = __shfl_up(is, d); const unsigned long long b = __shfl_up(iq, d);
-            if (lane >= d) { is += a; iq += b; }
-        }
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long b = __shfl_up(iq, d); if (lane >= d) iq += b; }
         if (lane == 63) { wb_s[wave] = is; wb_q[wave] = iq; }
         __syncthreads();
         for (int j = 0; j < wave; j++) { is += wb_s[j]; iq += wb_q[j]; }
-        unsigned acc_s[8]; unsigned long long acc_q[8];
+        unsigned acc_s[4]; unsigned long long acc_q[4];
         {
             const unsigned es = is - ts; const unsigned long long eq = iq - tq;
             acc_s[0] = es; acc_q[0] = eq;
 #pragma unroll
-            for (int k = 1; k < 8; k++) { acc_s[k] = es + ps[k - 1]; acc_q[k] = eq + pq[k - 1]; }
+            for (int k = 1; k < 4; k++) { acc_s[k] = es + ps[k - 1]; acc_q[k] = eq + pq[k - 1]; }
         }
         __syncthreads();                                   // wb_* consumed
-        if (tid == 255) { cbase_s = is; cbase_q = iq; }
+        if (tid == kIntThreads - 1) { cbase_s = is; cbase_q = iq; }
         if (band == 0 && in_pitch) {                        // integral row 0 (all zero)
-            int *so = sbase + X0; unsigned long long *qo = qbase + X0;
-            *(int4 *)so = make_int4(0, 0, 0, 0); *(int4 *)(so + 4) = make_int4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) *(ulonglong2 *)(qo + k) = make_ulonglong2(0, 0);
+            *(int4 *)(sbase + X0) = make_int4(0, 0, 0, 0);
+            *(uint4 *)(lbase + X0) = make_uint4(0, 0, 0, 0);
+            *(uint4 *)(hbase + X0) = make_uint4(0, 0, 0, 0);
         }
-        // ---- rows of the band
+        // ---- rows of the band (the next row's pixels are in flight while this one is scanned)
+        unsigned px_next = 0;
+        if (X0 < g.w && y0 < y1) px_next = *(const unsigned *)(gbase + (size_t)y0 * g.gpitch + X0);
         for (int y = y0; y < y1; y++) {
             const int r = y - y0, par = r & 1;
-            unsigned long long px = 0;
-            if (X0 < g.w) px = *(const unsigned long long *)(gbase + (size_t)y * g.gpitch + X0);
-            unsigned ls[8], lq[8];
+            const unsigned px = px_next;
+            if (X0 < g.w && y + 1 < y1) px_next = *(const unsigned *)(gbase + (size_t)(y + 1) * g.gpitch + X0);
+            unsigned ls[4], lq[4];
             unsigned rs = 0, rq = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 4; k++) {
                 const unsigned v = (X0 + k < g.w) ? (unsigned)sl[(px >> (8 * k)) & 255] : 0u;
                 rs += v; rq += v * v;
                 ls[k] = rs; lq[k] = rq;
             }
             const unsigned t_s = rs, t_q = rq;
-            unsigned i_s = t_s + (tid == 0 ? carry_s[r] : 0u), i_q = t_q + (tid == 0 ? carry_q[r] : 0u);
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned a = __shfl_up(i_s, d), b = __shfl_up(i_q, d);
-                if (lane >= d) { i_s += a; i_q += b; }
-            }
+            unsigned i_s = wave_incl_scan_u32(t_s + (tid == 0 ? carry_s[r] : 0u), lane);
+            unsigned i_q = wave_incl_scan_u32(t_q + (tid == 0 ? carry_q[r] : 0u), lane);
             if (lane == 63) { ws_s[par][wave] = i_s; ws_q[par][wave] = i_q; }
             __syncthreads();
             for (int j = 0; j < wave; j++) { i_s += ws_s[par][j]; i_q += ws_q[par][j]; }
-            if (tid == 255) { carry_s[r] = i_s; carry_q[r] = i_q; }
+            if (tid == kIntThreads - 1) { carry_s[r] = i_s; carry_q[r] = i_q; }
             const unsigned e_s = i_s - t_s, e_q = i_q - t_q;
             acc_s[0] += e_s; acc_q[0] += e_q;
 #pragma unroll
-            for (int k = 1; k < 8; k++) { acc_s[k] += e_s + ls[k - 1]; acc_q[k] += e_q + lq[k - 1]; }
+            for (int k = 1; k < 4; k++) { acc_s[k] += e_s + ls[k - 1]; acc_q[k] += e_q + lq[k - 1]; }
             if (in_pitch) {
-                int *so = sbase + (size_t)(y + 1) * g.spitch + X0;
-                unsigned long long *qo = qbase + (size_t)(y + 1) * g.spitch + X0;
-                *(int4 *)so = make_int4((int)acc_s[0], (int)acc_s[1], (int)acc_s[2], (int)acc_s[3]);
-                *(int4 *)(so + 4) = make_int4((int)acc_s[4], (int)acc_s[5], (int)acc_s[6], (int)acc_s[7]);
-#pragma unroll
-                for (int k = 0; k < 8; k += 2) *(ulonglong2 *)(qo + k) = make_ulonglong2(acc_q[k], acc_q[k + 1]);
+                const size_t o = (size_t)(y + 1) * g.spitch + X0;
+                *(int4 *)(sbase + o) = make_int4((int)acc_s[0], (int)acc_s[1], (int)acc_s[2], (int)acc_s[3]);
+                *(uint4 *)(lbase + o) = make_uint4((unsigned)acc_q[0], (unsigned)acc_q[1], (unsigned)acc_q[2], (unsigned)acc_q[3]);
+                *(uint4 *)(hbase + o) = make_uint4((unsigned)(acc_q[0] >> 32), (unsigned)(acc_q[1] >> 32), (unsigned)(acc_q[2] >> 32),
+                                                   (unsigned)(acc_q[3] >> 32));
             }
         }
         __syncthreads();
@@ -526,8 +534,8 @@ void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, in
                      const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
                      int batch)
 {
-    hipLaunchKernelGGL(k_integral, dim3(g.nbands, batch), dim3(256), 0, st, gray, lut, lut_stride, g, bandsum,
-                       bandsq, sum, sqsum);
+    hipLaunchKernelGGL(k_integral, dim3(g.nbands, batch), dim3(kIntThreads), 0, st, gray, lut, lut_stride, g, bandsum,
+                       bandsq, sum, (unsigned *)sqsum);
 }
 
 } // namespace nvca
