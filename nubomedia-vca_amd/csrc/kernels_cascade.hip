@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     if (sidx < 0) return;
     const StripRec strip = a.strips[sidx];
     const ScaleRec &sc = a.scales[strip.scale];
-    const int endX = sc.endX, nwin = strip.nrows * endX;
+    // a strip covers columns [ix0, ix0 + ncols) of nrows scan rows (rows longer than a strip are cut into segments)
+    const int endX = strip.ncols, ix0 = strip.ix0, nwin = strip.nrows * endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
     const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
     const int *__restrict__ xpos = a.pos + sc.xpos_off;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
         const int w = base + tid;
         bool keep = false;
         if (w < nwin) {
-            const int r = w / endX, ix = w - r * endX;
+            const int r = w / endX, ix = ix0 + (w - r * endX);
             const unsigned long long *rb = bits + (size_t)r * sc.wpr;
             if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
         }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
             int w = 0;
             if (i < n && p < P) {
                 w = q[cur][i];
-                const int r = w / endX, ix = w - r * endX;
+                const int r = w / endX, ix = ix0 + (w - r * endX);
                 const unsigned off = (unsigned)(ypos[r] * sc.pitch + xpos[ix]);
                 const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
                 const bool pair = a.pair_policy && (st.flags & 1);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
             bool pass = false; int w = 0;
             if (i < n) {
                 w = q[cur][i];
-                const int r = w / endX, ix = w - r * endX;
+                const int r = w / endX, ix = ix0 + (w - r * endX);
                 const unsigned off = (unsigned)(ypos[r] * sc.pitch + xpos[ix]);
                 const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
                 pass = run_stage(sum, off, vnf, recs, st, a.pair_policy);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
         const unsigned gb = gbase_s;
         for (int i = tid; i < nh; i += 256) {
             const int w = q[cur][i];
-            const int r = w / endX, ix = w - r * endX;
+            const int r = w / endX, ix = ix0 + (w - r * endX);
             ent[gb + i] = ((unsigned)slot << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
         }
         return;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     const unsigned gb = gbase_s;
     for (int i = tid; i < nh; i += 256) {
         const int w = q[cur][i];
-        const int r = w / endX, ix = w - r * endX;
+        const int r = w / endX, ix = ix0 + (w - r * endX);
         const unsigned key = ((unsigned)strip.scale << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
         if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
     }

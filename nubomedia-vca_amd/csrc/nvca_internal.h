@@ -71,7 +71,7 @@ struct ScaleRec {           // one evaluated scale
     double factor;
 };
 
-struct StripRec { int scale, iy0, nrows, pad; };   // a block's share of the scan
+struct StripRec { int scale, iy0, nrows, ix0, ncols, pad0, pad1, pad2; };   // a block's share of the scan: nrows x ncols windows
 struct TileRec {            // a tw x th block of windows whose integral footprint is staged in LDS
     int scale, ix0, iy0, tw, th;
     int x0a, y0;            // top-left of the staged region (x0a multiple of 4)

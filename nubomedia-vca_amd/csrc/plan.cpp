@@ -276,12 +276,23 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
                     tile_w.push_back((long long)t.tw * t.th + 64);
                 }
         } else {
-            int rows_per = std::max(1, std::min(kStripMaxWin / sr.endX, 64));
-            if (sr.endX > kStripMaxWin) { err = "row longer than a strip"; return NVCA_ERR_ARG; }
-            for (int iy = 0; iy < sr.endY; iy += rows_per) {
-                StripRec st; st.scale = (int)s; st.iy0 = iy; st.nrows = std::min(rows_per, sr.endY - iy); st.pad = 0;
-                strips.push_back(st);
-                strip_w.push_back((long long)st.nrows * sr.endX);
+            if (sr.endX <= kStripMaxWin) {
+                const int rows_per = std::max(1, std::min(kStripMaxWin / sr.endX, 64));
+                for (int iy = 0; iy < sr.endY; iy += rows_per) {
+                    StripRec st; memset(&st, 0, sizeof(st));
+                    st.scale = (int)s; st.iy0 = iy; st.nrows = std::min(rows_per, sr.endY - iy); st.ix0 = 0; st.ncols = sr.endX;
+                    strips.push_back(st);
+                    strip_w.push_back((long long)st.nrows * st.ncols);
+                }
+            } else {                                 // long rows: equal segments of one row each
+                const int nseg = (sr.endX + kStripMaxWin - 1) / kStripMaxWin, seg = (sr.endX + nseg - 1) / nseg;
+                for (int iy = 0; iy < sr.endY; iy++)
+                    for (int x0 = 0; x0 < sr.endX; x0 += seg) {
+                        StripRec st; memset(&st, 0, sizeof(st));
+                        st.scale = (int)s; st.iy0 = iy; st.nrows = 1; st.ix0 = x0; st.ncols = std::min(seg, sr.endX - x0);
+                        strips.push_back(st);
+                        strip_w.push_back((long long)st.ncols);
+                    }
             }
         }
     }

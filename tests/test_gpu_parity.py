@@ -352,3 +352,23 @@ def test_optional_evaluator_paths(ctx, casc, orc_cascade, env, monkeypatch):
     raw = ctx.detect_raw(casc, g, 1.1, 0, (40, 40))
     eraw = orc.detect_raw(orc_cascade, g, 1.1, 0, (40, 40))
     assert len(eraw) > 0 and np.array_equal(raw, eraw)
+
+
+def test_detect_long_scan_rows(ctx, casc, orc_cascade):
+    """minSize 0 on a wide image: scan rows of > 512 windows are cut into strip segments"""
+    import orc
+    from nubovca import capi, synth
+    g = orc.equalize_hist(synth.make_gray(1400, 300, 31, "natural", [(300, 60, 150), (900, 100, 60)]))
+    assert np.array_equal(ctx.detect_raw(casc, g, 1.2, 0, (0, 0)), orc.detect_raw(orc_cascade, g, 1.2, 0, (0, 0)))
+    assert np.array_equal(ctx.detect_raw(casc, g, 1.2, capi.HAAR_SCALE_IMAGE, (0, 0)),
+                          orc.detect_raw(orc_cascade, g, 1.2, orc.HAAR_SCALE_IMAGE, (0, 0)))
+
+
+def test_detect_4k(ctx, casc, orc_cascade):
+    """3840x2160 (w + 1 > 2048: multi-pass integral rows; sum close to the int32 limit)"""
+    import orc
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(3840, 2160, 41, "natural", [(500, 300, 700), (2500, 900, 400)]))
+    raw = ctx.detect_raw(casc, g, 1.2, 0, (192, 108))
+    eraw = orc.detect_raw(orc_cascade, g, 1.2, 0, (192, 108))
+    assert len(eraw) > 0 and np.array_equal(raw, eraw)
