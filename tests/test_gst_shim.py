@@ -191,3 +191,30 @@ def test_part_pipeline_matches_oracle(shim, synth_xml, orc_cascade, factory, kin
         assert got == ["%s:%d,%d,%d,%d" % ((fmt,) + tuple(x)) for x in a]
         seen += len(a)
     assert seen > 0
+
+
+def test_kurento_double_parses_signal_payload():
+    from nubovca import kurento_double as kd
+    msg = "x:10,y:20,width:30,height:40;x:1,y:2,width:3,height:4;"
+    assert kd.parse_event_string(msg) == [dict(name="face", x=10, y=20, width=30, height=40), dict(name="face", x=1, y=2, width=3, height=4)]
+    assert kd.parse_event_string("") == [] and kd.parse_event_string("x:5,y:6,width:7") == []
+
+
+@pytest.mark.gpu
+def test_signal_payload_round_trips_through_server_parser(shim, synth_xml, orc_cascade):
+    """what `face-event` carries is exactly what NuboFaceDetectorImpl::onFace would turn into FaceInfo records"""
+    import orc
+    from nubovca import kurento_double as kd
+    frames = _scene(4)
+    r = _run_harness("nubofacedetector", "BGR", 640, 480, frames, props=["activate-events=1", "events-ms=0"], cascade_xml=synth_xml)
+    assert r.returncode == 0
+    sigs = [l[len("signal "):] for l in r.stdout.splitlines() if l.startswith("signal ")]
+    ofs = orc.FaceStream(orc_cascade)
+    exp = []
+    for fr in frames:
+        b, _ = ofs.process(fr)
+        if len(b):
+            exp.append([dict(name="face", x=int(x), y=int(y), width=int(w), height=int(h)) for x, y, w, h in b])
+    assert [kd.parse_event_string(s) for s in sigs] == exp and len(exp) > 0
+    for prop in kd.FACE_METHODS.values():
+        assert prop in _inspect("nubofacedetector")
