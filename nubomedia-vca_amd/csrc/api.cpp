@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <fstream>
 #include <sstream>
+#include <chrono>
 
 using namespace nvca;
 
@@ -79,14 +80,15 @@ static inline int cv_round(double v)
 }
 
 struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
-    PinnedBuf h_hits, h_srcptrs;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off, grp, gthr;
+    PinnedBuf h_hits, h_srcptrs, h_grp, h_gthr;
+    std::vector<int> gthr_last;       // thresholds currently resident in gthr
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
         sqsum.release(); hits.release(); srcptrs.release(); staging.release(); aux.release();
-        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
-        h_hits.release(); h_srcptrs.release();
+        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release(); grp.release(); gthr.release();
+        h_hits.release(); h_srcptrs.release(); h_grp.release(); h_gthr.release(); gthr_last.clear();
     }
 };
 
@@ -193,10 +195,16 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
 }
 
 // cascade scan over the integral planes; fills raw[b] (canonical scale,y,x order)
+// group_thr (optional, [batch]): cv::groupRectangles thresholds; when given and the plan allows it the grouping
+// runs on the device (k_group) and raw[b] comes back already grouped -- grouped[b] says which.
+static constexpr int kGroupOutCap = 64;      // final boxes per frame returned by k_group (more -> host grouping)
 static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, int batch,
-                       std::vector<std::vector<nvca_rect>> &raw)
+                       std::vector<std::vector<nvca_rect>> &raw, const int *group_thr = nullptr,
+                       std::vector<char> *grouped = nullptr)
 {
     Workspace &ws = *ctx->ws;
+    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
     raw.assign(batch, {});
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * batch + 64, 1u << 28);   // every window may survive
@@ -208,6 +216,21 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hits.p, 0, sizeof(unsigned long long), ctx->stream));
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
     static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
+    static const bool host_group = getenv("NVCA_HOST_GROUP") != nullptr;         // keep cv::groupRectangles on the host (A/B testing)
+    const bool dev_group = group_thr && grouped && dp.device_group_ok && !host_group && !dp.tasks.empty() && !skip_cascade;
+    if (grouped) grouped->assign(batch, 0);
+    if (dev_group) {
+        if (ws.grp.ensure((size_t)batch * (2 + 4 * kGroupOutCap) * sizeof(int)) || ws.h_grp.ensure((size_t)batch * (2 + 4 * kGroupOutCap) * sizeof(int)) ||
+            ws.gthr.ensure((size_t)batch * sizeof(int)) || ws.h_gthr.ensure((size_t)batch * sizeof(int))) {
+            ctx->set_error("device allocation failed for the grouping workspace"); return NVCA_ERR_NOMEM;
+        }
+        if (ws.gthr_last.size() != (size_t)batch || memcmp(ws.gthr_last.data(), group_thr, batch * sizeof(int)) != 0) {
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));             // h_gthr may still feed an earlier copy
+            memcpy(ws.h_gthr.p, group_thr, batch * sizeof(int));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.gthr.p, ws.h_gthr.p, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            ws.gthr_last.assign(group_thr, group_thr + batch);
+        }
+    }
     if (!dp.tasks.empty() && !skip_cascade) {
         CascadeArgs a;
         a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
@@ -250,13 +273,49 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
             { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
         }
         { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
+        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, ws.gthr.as<int>(), ws.grp.as<int>(), kGroupOutCap, batch); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
+    if (dev_group) {
+        // the device hands back final boxes; the raw list is only fetched for frames it declined
+        const size_t rec = 2 + 4 * kGroupOutCap;
+        int *hg = ws.h_grp.as<int>();
+        unsigned long long *hh = ws.h_hits.as<unsigned long long>();
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hg, ws.grp.p, rec * batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh, ws.hits.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        drain_timer(ctx);
+        const unsigned long long total = hh[0];
+        if (total > cap) {
+            ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
+            return NVCA_ERR_OVERFLOW;
+        }
+        bool need_raw = false;
+        grouped->assign(batch, 1);
+        for (int b = 0; b < batch; b++) {
+            const int *r = hg + rec * b;
+            if (r[0] < 0 || r[0] > kGroupOutCap) { (*grouped)[b] = 0; need_raw = need_raw || r[1] > 0; continue; }
+            raw[b].resize(r[0]);
+            for (int k = 0; k < r[0]; k++) raw[b][k] = nvca_rect{r[2 + 4 * k], r[3 + 4 * k], r[4 + 4 * k], r[5 + 4 * k]};
+        }
+        if (!need_raw) return NVCA_OK;
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1, ws.hits.as<unsigned long long>() + 1, total * sizeof(unsigned long long),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        std::sort(hh + 1, hh + 1 + total);
+        for (unsigned long long i = 0; i < total; i++) {
+            const int slot = (int)(hh[1 + i] >> 32);
+            if (!(*grouped)[slot]) raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
+        }
+        return NVCA_OK;
+    }
     // one D2H covers the count and (almost always) every candidate
     unsigned long long *hh = ws.h_hits.as<unsigned long long>();
     const size_t first = std::min<size_t>(cap, 2048);
     NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh, ws.hits.p, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    auto tp1 = std::chrono::steady_clock::now();
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    auto tp2 = std::chrono::steady_clock::now();
     const unsigned long long total = hh[0];
     if (total > cap) {
         drain_timer(ctx);
@@ -274,6 +333,11 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         const unsigned long long e = hh[1 + i];
         const int slot = (int)(e >> 32);
         raw[slot].push_back(dp.hit_rect((unsigned)e));
+    }
+    if (hostprof) {
+        auto tp3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[nvca host] cascade enqueue %ld us, wait %ld us, collect %ld us\n", us(tp0, tp1), us(tp1, tp2), us(tp2, tp3));
     }
     return NVCA_OK;
 }
@@ -851,8 +915,10 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
     if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, gray, stride, w, h, mem))) return rc;
     run_integral(ctx, gp->g, nullptr, 1);
     std::vector<std::vector<nvca_rect>> raw;
-    if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, 1, raw))) return rc;
-    if (!raw_only) group_all(raw, min_neighbors);
+    const int gthr = (!raw_only && min_neighbors != 0) ? std::max(min_neighbors, 1) : 0;
+    std::vector<char> grouped;
+    if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, 1, raw, gthr ? &gthr : nullptr, &grouped))) return rc;
+    if (gthr && !grouped[0]) group_all(raw, min_neighbors);
     out.swap(raw[0]);
     return NVCA_OK;
 }
@@ -981,6 +1047,8 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
+    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    auto tq0 = std::chrono::steady_clock::now(), tq1 = tq0, tq2 = tq0;
     std::vector<FrameWork> work(n);
     // ---- pass 1: geometry + gating, in frame order
     for (int i = 0; i < n; i++) {
@@ -1030,10 +1098,14 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
           launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), batch); }
         run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), batch);
         std::vector<std::vector<nvca_rect>> raw;
-        if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, batch, raw))) return rc;   // detectMultiScale :809-811
+        tq1 = std::chrono::steady_clock::now();
+        std::vector<int> gthr(batch);
+        std::vector<char> grouped;
+        for (int b = 0; b < batch; b++) { const int mn = streams[idx[b]]->p.min_neighbors; gthr[b] = mn != 0 ? std::max(mn, 1) : 0; }
+        if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, batch, raw, gthr.data(), &grouped))) return rc;   // detectMultiScale :809-811
+        tq2 = std::chrono::steady_clock::now();
         for (int b = 0; b < batch; b++) {
-            const int mn = streams[idx[b]]->p.min_neighbors;
-            if (mn != 0) group_rectangles(raw[b], std::max(mn, 1), 0.2);
+            if (gthr[b] != 0 && !grouped[b]) group_rectangles(raw[b], gthr[b], 0.2);
             work[idx[b]].det.swap(raw[b]);
         }
     }
@@ -1055,6 +1127,11 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
             o.w = (int)((unsigned)r.w * (unsigned)w.norm_scale); o.h = (int)((unsigned)r.h * (unsigned)w.norm_scale);
             if (ids) ids[(size_t)i * cap + k] = s->faces.faces[k].id;
         }
+    }
+    if (hostprof) {
+        auto tq3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[nvca host] batch: before cascade %ld us, cascade %ld us, after %ld us\n", us(tq0, tq1), us(tq1, tq2), us(tq2, tq3));
     }
     return NVCA_OK;
 }

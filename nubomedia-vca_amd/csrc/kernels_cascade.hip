@@ -575,6 +575,162 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
     }
 }
 
+// ---- K6: groupRectangles on the device, one workgroup per frame ----------------------------------
+// cv::groupRectangles(rects, groupThreshold, 0.2) as called at the end of cvHaarDetectObjectsForROC
+// (cascadedetect.cpp / operations.hpp partition()).  The raw candidates of a frame are pulled out of the
+// batch-wide list, sorted by key (= OpenCV's serial scan order: scale, y, x), clustered with a min-index
+// union-find in LDS (class numbering by first member, as cv::partition assigns it), averaged with the same
+// float rounding, filtered, and written as final boxes: the host only receives boxes.
+static constexpr int kGroupMax = 2048;       // raw candidates per frame handled on the device
+
+__device__ __forceinline__ bool similar_rects(const int4 &a, const int4 &b, double eps)
+{
+    const double delta = eps * ((a.z < b.z ? a.z : b.z) + (a.w < b.w ? a.w : b.w)) * 0.5;
+    return abs(a.x - b.x) <= delta && abs(a.y - b.y) <= delta && abs(a.x + a.z - b.x - b.z) <= delta &&
+           abs(a.y + a.w - b.y - b.w) <= delta;
+}
+
+__global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restrict__ group_thr, int *__restrict__ out, int out_cap)
+{
+    __shared__ unsigned keys[kGroupMax];
+    __shared__ int parent[kGroupMax];
+    __shared__ int cls_of[kGroupMax];          // class id of a root; then reused
+    __shared__ int4 rects[kGroupMax];
+    __shared__ int csum[4][256], ccnt[256];    // per-class sums (classes beyond 256 -> fallback)
+    __shared__ int n_s, ncls_s, fallback_s, nout_s;
+    const int tid = threadIdx.x, slot = blockIdx.x;
+    int *o = out + (size_t)slot * (2 + 4 * out_cap);       // [0] = count (-1: host must group), [1] = raw count
+    if (tid == 0) { n_s = 0; ncls_s = 0; fallback_s = 0; nout_s = 0; }
+    __syncthreads();
+    unsigned long long total = a.hits[0];
+    if (total > a.hit_cap) total = a.hit_cap;
+    for (unsigned long long i = tid; i < total; i += 256) {
+        const unsigned long long e = a.hits[1 + i];
+        if ((int)(e >> 32) == slot) {
+            const int k = atomicAdd(&n_s, 1);
+            if (k < kGroupMax) keys[k] = (unsigned)e;
+        }
+    }
+    __syncthreads();
+    const int n = n_s;
+    const int thr = group_thr[slot];
+    if (tid == 0) o[1] = n;
+    if (n > kGroupMax || thr <= 0) { if (tid == 0) o[0] = -1; return; }       // host path (rare / ungrouped)
+    if (n == 0) { if (tid == 0) o[0] = 0; return; }
+    // ---- bitonic sort of the keys (ascending), padded with 0xffffffff
+    int np = 1;
+    while (np < n) np <<= 1;
+    for (int i = n + tid; i < np; i += 256) keys[i] = 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned x = keys[i], y = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    // ---- rectangles + singleton sets
+    for (int i = tid; i < n; i += 256) {
+        const unsigned key = keys[i];
+        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+        const ScaleRec &sc = a.scales[s];
+        rects[i] = make_int4(a.pos[sc.xpos_off + ix], a.pos[sc.ypos_off + iy], sc.winw, sc.winh);
+        parent[i] = i;
+    }
+    __syncthreads();
+    // ---- union of similar pairs (root = smallest member index)
+    const long long npairs = (long long)n * (n - 1) / 2;
+    for (long long p = tid; p < npairs; p += 256) {
+        // unrank p -> (i < j)
+        int j = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+        while ((long long)j * (j - 1) / 2 > p) j--;
+        while ((long long)(j + 1) * j / 2 <= p) j++;
+        const int i = (int)(p - (long long)j * (j - 1) / 2);
+        if (!similar_rects(rects[i], rects[j], 0.2)) continue;
+        int x = i, y = j;
+        for (;;) {
+            while (parent[x] != x) x = parent[x];
+            while (parent[y] != y) y = parent[y];
+            if (x == y) break;
+            if (x > y) { const int t = x; x = y; y = t; }
+            const int old = atomicMin(&parent[y], x);
+            if (old == y) break;
+            y = old;
+        }
+    }
+    __syncthreads();
+    // ---- class ids in order of first member; per-class sums
+    for (int i = tid; i < n; i += 256) {
+        int r = i;
+        while (parent[r] != r) r = parent[r];
+        cls_of[i] = r;                         // root index for now
+    }
+    __syncthreads();
+    if (tid == 0) {                             // number the roots in ascending order (n <= 2048: a short serial pass)
+        int c = 0;
+        for (int i = 0; i < n; i++) if (cls_of[i] == i) { parent[i] = c < 256 ? c : 255; c++; }
+        ncls_s = c;
+        if (c > 256) fallback_s = 1;
+    }
+    for (int i = tid; i < 256; i += 256) { csum[0][i] = csum[1][i] = csum[2][i] = csum[3][i] = 0; ccnt[i] = 0; }
+    __syncthreads();
+    if (fallback_s) { if (tid == 0) o[0] = -1; return; }
+    const int ncls = ncls_s;
+    for (int i = tid; i < n; i += 256) {
+        const int c = parent[cls_of[i]];       // class id of my root
+        atomicAdd(&csum[0][c], rects[i].x); atomicAdd(&csum[1][c], rects[i].y);
+        atomicAdd(&csum[2][c], rects[i].z); atomicAdd(&csum[3][c], rects[i].w);
+        atomicAdd(&ccnt[c], 1);
+    }
+    __syncthreads();
+    // ---- class averages: float s = 1.f / n; saturate_cast<int>(sum * s) (round half to even)
+    int4 avg = make_int4(0, 0, 0, 0); int cnt = 0;
+    if (tid < ncls) {
+        cnt = ccnt[tid];
+        const float sc = 1.f / (float)cnt;
+        avg = make_int4(__float2int_rn((float)csum[0][tid] * sc), __float2int_rn((float)csum[1][tid] * sc),
+                        __float2int_rn((float)csum[2][tid] * sc), __float2int_rn((float)csum[3][tid] * sc));
+    }
+    __syncthreads();
+    if (tid < ncls) { rects[tid] = avg; cls_of[tid] = cnt; }      // reuse LDS: class rects and weights
+    __syncthreads();
+    // ---- keep class i unless too weak or inside a stronger one
+    bool keepc = false;
+    if (tid < ncls && cnt > thr) {
+        keepc = true;
+        for (int j = 0; j < ncls; j++) {
+            const int n2 = cls_of[j];
+            if (j == tid || n2 <= thr) continue;
+            const int4 r2 = rects[j];
+            const int dx = __double2int_rn(r2.z * 0.2), dy = __double2int_rn(r2.w * 0.2);
+            if (avg.x >= r2.x - dx && avg.y >= r2.y - dy && avg.x + avg.z <= r2.x + r2.z + dx && avg.y + avg.w <= r2.y + r2.w + dy &&
+                (n2 > (3 > cnt ? 3 : cnt) || cnt < 3)) { keepc = false; break; }
+        }
+    }
+    // ncls <= 256: one ballot-ordered compaction over the 4 waves, in class order
+    __shared__ int wcount[4];
+    const unsigned long long km = __ballot(keepc);
+    if ((tid & 63) == 0) wcount[tid >> 6] = __popcll(km);
+    __syncthreads();
+    int base = 0;
+    for (int wv = 0; wv < (tid >> 6); wv++) base += wcount[wv];
+    if (keepc) {
+        const int pos = base + __popcll(km & ((1ull << (tid & 63)) - 1ull));
+        if (pos < out_cap) { int *q = o + 2 + 4 * pos; q[0] = avg.x; q[1] = avg.y; q[2] = avg.z; q[3] = avg.w; }
+    }
+    if (tid == 0) o[0] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+}
+
+void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch)
+{
+    hipLaunchKernelGGL(k_group, dim3(batch), dim3(256), 0, st, a, group_thr, out, out_cap);
+}
+
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which)
 {
     if (batch <= 0 || a.ntasks <= 0) return;

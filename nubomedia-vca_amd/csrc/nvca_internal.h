@@ -243,5 +243,7 @@ struct CascadeArgs {
 };
 // which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
+// groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
+void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch);
 
 } // namespace nvca

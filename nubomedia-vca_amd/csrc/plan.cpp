@@ -306,6 +306,9 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     use_lists = false;
     if (const char *e = getenv("NVCA_LISTS")) use_lists = atoi(e) != 0 && !use_tiles;
     if (const char *e = getenv("NVCA_LIST_FROM")) list_from = std::max(1, atoi(e));
+    device_group_ok = true;
+    for (size_t q = 0; q < specs.size(); q++)
+        if (specs[q].out_factor != 0 || specs[q].out_w != scales[q].winw || specs[q].out_h != scales[q].winh) device_group_ok = false;
     return NVCA_OK;
 }
 

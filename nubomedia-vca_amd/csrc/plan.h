@@ -31,6 +31,7 @@ struct DetectPlan {
     std::vector<StripRec> strips;
     std::vector<int> pos;
     std::vector<unsigned> tasks; // stage-0 wave tasks
+    bool device_group_ok = false;     // candidate rects are plain (x, y, winw, winh): k_group can rebuild them
     int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
     std::vector<TileRec> tiles;  // LDS-staged tiles (small scales)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;

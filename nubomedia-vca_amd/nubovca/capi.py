@@ -297,12 +297,12 @@ class Context:
         ids = (C.c_int * (n * cap))()
         cnt = (C.c_int * n)()
         self.check(self.L.nvca_face_batch_process(self.h, n, sh, fr, out, ids, cap, cnt))
+        boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)       # views of the ctypes buffers: no per-box python work
+        idv = np.frombuffer(ids, dtype=np.int32).reshape(n, cap)
         res = []
         for i in range(n):
             k = min(cnt[i], cap)
-            boxes = np.array([[out[i * cap + j].x, out[i * cap + j].y, out[i * cap + j].w, out[i * cap + j].h]
-                              for j in range(k)], np.int32).reshape(k, 4)
-            res.append((boxes, np.array(ids[i * cap:i * cap + k], np.int32)))
+            res.append((boxes[i, :k].copy(), idv[i, :k].copy()))
         return res
 
 

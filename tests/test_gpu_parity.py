@@ -162,6 +162,22 @@ def test_detect_lenient_cascade_many_hits(ctx, casc_small, orc_small):
     assert np.array_equal(det, orc.detect_multiscale(orc_small, g, 1.1, 3, 0, (0, 0)))
 
 
+@pytest.mark.parametrize("w,h,kind,seed", [(400, 300, "gradient", 8), (640, 480, "noise", 5), (800, 600, "natural", 11),
+                                           (1280, 720, "noise", 2)])
+def test_device_grouping_sweep(ctx, casc_small, orc_small, w, h, kind, seed):
+    """groupRectangles runs on the device for the plain scan (k_group): many clusters, every threshold, and the
+    frames with more raw candidates than the kernel takes (host grouping takes over) must all match."""
+    import orc
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(w, h, seed, kind, [(50, 40, 150), (220, 60, 90)]))
+    nraw = len(orc.detect_raw(orc_small, g, 1.1, 0, (0, 0)))
+    assert nraw > 50
+    for mn in (1, 2, 3, 5, 9):
+        det = ctx.detect_multiscale(casc_small, g, 1.1, mn, 0, (0, 0))
+        edet = orc.detect_multiscale(orc_small, g, 1.1, mn, 0, (0, 0))
+        assert np.array_equal(det, edet), (mn, nraw, len(det), len(edet))
+
+
 def test_detect_f64_policy(ctx, casc, orc_cascade):
     import orc
     from nubovca import capi, synth
