@@ -104,7 +104,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_stumps_lds.release(); d_list_off.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_list_off.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -119,7 +119,8 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_tasks, tasks.data(), tasks.size() * sizeof(unsigned)},
         {&d_tiles, tiles.data(), tiles.size() * sizeof(TileRec)},
         {&d_tile_order, tile_order.data(), tile_order.size() * sizeof(int)},
-        {&d_stumps_lds, stumps_lds.data(), stumps_lds.size() * sizeof(StumpRec)},
+        {&d_tstumps, tstumps.data(), tstumps.size() * sizeof(TStumpRec)},
+        {&d_tcoords, tcoords.data(), tcoords.size() * sizeof(unsigned short)},
     };
     for (auto &it : items) {
         if (it.n == 0) continue;
@@ -245,7 +246,8 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
         { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
-        a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.stumps_lds = dp.d_stumps_lds.as<StumpRec>();
+        a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.tstumps = dp.d_tstumps.as<TStumpRec>();
+        a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
         a.list_from = 0;
         a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
         const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());

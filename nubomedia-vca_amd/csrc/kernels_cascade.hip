@@ -12,10 +12,12 @@
 //                    is resolved later in closed form from these bits: window j is
 //                    visited iff the run of stage-0 rejects immediately left of it in
 //                    its row has even length.
-//  K5b k_strip       per strip (<= 512 windows of one scale): visited survivors are
-//                    compacted into LDS and run through the next stages one window
-//                    per lane, re-compacted after every stage; whoever survives
-//                    stage deep_stage-1 is appended to the deep list.
+//  K5b k_tile        per tile (<= 32 x 32 windows of one scale): the integral samples the
+//                    tile touches are staged, compacted, in LDS; visited survivors are
+//                    queued in LDS and run through the next stages one window per lane,
+//                    re-compacted after every stage; whoever survives stage
+//                    deep_stage-1 is appended to the deep list.  (k_strip: the same on
+//                    row strips with global gathers, NVCA_TILES=0.)
 //  K5c k_deep        one wave per surviving window, one stump per lane (the long
 //                    stages have 33..213 stumps): the serial 2000-stump tail of the
 //                    few face-like windows becomes ~34 wave-wide steps.
@@ -377,83 +379,117 @@ __global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
     }
 }
 
-// ---- K5b': the same early stages for the small scales, window sums staged in LDS -------
-// A tw x tw block of windows of one scale reads a footprint of ((tw-1)*ystep + reach)^2
-// samples of the sum plane; it is copied once (coalesced 16-byte loads) into LDS and every
-// rectangle corner is then an LDS read instead of a cache-missing global gather.
+// ---- K5b: stages 1 .. deep_stage-1 on LDS lattice tiles -------------------------------------
+// A tile is nx x ny (<= 32 x 32) windows of one scale.  Window origins and scaled rectangle corners of a scale
+// fall on a near-lattice, so the tile's windows touch only ~2.7 (n + 20) distinct columns and rows of the sum
+// plane whatever the scale.  Those rows x columns are copied, compacted, into LDS once; every rectangle corner
+// is then two u16 map look-ups (column index, row offset) and one LDS read, instead of a global gather whose 64
+// lanes touch up to 64 different cache lines.  Values and arithmetic are unchanged.
+template <bool PAIR>
+__device__ __forceinline__ double tile_vote(const int *T, const unsigned short *cmap, const unsigned short *rmap,
+                                            int xw, int yw, double vnf, const TStumpRec &f)
+{
+    auto rs = [&](int q) {
+        const int c0 = cmap[xw + f.x0[q]], c1 = cmap[xw + f.x1[q]];
+        const int r0 = rmap[yw + f.y0[q]], r1 = rmap[yw + f.y1[q]];
+        return T[r0 + c0] - T[r0 + c1] - T[r1 + c0] + T[r1 + c1];
+    };
+    const int s0 = rs(0);
+    const int s1 = rs(1);
+    const double t = f.thr * vnf;
+    double v;
+    if (PAIR) {
+        const float fs = (float)s0 * f.w[0] + (float)s1 * f.w[1];
+        v = (double)fs;
+    } else {
+        v = (double)((float)s0 * f.w[0]);
+        v += (double)((float)s1 * f.w[1]);
+        if (f.nrect == 3) {
+            const int s2 = rs(2);
+            v += (double)((float)s2 * f.w[2]);
+        }
+    }
+    return v >= t ? f.a1 : f.a0;
+}
+
 __global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
 {
-    __shared__ int tile[kTileRows * kTilePitch];
-    __shared__ double vnf_s[256];
-    __shared__ double psum[kTileThreads];
-    __shared__ unsigned short q[2][256];
-    __shared__ int qn[2];
-    __shared__ unsigned gbase_s;
-
-    const int tid = threadIdx.x, lane = tid & 63;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x / a.tile_blocks_per_frame;
     const int tidx = a.tile_order[blockIdx.x - slot * a.tile_blocks_per_frame];
     if (tidx < 0) return;
     const TileRec t = a.tiles[tidx];
     const ScaleRec &sc = a.scales[t.scale];
-    const StumpRec *__restrict__ recs = a.stumps_lds + t.stump_off;
+    const TStumpRec *__restrict__ recs = a.tstumps + t.stump_off;
 
-    if (tid < 2) qn[tid] = 0;
-    {   // stage the footprint
-        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off + (size_t)t.y0 * a.spitch + t.x0a;
-        // 64 threads across a row (rw4 <= 49 groups), 8 rows in flight per pass, 4 passes unrolled
-        const int c4 = tid & 63, r0 = tid >> 6;
-        if (c4 < t.rw4) {
-            const int *__restrict__ sp = src + c4 * 4;
-            int *dp = &tile[c4 * 4];
-            int r = r0;
-            for (; r + 24 < t.rh; r += 32) {
-                const int4 v0 = *(const int4 *)(sp + (size_t)r * a.spitch);
-                const int4 v1 = *(const int4 *)(sp + (size_t)(r + 8) * a.spitch);
-                const int4 v2 = *(const int4 *)(sp + (size_t)(r + 16) * a.spitch);
-                const int4 v3 = *(const int4 *)(sp + (size_t)(r + 24) * a.spitch);
-                *(int4 *)(dp + r * kTilePitch) = v0;
-                *(int4 *)(dp + (r + 8) * kTilePitch) = v1;
-                *(int4 *)(dp + (r + 16) * kTilePitch) = v2;
-                *(int4 *)(dp + (r + 24) * kTilePitch) = v3;
-            }
-            for (; r < t.rh; r += 8) *(int4 *)(dp + r * kTilePitch) = *(const int4 *)(sp + (size_t)r * a.spitch);
+    // LDS carve-up (tile_lds_bytes() on the host sizes exactly this)
+    double *psum = (double *)lds;
+    unsigned short *q0 = (unsigned short *)(lds + kTileThreads * 8);
+    unsigned short *winx = q0 + 2 * kTileWin * kTileWin, *winy = winx + kTileWin;
+    int *qn = (int *)(winy + kTileWin);                       // qn[0], qn[1], qn[2] = list base
+    unsigned short *cmap = (unsigned short *)((unsigned char *)qn + 64);
+    unsigned short *rmap = cmap + ((t.span_x + 3) & ~3);
+    int *T = (int *)(rmap + ((t.span_y + 3) & ~3));
+    const int pitchT = tile_pitch(t.ncol);
+
+    const unsigned short *__restrict__ cl = a.tcoords + t.col_off, *__restrict__ rl = a.tcoords + t.row_off;
+    const int *__restrict__ xpos = a.pos + sc.xpos_off + t.ix0;
+    const int *__restrict__ ypos = a.pos + sc.ypos_off + t.iy0;
+    if (tid < 3) qn[tid] = 0;
+    if (tid < t.nx) winx[tid] = (unsigned short)(xpos[tid] - t.x0);
+    if (tid >= 64 && tid < 64 + t.ny) winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
+    for (int c = tid; c < t.ncol; c += kTileThreads) cmap[cl[c] - t.x0] = (unsigned short)c;
+    for (int r = tid; r < t.nrow; r += kTileThreads) rmap[rl[r] - t.y0] = (unsigned short)(r * pitchT);
+    {   // stage the sample rows: a wave per row (two rows in flight), lanes across the compacted columns
+        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+        int xc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = c < t.ncol ? (int)cl[c] : -1; }
+        for (int r = wave; r < t.nrow; r += 16) {
+            const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + 8 < t.nrow ? ra + 8 : ra;
+            const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
+            int va[4], vb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (xc[k] >= 0) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (xc[k] >= 0) { T[ra * pitchT + lane + 64 * k] = va[k]; T[rb * pitchT + lane + 64 * k] = vb[k]; }
         }
     }
-    // visited stage-0 survivors of the tile
-    const int nwin = t.tw * t.th;
-    bool keep = false;
-    if (tid < nwin) {
-        const int ty = tid / t.tw, tx = tid - ty * t.tw;
-        const int ix = t.ix0 + tx, iy = t.iy0 + ty;
-        const size_t rowtask = (size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr;
-        const unsigned long long *rb = a.failbits + rowtask;
-        if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = visited(rb, ix);
-        if (keep) vnf_s[tid] = a.vnf[(rowtask + (ix >> 6)) * 64 + (ix & 63)];
-    }
-    __syncthreads();                 // qn zeroed, tile staged
-    {
+    const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
+    const double *__restrict__ vnfp = a.vnf + ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
+    __syncthreads();                 // qn zeroed
+    // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
+    for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
+        const int w = base + tid, ry = w >> 5, rx = w & 31;
+        bool keep = false;
+        if (ry < t.ny && rx < t.nx) {
+            const int ix = t.ix0 + rx;
+            const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
+            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
+        }
         const unsigned long long km = __ballot(keep);
         if (km) {
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&qn[0], __popcll(km));
             wbase = __shfl(wbase, 0);
-            if (keep) q[0][wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+            if (keep) q0[wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
         }
     }
     int cur = 0;
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
     for (int s = 1; s < last; s++) {
-        __syncthreads();
+        __syncthreads();             // queue complete (first pass: tile and maps staged as well)
         const int n = qn[cur];
         if (n == 0) break;
         if (tid == 0) qn[cur ^ 1] = 0;
         __syncthreads();
+        const unsigned short *qi = q0 + cur * kTileWin * kTileWin;
+        unsigned short *qo = q0 + (cur ^ 1) * kTileWin * kTileWin;
         const StageRec st = a.stages[s];
-        bool pass = false; int w = 0;
-        if (st.flags & 2) {
-            // votes may be summed in any order: spread the stage's stumps over the idle lanes.
-            // thread = (window slot i, stump partition p); partition p takes stumps p, p+P, ...
+        const bool pair = a.pair_policy && (st.flags & 1);
+        if ((st.flags & 2) && n <= kTileThreads / 2) {
+            // few survivors and an order-free stage sum: thread = (window slot i, stump partition p)
             int lg = 0;
             while ((1 << lg) < n) lg++;
             const int npad = 1 << lg;
@@ -462,57 +498,74 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
             const int i = tid & (npad - 1), p = tid >> lg;
             double part = 0.0;
             if (i < n && p < P) {
-                w = q[cur][i];
-                const int ty = w / t.tw, tx = w - ty * t.tw;
-                const unsigned o = (unsigned)((a.pos[sc.ypos_off + t.iy0 + ty] - t.y0) * kTilePitch +
-                                              (a.pos[sc.xpos_off + t.ix0 + tx] - t.x0a));
-                const double vnf = vnf_s[w];
-                const bool pair = a.pair_policy && (st.flags & 1);
+                const int w = qi[i], ry = w >> 5, rx = w & 31, ix = t.ix0 + rx;
+                const int xw = winx[rx], yw = winy[ry];
+                const double vnf = vnfp[((size_t)ry * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
                     for (int j = pu; j < st.count; j += P)
-                        part += pair ? stump_vote<true>(tile, o, vnf, recs[st.first + j]) : stump_vote<false>(tile, o, vnf, recs[st.first + j]);
+                        part += pair ? tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j])
+                                     : tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
                 } else {
                     for (int j = p; j < st.count; j += P)
-                        part += pair ? stump_vote<true>(tile, o, vnf, recs[st.first + j]) : stump_vote<false>(tile, o, vnf, recs[st.first + j]);
+                        part += pair ? tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j])
+                                     : tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
                 }
             }
             psum[tid] = part;
             __syncthreads();
+            bool pass = false; int w = 0;
             if (tid < n) {
                 double tot = 0.0;
                 for (int pp = 0; pp < P; pp++) tot += psum[(pp << lg) + tid];
                 pass = !(tot < (double)st.thr);
+                w = qi[tid];
             }
-        } else if (tid < n) {
-            w = q[cur][tid];
-            const int ty = w / t.tw, tx = w - ty * t.tw;
-            const unsigned o = (unsigned)((a.pos[sc.ypos_off + t.iy0 + ty] - t.y0) * kTilePitch +
-                                          (a.pos[sc.xpos_off + t.ix0 + tx] - t.x0a));
-            pass = run_stage(tile, o, vnf_s[w], recs, st, a.pair_policy);
-        }
-        const unsigned long long pm = __ballot(pass);
-        if (pm) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
-            wbase = __shfl(wbase, 0);
-            if (pass) q[cur ^ 1][wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
+                wbase = __shfl(wbase, 0);
+                if (pass) qo[wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
+            }
+        } else
+        for (int base = 0; base < n; base += kTileThreads) {
+            const int i = base + tid;
+            bool pass = false; int w = 0;
+            if (i < n) {
+                w = qi[i];
+                const int ry = w >> 5, rx = w & 31, ix = t.ix0 + rx;
+                const int xw = winx[rx], yw = winy[ry];
+                const double vnf = vnfp[((size_t)ry * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+                double stage_sum = 0.0;
+                if (pair) for (int j = 0; j < st.count; j++) stage_sum += tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
+                else for (int j = 0; j < st.count; j++) stage_sum += tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
+                pass = !(stage_sum < (double)st.thr);
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
+                wbase = __shfl(wbase, 0);
+                if (pass) qo[wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
+            }
         }
         cur ^= 1;
     }
     __syncthreads();
     const int nh = qn[cur];
     if (nh == 0) return;
+    // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
-    if (tid == 0) gbase_s = (unsigned)atomicAdd(list, (unsigned long long)nh);
+    if (tid == 0) qn[2] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
     __syncthreads();
-    const unsigned gb = gbase_s;
-    if (tid < nh) {
-        const int w = q[cur][tid];
-        const int ty = w / t.tw, tx = w - ty * t.tw;
-        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + ty) << 13) | (unsigned)(t.ix0 + tx);
-        if (gb + tid < cap) list[1 + gb + tid] = ((unsigned long long)slot << 32) | key;
+    const unsigned gb = (unsigned)qn[2];
+    const unsigned short *qi = q0 + cur * kTileWin * kTileWin;
+    for (int i = tid; i < nh; i += kTileThreads) {
+        const int w = qi[i];
+        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)(t.ix0 + (w & 31));
+        if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
     }
 }
 
@@ -597,10 +650,10 @@ __global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restr
     __shared__ int cls_of[kGroupMax];          // class id of a root; then reused
     __shared__ int4 rects[kGroupMax];
     __shared__ int csum[4][256], ccnt[256];    // per-class sums (classes beyond 256 -> fallback)
-    __shared__ int n_s, ncls_s, fallback_s, nout_s;
+    __shared__ int n_s, ncls_s, fallback_s;
     const int tid = threadIdx.x, slot = blockIdx.x;
     int *o = out + (size_t)slot * (2 + 4 * out_cap);       // [0] = count (-1: host must group), [1] = raw count
-    if (tid == 0) { n_s = 0; ncls_s = 0; fallback_s = 0; nout_s = 0; }
+    if (tid == 0) { n_s = 0; ncls_s = 0; fallback_s = 0; }
     __syncthreads();
     unsigned long long total = a.hits[0];
     if (total > a.hit_cap) total = a.hit_cap;
@@ -749,8 +802,14 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
         for (int sidx = from; sidx < last; sidx++)
             hipLaunchKernelGGL(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
-        if (a.tile_blocks_per_frame > 0)
-            hipLaunchKernelGGL(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), 0, st, a);
+        if (a.tile_blocks_per_frame > 0) {
+            static int lds_allowed = 0;          // dynamic LDS above 64 KiB has to be granted once
+            if (a.tile_lds > lds_allowed) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
+                lds_allowed = a.tile_lds;
+            }
+            hipLaunchKernelGGL(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
+        }
     } else if (which == 1) {
         if (a.blocks_per_frame > 0)
             hipLaunchKernelGGL(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);

@@ -72,16 +72,35 @@ struct ScaleRec {           // one evaluated scale
 };
 
 struct StripRec { int scale, iy0, nrows, ix0, ncols, pad0, pad1, pad2; };   // a block's share of the scan: nrows x ncols windows
-struct TileRec {            // a tw x th block of windows whose integral footprint is staged in LDS
-    int scale, ix0, iy0, tw, th;
-    int x0a, y0;            // top-left of the staged region (x0a multiple of 4)
-    int rw4, rh;            // region size: rw4 16-byte groups per row, rh rows
-    int stump_off;          // first StumpRec (LDS-pitch offsets) of this scale in stumps_lds
+// A tile is a block of nx x ny windows (<= 32 x 32) of one scale.  The windows of a scale only ever touch the integral
+// image on a near-lattice of positions (window origin + scaled rectangle corner), a small fraction of the pixels they
+// span; the tile kernel stages exactly those sample rows x columns, compacted, in LDS and looks corners up through a
+// column map and a row map.  Tile size in windows is therefore the same at every scale.
+struct TileRec {
+    int scale, ix0, iy0, nx, ny;
+    int x0, y0;             // plane coordinates of the tile's first window: origin of the maps
+    int ncol, nrow;         // distinct sample columns / rows staged
+    int span_x, span_y;     // map extents: the largest column / row offset from (x0, y0) ever looked up, + 1
+    int col_off, row_off;   // first entry of the column / row coordinate lists (plane coordinates, u16) in `tcoords`
+    int stump_off;          // first TStumpRec of this scale
     int pad0, pad1;
 };
-static constexpr int kTileRows = 192;               // staged region: at most 192 rows ...
-static constexpr int kTilePitch = 196;              // ... of 196 ints (147 KiB of the CU's 160 KiB LDS)
+struct TStumpRec {          // a stump with separate corner columns / rows (window-relative pixels)
+    int x0[3], x1[3], y0[3], y1[3];
+    float w[3]; int nrect;
+    double thr, a0, a1;
+};
+static constexpr int kTileWin = 32;                 // windows per tile side (window id = ry * 32 + rx)
 static constexpr int kTileThreads = 512;
+static constexpr int kTileLdsBudget = 80 * 1024 - 512;   // two tiles resident per CU (160 KiB LDS)
+static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
+// LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
+__host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
+__host__ __device__ inline int tile_lds_fixed() { return 2 * kTileWin * kTileWin * 2 + kTileThreads * 8 + 4 * kTileWin + 64; }
+__host__ __device__ inline int tile_lds_bytes(int ncol, int nrow, int span_x, int span_y)
+{
+    return 4 * nrow * tile_pitch(ncol) + 2 * ((span_x + 3) & ~3) + 2 * ((span_y + 3) & ~3) + tile_lds_fixed();
+}
 
 static constexpr int kStripMaxWin = 512;   // windows per strip (LDS budget of the evaluator)
 static constexpr int kIntegralBand = 16;   // rows per integral band
@@ -224,7 +243,7 @@ struct CascadeArgs {
     const StripRec *strips; const int *pos;
     const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
-    const StumpRec *stumps_lds;
+    const TStumpRec *tstumps; const unsigned short *tcoords; int tile_lds;
     // global survivor lists (k_list_*): per-scale segments; counts per stage
     unsigned *list_cnt;            // [nstages][64]
     unsigned *list_ent;            // [2][list_cap]

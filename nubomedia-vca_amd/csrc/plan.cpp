@@ -184,17 +184,17 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     if (!c.stump_based) { err = "tree weak classifiers are not supported by the device evaluator yet"; return NVCA_ERR_UNSUPPORTED; }
     specs = std::move(in);
     nstumps = (int)c.cls.size();
-    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps_lds.clear(); stumps.clear();
+    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps.clear();
     if (const char *e = getenv("NVCA_DEEP_STAGE")) deep_stage = std::max(1, atoi(e));
-    // LDS-staged tiles (k_tile) are kept as an option: on MI355X the row-strip kernel is faster for this
-    // workload ("what was tried"), so they are off unless NVCA_TILES=1
-    bool use_tiles = false;
+    // stages 1 .. deep_stage-1 run on LDS lattice tiles (k_tile); NVCA_TILES=0 selects the older row strips (k_strip)
+    bool use_tiles = true;
     if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
-    use_tiles = use_tiles && allow_tiles;
+    (void)allow_tiles;
+    tstumps.clear(); tcoords.clear(); tile_lds = 0;
     if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
     build_stage_recs(c, stages);
     std::vector<long long> strip_w, tile_w;
-    double last_tf = -1; int last_pitch = -1, last_off = 0;
+    double last_tf = -1; int last_pitch = -1, last_off = 0, last_toff = -1, last_tstump_src = -1;
     for (size_t s = 0; s < specs.size(); s++) {
         const ScaleSpec &sp = specs[s];
         const int pitch = sp.pitch;
@@ -224,58 +224,80 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
         if (sr.endX <= 0 || sr.endY <= 0) continue;
         const int *xp = &pos[sr.xpos_off], *yp = &pos[sr.ypos_off];
         const StumpRec *tab = &stumps[sr.stump_off];
-        // ---- LDS tiles for the small scales: a tw x tw block of windows reads a footprint of
-        // ((tw-1)*ystep + reach)^2 integral samples; stage it once in LDS when it fits and is reused enough
-        int tw = 0, reach_x = 0, reach_y = 0;
-        if (use_tiles && sp.adaptive && sp.plane_off == 0 && (int)stages.size() > 1 && deep_stage > 1) {
-            for (int k = 0; k < nstumps; k++)
+        // ---- LDS lattice tiles: stages 1 .. early_last-1 read only (window origin + scaled corner) samples; per tile of
+        // n x n windows those are ~2.7 (n + 20) distinct columns and rows whatever the scale.  Stage exactly them.
+        int tw = 0;
+        std::vector<int> offx, offy;
+        const int early_last = std::min<int>(deep_stage, (int)stages.size());
+        if (use_tiles && early_last > 1) {
+            const int k0 = stages[1].first, k1 = stages[early_last - 1].first + stages[early_last - 1].count;
+            for (int k = k0; k < k1; k++)
                 for (int q = 0; q < tab[k].nrect; q++) {
-                    reach_x = std::max(reach_x, tab[k].p[q][3] % pitch); reach_y = std::max(reach_y, tab[k].p[q][3] / pitch);
+                    offx.push_back(tab[k].p[q][0] % pitch); offx.push_back(tab[k].p[q][3] % pitch);
+                    offy.push_back(tab[k].p[q][0] / pitch); offy.push_back(tab[k].p[q][3] / pitch);
                 }
-            const double ystep = sr.endX > 1 ? (double)(xp[sr.endX - 1] - xp[0]) / (sr.endX - 1) : 2.;
-            const int budget = std::min(kTileRows, kTilePitch - 4);
-            tw = (int)std::floor((budget - 2 - std::max(reach_x, reach_y) - 1) / ystep) + 1;
-            tw = std::min(tw, 16);
-            int min_tw = 10;
-            if (const char *e = getenv("NVCA_TILE_MIN_TW")) min_tw = std::max(2, atoi(e));
-            while (tw >= min_tw) {                  // verify with the real (rounded) positions
+            std::sort(offx.begin(), offx.end()); offx.erase(std::unique(offx.begin(), offx.end()), offx.end());
+            std::sort(offy.begin(), offy.end()); offy.erase(std::unique(offy.begin(), offy.end()), offy.end());
+            // distinct sample coordinates of windows [i0, i1) along one axis
+            auto coords = [](const int *p, int i0, int i1, const std::vector<int> &off, std::vector<int> &out) {
+                out.clear();
+                for (int i = i0; i < i1; i++) for (int o : off) out.push_back(p[i] + o);
+                std::sort(out.begin(), out.end()); out.erase(std::unique(out.begin(), out.end()), out.end());
+            };
+            std::vector<int> cx, cy;
+            for (tw = kTileWin; tw >= 1; tw--) {         // largest tile side whose every tile fits the LDS budget
                 bool ok = true;
-                for (int i0 = 0; i0 < sr.endX && ok; i0 += tw) {
-                    const int i1 = std::min(i0 + tw, sr.endX) - 1;
-                    if ((xp[i1] + reach_x + 1) - (xp[i0] & ~3) > kTilePitch) ok = false;
+                int worst_c = 0, worst_r = 0, worst_sx = 0, worst_sy = 0;
+                for (int i0 = 0; i0 < sr.endX; i0 += tw) {
+                    coords(xp, i0, std::min(i0 + tw, sr.endX), offx, cx);
+                    worst_c = std::max(worst_c, (int)cx.size()); worst_sx = std::max(worst_sx, cx.back() - xp[i0] + 1);
                 }
-                for (int i0 = 0; i0 < sr.endY && ok; i0 += tw) {
-                    const int i1 = std::min(i0 + tw, sr.endY) - 1;
-                    if ((yp[i1] + reach_y + 1) - yp[i0] > kTileRows) ok = false;
+                for (int i0 = 0; i0 < sr.endY; i0 += tw) {
+                    coords(yp, i0, std::min(i0 + tw, sr.endY), offy, cy);
+                    worst_r = std::max(worst_r, (int)cy.size()); worst_sy = std::max(worst_sy, cy.back() - yp[i0] + 1);
                 }
+                ok = worst_c <= kTileMaxCols && worst_r * tile_pitch(worst_c) < 65536 &&
+                     tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy) <= kTileLdsBudget;
                 if (ok) break;
-                tw--;
             }
-            if (tw < min_tw) tw = 0;
-        }
-        if (tw) {
-            const int lds_off = (int)stumps_lds.size();
-            for (int k = 0; k < nstumps; k++) {          // same records, offsets re-based to the LDS pitch
-                StumpRec r = tab[k];
-                for (int q = 0; q < r.nrect; q++)
-                    for (int e = 0; e < 4; e++) r.p[q][e] = (r.p[q][e] / pitch) * kTilePitch + (r.p[q][e] % pitch);
-                stumps_lds.push_back(r);
-            }
-            const int plane_rows = sp.plane_rows;
-            for (int iy0 = 0; iy0 < sr.endY; iy0 += tw)
-                for (int ix0 = 0; ix0 < sr.endX; ix0 += tw) {
-                    TileRec t; memset(&t, 0, sizeof(t));
-                    t.scale = (int)s; t.ix0 = ix0; t.iy0 = iy0;
-                    t.tw = std::min(tw, sr.endX - ix0); t.th = std::min(tw, sr.endY - iy0);
-                    t.x0a = xp[ix0] & ~3; t.y0 = yp[iy0];
-                    const int xend = std::min(xp[ix0 + t.tw - 1] + reach_x + 1, pitch);
-                    t.rw4 = (xend - t.x0a + 3) / 4;
-                    t.rh = std::min(yp[iy0 + t.th - 1] + reach_y + 1, plane_rows) - t.y0;
-                    t.stump_off = lds_off;
-                    tiles.push_back(t);
-                    tile_w.push_back((long long)t.tw * t.th + 64);
+            if (tw >= 1) {
+                const bool shared = sr.stump_off == last_tstump_src && last_toff >= 0;     // pyramid levels share one table
+                const int toff = shared ? last_toff : (int)tstumps.size();
+                last_toff = toff; last_tstump_src = sr.stump_off;
+                for (int k = 0; k < nstumps && !shared; k++) {
+                    TStumpRec r; memset(&r, 0, sizeof(r));
+                    const StumpRec &f = tab[k];
+                    for (int q = 0; q < f.nrect; q++) {
+                        r.x0[q] = f.p[q][0] % pitch; r.x1[q] = f.p[q][3] % pitch;
+                        r.y0[q] = f.p[q][0] / pitch; r.y1[q] = f.p[q][3] / pitch;
+                        r.w[q] = f.w[q];
+                    }
+                    r.nrect = f.nrect; r.thr = f.thr; r.a0 = f.a0; r.a1 = f.a1;
+                    tstumps.push_back(r);
                 }
-        } else {
+                for (int iy0 = 0; iy0 < sr.endY; iy0 += tw) {
+                    coords(yp, iy0, std::min(iy0 + tw, sr.endY), offy, cy);
+                    const int row_off = (int)tcoords.size();
+                    for (int v : cy) tcoords.push_back((unsigned short)v);
+                    for (int ix0 = 0; ix0 < sr.endX; ix0 += tw) {
+                        coords(xp, ix0, std::min(ix0 + tw, sr.endX), offx, cx);
+                        TileRec t; memset(&t, 0, sizeof(t));
+                        t.scale = (int)s; t.ix0 = ix0; t.iy0 = iy0;
+                        t.nx = std::min(tw, sr.endX - ix0); t.ny = std::min(tw, sr.endY - iy0);
+                        t.x0 = xp[ix0]; t.y0 = yp[iy0];
+                        t.ncol = (int)cx.size(); t.nrow = (int)cy.size();
+                        t.span_x = cx.back() - t.x0 + 1; t.span_y = cy.back() - t.y0 + 1;
+                        t.col_off = (int)tcoords.size(); t.row_off = row_off;
+                        for (int v : cx) tcoords.push_back((unsigned short)v);
+                        t.stump_off = toff;
+                        tile_lds = std::max(tile_lds, tile_lds_bytes(t.ncol, t.nrow, t.span_x, t.span_y));
+                        tiles.push_back(t);
+                        tile_w.push_back((long long)t.nx * t.ny + 256);
+                    }
+                }
+            } else tw = 0;
+        }
+        if (!tw) {
             if (sr.endX <= kStripMaxWin) {
                 const int rows_per = std::max(1, std::min(kStripMaxWin / sr.endX, 64));
                 for (int iy = 0; iy < sr.endY; iy += rows_per) {

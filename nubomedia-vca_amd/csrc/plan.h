@@ -33,9 +33,11 @@ struct DetectPlan {
     std::vector<unsigned> tasks; // stage-0 wave tasks
     bool device_group_ok = false;     // candidate rects are plain (x, y, winw, winh): k_group can rebuild them
     int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
-    std::vector<TileRec> tiles;  // LDS-staged tiles (small scales)
+    std::vector<TileRec> tiles;  // LDS lattice tiles (k_tile); empty: row strips (k_strip)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;
-    std::vector<StumpRec> stumps_lds;
+    std::vector<TStumpRec> tstumps;
+    std::vector<unsigned short> tcoords;
+    int tile_lds = 0;            // dynamic LDS bytes of the largest tile
     std::vector<unsigned> list_off;   // per-scale offsets (windows per frame) into the survivor lists
     unsigned list_windows = 0;        // windows per frame
     bool use_lists = true;
@@ -44,7 +46,7 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_stumps_lds, d_list_off;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_list_off;
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
