@@ -92,7 +92,8 @@ void *nvca_ctx_stream(nvca_ctx *ctx);
 #define NVCA_K_TRACKER   9  /* tracker pixel pass + labelling           */
 #define NVCA_K_RESIZE1  10  /* 8UC1 resize (pyramid / parts)            */
 #define NVCA_K_TILE     11  /* cascade: early stages from LDS-staged tiles */
-#define NVCA_K_COUNT    12
+#define NVCA_K_BAND     12  /* cascade: variance + stage 0 + early stages, one row of tiles per workgroup */
+#define NVCA_K_COUNT    13
 int  nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on);
 /* total_ms[NVCA_K_COUNT], launches[NVCA_K_COUNT]; resets the accumulators */
 int  nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches);

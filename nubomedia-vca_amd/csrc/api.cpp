@@ -104,7 +104,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_list_off.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_list_off.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -121,6 +121,8 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_tile_order, tile_order.data(), tile_order.size() * sizeof(int)},
         {&d_tstumps, tstumps.data(), tstumps.size() * sizeof(TStumpRec)},
         {&d_tcoords, tcoords.data(), tcoords.size() * sizeof(unsigned short)},
+        {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
+        {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
     };
     for (auto &it : items) {
         if (it.n == 0) continue;
@@ -244,14 +246,20 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
         a.deep_stage = dp.deep_stage; a.deep = ws.deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
-        { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.tstumps = dp.d_tstumps.as<TStumpRec>();
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
+        { static const int e = getenv("NVCA_EXP") ? atoi(getenv("NVCA_EXP")) : 0; a.exp = e; }
         a.list_from = 0;
         a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
+        a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
+        // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the GPU several times
+        // over; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
+        static const int band_env = getenv("NVCA_BAND") ? atoi(getenv("NVCA_BAND")) : -1;
+        const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 1024);
+        if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
-        const bool lists = dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
+        const bool lists = !use_band && dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
         if (lists) {
             // per-scale segment offsets depend on the batch (segment = windows of the scale x batch)
             const size_t cap_l = (size_t)dp.list_windows * batch;
@@ -270,6 +278,8 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
             a.list_cnt = ws.list_cnt.as<unsigned>(); a.list_ent = ws.list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
             a.list_cap = (unsigned)cap_l; a.list_from = dp.list_from;
             TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 4);
+        } else if (use_band) {
+            TimedLaunch t(ctx, NVCA_K_BAND); launch_cascade_sc(ctx->stream, a, batch, 5);
         } else {
             { TimedLaunch t(ctx, NVCA_K_TILE); launch_cascade_sc(ctx->stream, a, batch, 3); }
             { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
@@ -497,7 +507,7 @@ const char *nvca_kernel_name(int k)
 {
     static const char *names[NVCA_K_COUNT] = {"gray_resize_hist", "equalize_lut", "integral_colsum", "integral_bandscan",
                                               "integral_rows", "cascade_stage0", "cascade_strip", "cascade_deep",
-                                              "group_rects", "tracker", "resize_gray", "cascade_tile"};
+                                              "group_rects", "tracker", "resize_gray", "cascade_tile", "cascade_band"};
     return (k >= 0 && k < NVCA_K_COUNT) ? names[k] : "?";
 }
 

@@ -29,17 +29,23 @@
 
 namespace nvca {
 
+// Wave-uniform table records are read through the constant address space: the compiler then issues scalar loads
+// (s_load) for them even though the kernels also store to global memory.  The tables are never written by a kernel.
+typedef const __attribute__((address_space(4))) StumpRec CStumpRec;
+typedef const __attribute__((address_space(4))) TStumpRec CTStumpRec;
+
 __device__ __forceinline__ int ldsum(const int *__restrict__ sum, unsigned idx) { return sum[idx]; }
 
-__device__ __forceinline__ int rect_sum(const int *__restrict__ sum, unsigned off, const int *p)
+template <class IntPtr>
+__device__ __forceinline__ int rect_sum(const int *__restrict__ sum, unsigned off, IntPtr p)
 {
     return ldsum(sum, off + (unsigned)p[0]) - ldsum(sum, off + (unsigned)p[1]) - ldsum(sum, off + (unsigned)p[2]) +
            ldsum(sum, off + (unsigned)p[3]);
 }
 
 // feature value of one stump on one window (v) against its threshold: returns the vote
-template <bool PAIR>
-__device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, double vnf, const StumpRec &f)
+template <bool PAIR, class Rec>
+__device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, double vnf, Rec &f)
 {
     const int s0 = rect_sum(sum, off, f.p[0]);
     const int s1 = rect_sum(sum, off, f.p[1]);
@@ -62,7 +68,7 @@ __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsign
 // one stage on one window per lane; recs are wave-uniform (scalar loads)
 template <bool PAIR>
 __device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned off, double vnf,
-                                           const StumpRec *__restrict__ recs, int count, float stage_thr)
+                                           CStumpRec *recs, int count, float stage_thr)
 {
     double stage_sum = 0.0;
     for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR>(sum, off, vnf, recs[j]);
@@ -70,7 +76,7 @@ __device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned
 }
 
 __device__ __forceinline__ bool run_stage(const int *__restrict__ sum, unsigned off, double vnf,
-                                          const StumpRec *__restrict__ recs, const StageRec &st, int pair_policy)
+                                          CStumpRec *recs, const StageRec &st, int pair_policy)
 {
     if (pair_policy && (st.flags & 1)) return eval_stage<true>(sum, off, vnf, recs + st.first, st.count, st.thr);
     return eval_stage<false>(sum, off, vnf, recs + st.first, st.count, st.thr);
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
         vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
         vnf = vnf * sc.inv_area - mean * mean;
         vnf = vnf >= 0. ? sqrt(vnf) : 1.;
-        pass0 = run_stage(sum, off, vnf, a.stumps + sc.stump_off, a.stages[0], a.pair_policy);
+        pass0 = run_stage(sum, off, vnf, (CStumpRec *)(a.stumps + sc.stump_off), a.stages[0], a.pair_policy);
     }
     const unsigned long long fb = __ballot(active && !pass0);
     const size_t o = (size_t)slot * a.ntasks + t;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     // a strip covers columns [ix0, ix0 + ncols) of nrows scan rows (rows longer than a strip are cut into segments)
     const int endX = strip.ncols, ix0 = strip.ix0, nwin = strip.nrows * endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-    const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
+    CStumpRec *recs = (CStumpRec *)(a.stumps + sc.stump_off);
     const int *__restrict__ xpos = a.pos + sc.xpos_off;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + strip.iy0;
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)strip.iy0 * sc.wpr;
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
             const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
             const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
             const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-            pass = run_stage(sum, off, vnf, a.stumps + sc.stump_off, st, a.pair_policy);
+            pass = run_stage(sum, off, vnf, (CStumpRec *)(a.stumps + sc.stump_off), st, a.pair_policy);
         }
         const unsigned long long pm = __ballot(pass);
         if (!pm) continue;
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
 // lanes touch up to 64 different cache lines.  Values and arithmetic are unchanged.
 template <bool PAIR>
 __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *cmap, const unsigned short *rmap,
-                                            int xw, int yw, double vnf, const TStumpRec &f)
+                                            int xw, int yw, double vnf, CTStumpRec &f)
 {
     auto rs = [&](int q) {
         const int c0 = cmap[xw + f.x0[q]], c1 = cmap[xw + f.x1[q]];
@@ -412,80 +418,95 @@ __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *
     return v >= t ? f.a1 : f.a0;
 }
 
-__global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
+// LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
+struct TileLds {
+    double *psum; unsigned short *q0, *winx, *winy; int *qn; double *vnf_s; unsigned *rej; int *carry;
+    unsigned short *cmap, *rmap; int *T; int pitchT;
+};
+__device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec &t)
 {
-    extern __shared__ __align__(16) unsigned char lds[];
+    TileLds L;
+    L.psum = (double *)lds;
+    L.q0 = (unsigned short *)(lds + kTileThreads * 8);
+    L.winx = L.q0 + 2 * kTileWin * kTileWin; L.winy = L.winx + kTileWin;
+    L.qn = (int *)(L.winy + kTileWin);                       // qn[0], qn[1], qn[2] = list base
+    L.vnf_s = (double *)((unsigned char *)L.qn + 64);
+    L.rej = (unsigned *)(L.vnf_s + kTileWin * kTileWin);
+    L.carry = (int *)(L.rej + kTileWin);
+    L.cmap = (unsigned short *)(L.carry + kTileWin);
+    L.rmap = L.cmap + ((t.span_x + 3) & ~3);
+    L.T = (int *)(L.rmap + ((t.span_y + 3) & ~3));
+    L.pitchT = tile_pitch(t.ncol);
+    return L;
+}
+
+// window origins, coordinate maps and the compacted sample rows x columns of one tile -> LDS (no barrier inside)
+__device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.x / a.tile_blocks_per_frame;
-    const int tidx = a.tile_order[blockIdx.x - slot * a.tile_blocks_per_frame];
-    if (tidx < 0) return;
-    const TileRec t = a.tiles[tidx];
-    const ScaleRec &sc = a.scales[t.scale];
-    const TStumpRec *__restrict__ recs = a.tstumps + t.stump_off;
-
-    // LDS carve-up (tile_lds_bytes() on the host sizes exactly this)
-    double *psum = (double *)lds;
-    unsigned short *q0 = (unsigned short *)(lds + kTileThreads * 8);
-    unsigned short *winx = q0 + 2 * kTileWin * kTileWin, *winy = winx + kTileWin;
-    int *qn = (int *)(winy + kTileWin);                       // qn[0], qn[1], qn[2] = list base
-    unsigned short *cmap = (unsigned short *)((unsigned char *)qn + 64);
-    unsigned short *rmap = cmap + ((t.span_x + 3) & ~3);
-    int *T = (int *)(rmap + ((t.span_y + 3) & ~3));
-    const int pitchT = tile_pitch(t.ncol);
-
     const unsigned short *__restrict__ cl = a.tcoords + t.col_off, *__restrict__ rl = a.tcoords + t.row_off;
     const int *__restrict__ xpos = a.pos + sc.xpos_off + t.ix0;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + t.iy0;
-    if (tid < 3) qn[tid] = 0;
-    if (tid < t.nx) winx[tid] = (unsigned short)(xpos[tid] - t.x0);
-    if (tid >= 64 && tid < 64 + t.ny) winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
-    for (int c = tid; c < t.ncol; c += kTileThreads) cmap[cl[c] - t.x0] = (unsigned short)c;
-    for (int r = tid; r < t.nrow; r += kTileThreads) rmap[rl[r] - t.y0] = (unsigned short)(r * pitchT);
-    {   // stage the sample rows: a wave per row (two rows in flight), lanes across the compacted columns
-        const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-        int xc[4];
+    if (tid < 3) L.qn[tid] = 0;
+    if (tid < t.nx) L.winx[tid] = (unsigned short)(xpos[tid] - t.x0);
+    if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
+    for (int c = tid; c < t.ncol; c += kTileThreads) L.cmap[cl[c] - t.x0] = (unsigned short)c;
+    for (int r = tid; r < t.nrow; r += kTileThreads) L.rmap[rl[r] - t.y0] = (unsigned short)(r * L.pitchT);
+    // a wave per sample row (two rows in flight), lanes across the compacted columns
+    const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+    int xc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = c < t.ncol ? (int)cl[c] : -1; }
-        for (int r = wave; r < t.nrow; r += 16) {
-            const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + 8 < t.nrow ? ra + 8 : ra;
-            const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
-            int va[4], vb[4];
+    for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = (int)cl[c < t.ncol ? c : t.ncol - 1]; }   // clamped: loads stay unconditional
+    for (int r = wave; r < t.nrow; r += 16) {
+        const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + 8 < t.nrow ? ra + 8 : ra;
+        const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
+        int va[4], vb[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (xc[k] >= 0) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
+        for (int k = 0; k < 4; k++) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (xc[k] >= 0) { T[ra * pitchT + lane + 64 * k] = va[k]; T[rb * pitchT + lane + 64 * k] = vb[k]; }
-        }
+        for (int k = 0; k < 4; k++) if (lane + 64 * k < t.ncol) { L.T[ra * L.pitchT + lane + 64 * k] = va[k]; L.T[rb * L.pitchT + lane + 64 * k] = vb[k]; }
     }
-    const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
-    const double *__restrict__ vnfp = a.vnf + ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
-    __syncthreads();                 // qn zeroed
-    // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
-    for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
-        const int w = base + tid, ry = w >> 5, rx = w & 31;
-        bool keep = false;
-        if (ry < t.ny && rx < t.nx) {
-            const int ix = t.ix0 + rx;
-            const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
-            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
-        }
-        const unsigned long long km = __ballot(keep);
-        if (km) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&qn[0], __popcll(km));
-            wbase = __shfl(wbase, 0);
-            if (keep) q0[wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
-        }
+}
+
+__device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long km = __ballot(keep);
+    if (km) {
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(count, __popcll(km));
+        wbase = __shfl(wbase, 0);
+        if (keep) q[wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
     }
+}
+
+// stages 1 .. last-1 on the windows queued in q0[0 .. qn[0]) (window id = ry * 32 + rx), then the survivors go to the
+// deep list / the candidates.  VNF_LDS: the variance normaliser comes from L.vnf_s (band kernel, which also has to
+// publish it for k_deep) instead of the stage-0 pre-pass's global array.  Ends with every thread past its last LDS use
+// of the queues only after the caller's next barrier.
+template <bool VNF_LDS>
+__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L)
+{
+    const int tid = threadIdx.x;
+    CTStumpRec *recs = (CTStumpRec *)(a.tstumps + t.stump_off);
+    const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
+    const double *__restrict__ vnfp = a.vnf + vbase;
+    auto vnf_of = [&](int w) {
+        if (VNF_LDS) return L.vnf_s[w];
+        const int ix = t.ix0 + (w & 31);
+        return vnfp[((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+    };
     int cur = 0;
-    const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
+    int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
+    if (a.exp >= 10 && a.exp - 10 < last) last = a.exp - 10;
     for (int s = 1; s < last; s++) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
-        const int n = qn[cur];
+        const int n = L.qn[cur];
         if (n == 0) break;
-        if (tid == 0) qn[cur ^ 1] = 0;
+        if (tid == 0) L.qn[cur ^ 1] = 0;
         __syncthreads();
-        const unsigned short *qi = q0 + cur * kTileWin * kTileWin;
-        unsigned short *qo = q0 + (cur ^ 1) * kTileWin * kTileWin;
+        const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
+        unsigned short *qo = L.q0 + (cur ^ 1) * kTileWin * kTileWin;
         const StageRec st = a.stages[s];
         const bool pair = a.pair_policy && (st.flags & 1);
         if ((st.flags & 2) && n <= kTileThreads / 2) {
@@ -498,74 +519,185 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
             const int i = tid & (npad - 1), p = tid >> lg;
             double part = 0.0;
             if (i < n && p < P) {
-                const int w = qi[i], ry = w >> 5, rx = w & 31, ix = t.ix0 + rx;
-                const int xw = winx[rx], yw = winy[ry];
-                const double vnf = vnfp[((size_t)ry * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+                const int w = qi[i];
+                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                const double vnf = vnf_of(w);
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
                     for (int j = pu; j < st.count; j += P)
-                        part += pair ? tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
+                        part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
+                                     : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 } else {
                     for (int j = p; j < st.count; j += P)
-                        part += pair ? tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
+                        part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
+                                     : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 }
             }
-            psum[tid] = part;
+            L.psum[tid] = part;
             __syncthreads();
             bool pass = false; int w = 0;
             if (tid < n) {
                 double tot = 0.0;
-                for (int pp = 0; pp < P; pp++) tot += psum[(pp << lg) + tid];
+                for (int pp = 0; pp < P; pp++) tot += L.psum[(pp << lg) + tid];
                 pass = !(tot < (double)st.thr);
                 w = qi[tid];
             }
-            const unsigned long long pm = __ballot(pass);
-            if (pm) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
-                wbase = __shfl(wbase, 0);
-                if (pass) qo[wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
-            }
+            queue_push(pass, w, qo, &L.qn[cur ^ 1]);
         } else
         for (int base = 0; base < n; base += kTileThreads) {
             const int i = base + tid;
             bool pass = false; int w = 0;
             if (i < n) {
                 w = qi[i];
-                const int ry = w >> 5, rx = w & 31, ix = t.ix0 + rx;
-                const int xw = winx[rx], yw = winy[ry];
-                const double vnf = vnfp[((size_t)ry * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                const double vnf = vnf_of(w);
                 double stage_sum = 0.0;
-                if (pair) for (int j = 0; j < st.count; j++) stage_sum += tile_vote<true>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
-                else for (int j = 0; j < st.count; j++) stage_sum += tile_vote<false>(T, cmap, rmap, xw, yw, vnf, recs[st.first + j]);
+                if (pair) for (int j = 0; j < st.count; j++) stage_sum += tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
+                else for (int j = 0; j < st.count; j++) stage_sum += tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 pass = !(stage_sum < (double)st.thr);
             }
-            const unsigned long long pm = __ballot(pass);
-            if (pm) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&qn[cur ^ 1], __popcll(pm));
-                wbase = __shfl(wbase, 0);
-                if (pass) qo[wbase + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)w;
-            }
+            queue_push(pass, w, qo, &L.qn[cur ^ 1]);
         }
         cur ^= 1;
     }
     __syncthreads();
-    const int nh = qn[cur];
+    if (a.exp) return;
+    const int nh = L.qn[cur];
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
-    if (tid == 0) qn[2] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
+    if (tid == 0) L.qn[2] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
     __syncthreads();
-    const unsigned gb = (unsigned)qn[2];
-    const unsigned short *qi = q0 + cur * kTileWin * kTileWin;
+    const unsigned gb = (unsigned)L.qn[2];
+    const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
     for (int i = tid; i < nh; i += kTileThreads) {
-        const int w = qi[i];
-        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)(t.ix0 + (w & 31));
+        const int w = qi[i], ix = t.ix0 + (w & 31);
+        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)ix;
         if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
+        if (VNF_LDS && last != a.nstages) a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
+    }
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x / a.tile_blocks_per_frame;
+    const int tidx = a.tile_order[blockIdx.x - slot * a.tile_blocks_per_frame];
+    if (tidx < 0) return;
+    const TileRec t = a.tiles[tidx];
+    const ScaleRec &sc = a.scales[t.scale];
+    const TileLds L = carve_tile(lds, t);
+    tile_fill(a, t, sc, slot, L);
+    const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
+    if (a.exp == 1) return;
+    __syncthreads();                 // qn zeroed
+    // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
+    for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
+        const int w = base + tid, ry = w >> 5, rx = w & 31;
+        bool keep = false;
+        if (ry < t.ny && rx < t.nx) {
+            const int ix = t.ix0 + rx;
+            const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
+            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
+        }
+        queue_push(keep, w, L.q0, &L.qn[0]);
+    }
+    if (a.exp == 2) return;
+    tile_stages<false>(a, t, sc, slot, L);
+}
+
+// ---- K5: the whole early cascade of a band of window rows in one workgroup ---------------------------------------
+// The workgroup walks the band's tiles left to right.  Per tile: stage the samples, evaluate the window variance and
+// stage 0 for every window from LDS (only the squared-integral corners are global reads), resolve the adaptive x step
+// from the tile's reject bits plus the parity of the reject run carried over from the tiles to the left, then run the
+// later stages as k_tile does.  No stage-0 pre-pass, no per-window global intermediates.
+__global__ __launch_bounds__(kTileThreads) void k_band(CascadeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // longest bands first across the whole batch (a band is a serial walk; the short ones level the tail)
+    const int bi = blockIdx.x / a.batch, slot = blockIdx.x - bi * a.batch;
+    const BandRec b = a.bands[a.band_order[bi]];
+    const ScaleRec &sc = a.scales[b.scale];
+    const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
+    const unsigned *__restrict__ sqh = sql + a.sum_slot;
+    const int ex0 = sc.eq[0] % sc.pitch, ey0 = sc.eq[0] / sc.pitch, ex1 = sc.eq[3] % sc.pitch, ey1 = sc.eq[3] / sc.pitch;
+    const StageRec st0 = a.stages[0];
+    const bool pair0 = a.pair_policy && (st0.flags & 1);
+    {   // carried parity lives at a fixed place: the carve-up's fixed part does not depend on the tile
+        const TileRec t0 = a.tiles[b.first_tile];
+        const TileLds L0 = carve_tile(lds, t0);
+        if (tid < kTileWin) L0.carry[tid] = 0;
+    }
+    for (int ti = 0; ti < b.ntiles; ti++) {
+        __syncthreads();             // previous tile completely done with LDS
+        const TileRec t = a.tiles[b.first_tile + ti];
+        const TileLds L = carve_tile(lds, t);
+        CTStumpRec *recs = (CTStumpRec *)(a.tstumps + t.stump_off);
+        tile_fill(a, t, sc, slot, L);
+        __syncthreads();
+        // variance + stage 0 for every window of the tile; a wave covers two window rows
+        for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
+            const int w = base + tid, ry = w >> 5, rx = w & 31;
+            const bool active = ry < t.ny && rx < t.nx;
+            bool pass0 = false;
+            if (active) {
+                const int xw = L.winx[rx], yw = L.winy[ry];
+                const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
+                const int ws = L.T[r0 + c0] - L.T[r0 + c1] - L.T[r1 + c0] + L.T[r1 + c1];
+                const double mean = (double)ws * sc.inv_area;
+                const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
+                const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
+                const unsigned long long q0 = ((unsigned long long)sqh[e0] << 32) | sql[e0], q1 = ((unsigned long long)sqh[e1] << 32) | sql[e1];
+                const unsigned long long q2 = ((unsigned long long)sqh[e2] << 32) | sql[e2], q3 = ((unsigned long long)sqh[e3] << 32) | sql[e3];
+                double vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
+                vnf = vnf * sc.inv_area - mean * mean;
+                vnf = vnf >= 0. ? sqrt(vnf) : 1.;
+                L.vnf_s[w] = vnf;
+                double stage_sum = 0.0;
+                if (pair0) for (int j = 0; j < st0.count; j++) stage_sum += tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st0.first + j]);
+                else for (int j = 0; j < st0.count; j++) stage_sum += tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st0.first + j]);
+                pass0 = !(stage_sum < (double)st0.thr);
+            }
+            const unsigned long long fb = __ballot(active && !pass0);
+            if (lane == 0 && ry < t.ny) L.rej[ry] = (unsigned)fb;
+            if (lane == 32 && ry < t.ny) L.rej[ry] = (unsigned)(fb >> 32);
+        }
+        __syncthreads();
+        // OpenCV's adaptive x step: a window is visited iff the run of stage-0 rejects immediately left of it in its
+        // row has even length; a run that reaches the tile's left edge continues with the carried parity
+        for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
+            const int w = base + tid, ry = w >> 5, rx = w & 31;
+            bool keep = false;
+            if (ry < t.ny && rx < t.nx) {
+                const unsigned R = L.rej[ry];
+                if (!((R >> rx) & 1u)) {
+                    if (!sc.adaptive) keep = true;
+                    else {
+                        int ones = 0;
+                        if (rx > 0) {
+                            const unsigned m = ~(R << (32 - rx));                 // window rx-1 at the MSB, rejects are 0 now
+                            ones = m ? __clz((int)m) : 32;
+                            if (ones > rx) ones = rx;
+                        }
+                        const int parity = ones == rx ? ((rx + L.carry[ry]) & 1) : (ones & 1);
+                        keep = !parity;
+                    }
+                }
+            }
+            queue_push(keep, w, L.q0, &L.qn[0]);
+        }
+        __syncthreads();
+        if (tid < t.ny) {            // parity of the reject run that ends at this tile's right edge
+            const unsigned R = L.rej[tid];
+            const unsigned m = ~(R << (32 - t.nx));
+            int ones = m ? __clz((int)m) : 32;
+            if (ones > t.nx) ones = t.nx;
+            L.carry[tid] = ones == t.nx ? ((t.nx + L.carry[tid]) & 1) : (ones & 1);
+        }
+        tile_stages<true>(a, t, sc, slot, L);
     }
 }
 
@@ -809,6 +941,15 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
                 lds_allowed = a.tile_lds;
             }
             hipLaunchKernelGGL(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
+        }
+    } else if (which == 5) {
+        if (a.band_blocks_per_frame > 0) {
+            static int lds_allowed_b = 0;
+            if (a.tile_lds > lds_allowed_b) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_band), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
+                lds_allowed_b = a.tile_lds;
+            }
+            hipLaunchKernelGGL(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 1) {
         if (a.blocks_per_frame > 0)

@@ -90,13 +90,21 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
     float w[3]; int nrect;
     double thr, a0, a1;
 };
+// A band is one row of tiles (<= 32 window rows of one scale, the full scan width): k_band walks it left to right in one
+// workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
+struct BandRec { int scale, iy0, ny, first_tile, ntiles, pad0, pad1, pad2; };
 static constexpr int kTileWin = 32;                 // windows per tile side (window id = ry * 32 + rx)
 static constexpr int kTileThreads = 512;
 static constexpr int kTileLdsBudget = 80 * 1024 - 512;   // two tiles resident per CU (160 KiB LDS)
 static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
 // LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
 __host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
-__host__ __device__ inline int tile_lds_fixed() { return 2 * kTileWin * kTileWin * 2 + kTileThreads * 8 + 4 * kTileWin + 64; }
+// fixed part: split-K partial sums | two window queues | window origins | counters | per-window variance normaliser
+// (band kernel) | per-row stage-0 reject words and carried run parity (band kernel)
+__host__ __device__ inline int tile_lds_fixed()
+{
+    return kTileThreads * 8 + 2 * kTileWin * kTileWin * 2 + 4 * kTileWin + 64 + kTileWin * kTileWin * 8 + 8 * kTileWin;
+}
 __host__ __device__ inline int tile_lds_bytes(int ncol, int nrow, int span_x, int span_y)
 {
     return 4 * nrow * tile_pitch(ncol) + 2 * ((span_x + 3) & ~3) + 2 * ((span_y + 3) & ~3) + tile_lds_fixed();
@@ -243,7 +251,8 @@ struct CascadeArgs {
     const StripRec *strips; const int *pos;
     const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
-    const TStumpRec *tstumps; const unsigned short *tcoords; int tile_lds;
+    const TStumpRec *tstumps; const unsigned short *tcoords; int tile_lds; int exp;
+    const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch;   // k_band
     // global survivor lists (k_list_*): per-scale segments; counts per stage
     unsigned *list_cnt;            // [nstages][64]
     unsigned *list_ent;            // [2][list_cap]
@@ -260,7 +269,7 @@ struct CascadeArgs {
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
 };
-// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage
+// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage, 5 = k_band
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
 // groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
 void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch);

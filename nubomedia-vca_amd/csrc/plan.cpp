@@ -190,7 +190,7 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     bool use_tiles = true;
     if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
     (void)allow_tiles;
-    tstumps.clear(); tcoords.clear(); tile_lds = 0;
+    tstumps.clear(); tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
     if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
     build_stage_recs(c, stages);
     std::vector<long long> strip_w, tile_w;
@@ -230,7 +230,10 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
         std::vector<int> offx, offy;
         const int early_last = std::min<int>(deep_stage, (int)stages.size());
         if (use_tiles && early_last > 1) {
-            const int k0 = stages[1].first, k1 = stages[early_last - 1].first + stages[early_last - 1].count;
+            // stage 0 and the variance rectangle included: the band kernel evaluates them from the tile as well
+            const int k0 = stages[0].first, k1 = stages[early_last - 1].first + stages[early_last - 1].count;
+            offx.push_back(sr.eq[0] % pitch); offx.push_back(sr.eq[3] % pitch);
+            offy.push_back(sr.eq[0] / pitch); offy.push_back(sr.eq[3] / pitch);
             for (int k = k0; k < k1; k++)
                 for (int q = 0; q < tab[k].nrect; q++) {
                     offx.push_back(tab[k].p[q][0] % pitch); offx.push_back(tab[k].p[q][3] % pitch);
@@ -277,6 +280,10 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
                 }
                 for (int iy0 = 0; iy0 < sr.endY; iy0 += tw) {
                     coords(yp, iy0, std::min(iy0 + tw, sr.endY), offy, cy);
+                    BandRec b; memset(&b, 0, sizeof(b));
+                    b.scale = (int)s; b.iy0 = iy0; b.ny = std::min(tw, sr.endY - iy0); b.first_tile = (int)tiles.size();
+                    b.ntiles = (sr.endX + tw - 1) / tw;
+                    bands.push_back(b);
                     const int row_off = (int)tcoords.size();
                     for (int v : cy) tcoords.push_back((unsigned short)v);
                     for (int ix0 = 0; ix0 < sr.endX; ix0 += tw) {
@@ -320,6 +327,13 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     }
     blocks_per_frame = build_xcd_order(strip_w, order);
     tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
+    if (!strips.empty()) bands.clear();          // the band kernel has no strip counterpart: all scales tiled, or none
+    {   // bands: longest first (a band is a serial walk over its tiles; the short ones fill the tail)
+        band_order.resize(bands.size());
+        for (size_t i = 0; i < bands.size(); i++) band_order[i] = (int)i;
+        std::stable_sort(band_order.begin(), band_order.end(), [&](int x, int y) { return bands[x].ntiles > bands[y].ntiles; });
+        band_blocks_per_frame = (int)bands.size();
+    }
     // per-scale segments of the global survivor lists (sized per frame; api.cpp scales them by the batch)
     list_off.clear(); list_windows = 0;
     for (const ScaleRec &sr : scales) { list_off.push_back(list_windows); list_windows += (unsigned)std::max(sr.endX, 0) * (unsigned)std::max(sr.endY, 0); }

@@ -17,7 +17,7 @@ ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OVERFLO
 MEM_HOST, MEM_DEVICE = 0, 1
 HAAR_DO_CANNY_PRUNING, HAAR_SCALE_IMAGE, HAAR_FIND_BIGGEST_OBJECT, HAAR_DO_ROUGH_SEARCH = 1, 2, 4, 8
 SUM_F32PAIR, SUM_F64 = 0, 1
-K_COUNT = 12
+K_COUNT = 13
 
 
 class NvcaError(RuntimeError):
