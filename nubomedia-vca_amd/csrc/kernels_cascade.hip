@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
 // plane whatever the scale.  Those rows x columns are copied, compacted, into LDS once; every rectangle corner
 // is then two u16 map look-ups (column index, row offset) and one LDS read, instead of a global gather whose 64
 // lanes touch up to 64 different cache lines.  Values and arithmetic are unchanged.
-template <bool PAIR>
+template <bool PAIR, bool UNI = true>
 __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *cmap, const unsigned short *rmap,
                                             int xw, int yw, double vnf, CTStumpRec &f)
 {
@@ -415,7 +415,9 @@ __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *
             v += (double)((float)s2 * f.w[2]);
         }
     }
-    return v >= t ? f.a1 : f.a0;
+    double a0 = f.a0, a1 = f.a1;
+    if (UNI) asm volatile("" : "+s"(a0), "+s"(a1));      // wave-uniform record: both votes stay in scalar registers (no dependent load of the selected one)
+    return v >= t ? a1 : a0;
 }
 
 // LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
@@ -529,8 +531,8 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                                      : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 } else {
                     for (int j = p; j < st.count; j += P)
-                        part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
+                        part += pair ? tile_vote<true, false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
+                                     : tile_vote<false, false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 }
             }
             L.psum[tid] = part;
