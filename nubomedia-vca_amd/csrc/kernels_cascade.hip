@@ -44,7 +44,7 @@ __device__ __forceinline__ int rect_sum(const int *__restrict__ sum, unsigned of
 }
 
 // feature value of one stump on one window (v) against its threshold: returns the vote
-template <bool PAIR, class Rec>
+template <bool PAIR, class Rec, bool UNI = false>
 __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, double vnf, Rec &f)
 {
     const int s0 = rect_sum(sum, off, f.p[0]);
@@ -62,7 +62,9 @@ __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsign
             v += (double)((float)s2 * f.w[2]);
         }
     }
-    return v >= t ? f.a1 : f.a0;
+    double a0 = f.a0, a1 = f.a1;
+    if (UNI) asm volatile("" : "+s"(a0), "+s"(a1));      // wave-uniform record: both votes stay in scalar registers
+    return v >= t ? a1 : a0;
 }
 
 // one stage on one window per lane; recs are wave-uniform (scalar loads)
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned
                                            CStumpRec *recs, int count, float stage_thr)
 {
     double stage_sum = 0.0;
-    for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR>(sum, off, vnf, recs[j]);
+    for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR, CStumpRec, true>(sum, off, vnf, recs[j]);
     return !(stage_sum < (double)stage_thr);
 }
 
@@ -459,8 +461,9 @@ __device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t
     int xc[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = (int)cl[c < t.ncol ? c : t.ncol - 1]; }   // clamped: loads stay unconditional
-    for (int r = wave; r < t.nrow; r += 16) {
-        const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + 8 < t.nrow ? ra + 8 : ra;
+    constexpr int NW = kTileThreads / 64;
+    for (int r = wave; r < t.nrow; r += 2 * NW) {
+        const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + NW < t.nrow ? ra + NW : ra;
         const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
         int va[4], vb[4];
 #pragma unroll
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
 // stage 0 for every window from LDS (only the squared-integral corners are global reads), resolve the adaptive x step
 // from the tile's reject bits plus the parity of the reject run carried over from the tiles to the left, then run the
 // later stages as k_tile does.  No stage-0 pre-pass, no per-window global intermediates.
-__global__ __launch_bounds__(kTileThreads) void k_band(CascadeArgs a)
+__global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(CascadeArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;

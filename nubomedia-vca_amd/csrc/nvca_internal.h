@@ -94,7 +94,7 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
 // workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
 struct BandRec { int scale, iy0, ny, first_tile, ntiles, pad0, pad1, pad2; };
 static constexpr int kTileWin = 32;                 // windows per tile side (window id = ry * 32 + rx)
-static constexpr int kTileThreads = 512;
+static constexpr int kTileThreads = 1024;
 static constexpr int kTileLdsBudget = 80 * 1024 - 512;   // two tiles resident per CU (160 KiB LDS)
 static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
 // LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
