@@ -185,7 +185,8 @@ def main():
         ab = algorithmic_bytes(W, H, w, h, n_boxes)
         groups = {"gray_resize_hist": ["gray_resize_hist"], "equalize_lut": ["equalize_lut"],
                   "integral": ["integral_colsum", "integral_bandscan", "integral_rows"],
-                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep", "cascade_tile"], "tracker": ["tracker"]}
+                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep", "cascade_tile", "cascade_band", "group_rects"],
+                  "tracker": ["tracker"]}
         kern = {}
         for gname, members in groups.items():
             ms = sum(ktimes.get(m, (0.0, 0))[0] for m in members)

@@ -255,7 +255,8 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the GPU several times
         // over; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
-        static const int band_env = getenv("NVCA_BAND") ? atoi(getenv("NVCA_BAND")) : -1;
+        const char *band_e = getenv("NVCA_BAND");
+        const int band_env = band_e ? atoi(band_e) : -1;
         const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 1024);
         if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
