@@ -299,6 +299,11 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         drain_timer(ctx);
         const unsigned long long total = hh[0];
+        if (hostprof) {
+            unsigned long long dc = 0;
+            (void)hipMemcpy(&dc, ws.deep.p, sizeof(dc), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[nvca host] deep windows %llu, raw candidates %llu (batch %d)\n", dc, total, batch);
+        }
         if (total > cap) {
             ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
             return NVCA_ERR_OVERFLOW;

@@ -18,9 +18,9 @@
 //                    re-compacted after every stage; whoever survives stage
 //                    deep_stage-1 is appended to the deep list.  (k_strip: the same on
 //                    row strips with global gathers, NVCA_TILES=0.)
-//  K5c k_deep        one wave per surviving window, one stump per lane (the long
+//  K5c k_deep        one workgroup per surviving window, one stump per thread (the long
 //                    stages have 33..213 stumps): the serial 2000-stump tail of the
-//                    few face-like windows becomes ~34 wave-wide steps.
+//                    few face-like windows becomes one step per stage.
 // Stage/rect tables are wave-uniform in K5a/K5b (scalar loads) and coalesced
 // per-lane records in K5c; window sums are gathers from the integral planes.
 // No MFMA: integer rect sums, f32 products, f64 stage sums -- exactly the
@@ -715,14 +715,17 @@ __device__ __forceinline__ double wave_sum_exact(double v)
 
 __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // one workgroup per surviving window: every late stage (33..213 stumps) is one step, stump per thread
+    __shared__ double part[2][4];
+    __shared__ double votes[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long cnt = a.deep[0];
     if (cnt > a.deep_cap) {                              // list overflowed: poison the hit count (host reports it)
-        if (gw == 0 && lane == 0) atomicAdd(a.hits, 1ull << 40);
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(a.hits, 1ull << 40);
         cnt = a.deep_cap;
     }
-    for (unsigned long long i = gw; i < cnt; i += nwaves) {
+    int flip = 0;                                        // partial-sum buffers alternate across stages AND windows
+    for (unsigned long long i = blockIdx.x; i < cnt; i += gridDim.x) {
         const unsigned long long e = a.deep[1 + i];
         const int slot = (int)(e >> 32);
         const unsigned key = (unsigned)e;
@@ -738,27 +741,34 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
             const bool pair = a.pair_policy && (st.flags & 1);
             double stage_sum = 0.0;
             if (st.flags & 2) {                         // any summation order is exact
-                double part = 0.0;
-                for (int j = lane; j < st.count; j += 64) {
+                double p = 0.0;
+                for (int j = tid; j < st.count; j += 256) {
                     const StumpRec &f = recs[st.first + j];
-                    part += pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
+                    p += pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
                 }
-                stage_sum = wave_sum_exact(part);
+                p = wave_sum_exact(p);
+                if (lane == 0) part[flip][wave] = p;
+                __syncthreads();
+                stage_sum = (part[flip][0] + part[flip][1]) + (part[flip][2] + part[flip][3]);
+                flip ^= 1;
             } else {                                    // keep OpenCV's left-to-right order
-                for (int c = 0; c < st.count; c += 64) {
-                    const int j = c + lane;
+                for (int c = 0; c < st.count; c += 256) {
+                    const int j = c + tid;
                     double vote = 0.0;
                     if (j < st.count) {
                         const StumpRec &f = recs[st.first + j];
                         vote = pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
                     }
-                    const int m = st.count - c < 64 ? st.count - c : 64;
-                    for (int l = 0; l < m; l++) stage_sum += __shfl(vote, l);
+                    __syncthreads();
+                    votes[tid] = vote;
+                    __syncthreads();
+                    const int m = st.count - c < 256 ? st.count - c : 256;
+                    for (int l = 0; l < m; l++) stage_sum += votes[l];      // every thread walks the same order
                 }
             }
             if (stage_sum < (double)st.thr) { alive = false; break; }
         }
-        if (alive && lane == 0) {
+        if (alive && tid == 0) {
             const unsigned long long h = atomicAdd(a.hits, 1ull);
             if (h < a.hit_cap) a.hits[1 + h] = e;
         }
@@ -960,7 +970,7 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
         if (a.blocks_per_frame > 0)
             hipLaunchKernelGGL(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
     } else if (a.deep_stage < a.nstages) {
-        hipLaunchKernelGGL(k_deep, dim3(256u * 8u), dim3(256), 0, st, a);    // 8192 waves, grid-stride over the list
+        hipLaunchKernelGGL(k_deep, dim3(8192), dim3(256), 0, st, a);    // grid-stride over the list, one window per workgroup at a time
     }
 }
 
