@@ -197,41 +197,56 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
       launch_integral(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), sum, sq, batch); }
 }
 
-// cascade scan over the integral planes; fills raw[b] (canonical scale,y,x order)
-// group_thr (optional, [batch]): cv::groupRectangles thresholds; when given and the plan allows it the grouping
+// cascade scan over the integral planes of slots [0, n); fills raw[b] (canonical scale,y,x order)
+// group_thr (optional, [n]): cv::groupRectangles thresholds; when given and the plan allows it the grouping
 // runs on the device (k_group) and raw[b] comes back already grouped -- grouped[b] says which.
+// A job owns a result region (`r0` = index of its first frame in the caller's batch of `total` frames): its candidate
+// list and box table stay untouched while later jobs are enqueued, so several jobs can be queued before one sync.
 static constexpr int kGroupOutCap = 64;      // final boxes per frame returned by k_group (more -> host grouping)
-static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, int batch,
-                       std::vector<std::vector<nvca_rect>> &raw, const int *group_thr = nullptr,
-                       std::vector<char> *grouped = nullptr)
+struct CascadeJob {
+    int r0 = 0, n = 0, total = 0;
+    bool dev_group = false;
+    unsigned cap = 0;
+    size_t first = 0;         // raw candidates fetched with the count (raw mode)
+    unsigned long long *d_hits = nullptr, *h_hits = nullptr;
+    int *d_grp = nullptr, *h_grp = nullptr;
+};
+
+static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, CascadeJob &job, const int *group_thr, bool want_group)
 {
     Workspace &ws = *ctx->ws;
-    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
-    auto tp0 = std::chrono::steady_clock::now();
-    raw.assign(batch, {});
+    const int batch = job.n, total = std::max(job.total, job.r0 + job.n);
+    const size_t hits_stride = (size_t)ctx->hit_cap + 1;                 // u64 words per result slot
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * batch + 64, 1u << 28);   // every window may survive
     if (ws.failbits.ensure(dp.tasks.size() * sizeof(unsigned long long) * batch + 8) ||
         ws.vnf.ensure(dp.tasks.size() * 64 * sizeof(double) * batch + 8) ||
-        ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long))) {
+        ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
+        ws.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || ws.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
         ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
     }
-    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hits.p, 0, sizeof(unsigned long long), ctx->stream));
+    job.cap = cap;
+    job.d_hits = ws.hits.as<unsigned long long>() + hits_stride * job.r0;
+    job.h_hits = ws.h_hits.as<unsigned long long>() + hits_stride * job.r0;
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->stream));
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
     static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
     static const bool host_group = getenv("NVCA_HOST_GROUP") != nullptr;         // keep cv::groupRectangles on the host (A/B testing)
-    const bool dev_group = group_thr && grouped && dp.device_group_ok && !host_group && !dp.tasks.empty() && !skip_cascade;
-    if (grouped) grouped->assign(batch, 0);
+    const bool dev_group = group_thr && want_group && dp.device_group_ok && !host_group && !dp.tasks.empty() && !skip_cascade;
+    job.dev_group = dev_group;
+    const size_t rec = 2 + 4 * kGroupOutCap;
     if (dev_group) {
-        if (ws.grp.ensure((size_t)batch * (2 + 4 * kGroupOutCap) * sizeof(int)) || ws.h_grp.ensure((size_t)batch * (2 + 4 * kGroupOutCap) * sizeof(int)) ||
-            ws.gthr.ensure((size_t)batch * sizeof(int)) || ws.h_gthr.ensure((size_t)batch * sizeof(int))) {
+        if (ws.grp.ensure((size_t)total * rec * sizeof(int)) || ws.h_grp.ensure((size_t)total * rec * sizeof(int)) ||
+            ws.gthr.ensure((size_t)total * sizeof(int)) || ws.h_gthr.ensure((size_t)total * sizeof(int))) {
             ctx->set_error("device allocation failed for the grouping workspace"); return NVCA_ERR_NOMEM;
         }
-        if (ws.gthr_last.size() != (size_t)batch || memcmp(ws.gthr_last.data(), group_thr, batch * sizeof(int)) != 0) {
+        job.d_grp = ws.grp.as<int>() + rec * job.r0; job.h_grp = ws.h_grp.as<int>() + rec * job.r0;
+        if (ws.gthr_last.size() < (size_t)total) ws.gthr_last.resize(total, -1);
+        if (memcmp(ws.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));             // h_gthr may still feed an earlier copy
-            memcpy(ws.h_gthr.p, group_thr, batch * sizeof(int));
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.gthr.p, ws.h_gthr.p, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            ws.gthr_last.assign(group_thr, group_thr + batch);
+            memcpy(ws.h_gthr.as<int>() + job.r0, group_thr, batch * sizeof(int));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.gthr.as<int>() + job.r0, ws.h_gthr.as<int>() + job.r0, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            std::copy(group_thr, group_thr + batch, ws.gthr_last.begin() + job.r0);
         }
     }
     if (!dp.tasks.empty() && !skip_cascade) {
@@ -245,7 +260,7 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
         a.failbits = ws.failbits.as<unsigned long long>(); a.vnf = ws.vnf.as<double>();
         a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
         a.deep_stage = dp.deep_stage; a.deep = ws.deep.as<unsigned long long>(); a.deep_cap = deep_cap;
-        a.hits = ws.hits.as<unsigned long long>(); a.hit_cap = cap;
+        a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.tstumps = dp.d_tstumps.as<TStumpRec>();
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
@@ -286,78 +301,75 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
             { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
         }
         { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
-        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, ws.gthr.as<int>(), ws.grp.as<int>(), kGroupOutCap, batch); }
+        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, ws.gthr.as<int>() + job.r0, job.d_grp, kGroupOutCap, batch); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
-    if (dev_group) {
-        // the device hands back final boxes; the raw list is only fetched for frames it declined
+    if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, rec * batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    } else {              // one D2H covers the count and (almost always) every candidate
+        job.first = std::min<size_t>(cap, 2048);
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, (job.first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return NVCA_OK;
+}
+
+// after the stream has been synchronised: raw[b] / grouped[b] for the job's n frames
+static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job, std::vector<std::vector<nvca_rect>> &raw,
+                           std::vector<char> *grouped)
+{
+    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    const int batch = job.n;
+    raw.assign(batch, {});
+    if (grouped) grouped->assign(batch, 0);
+    unsigned long long *hh = job.h_hits;
+    const unsigned long long total = hh[0];
+    if (hostprof) {
+        unsigned long long dc = 0;
+        (void)hipMemcpy(&dc, ctx->ws->deep.p, sizeof(dc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[nvca host] deep windows (last job) %llu, raw candidates %llu (job of %d)\n", dc, total, batch);
+    }
+    if (total > job.cap) {
+        ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
+        return NVCA_ERR_OVERFLOW;
+    }
+    size_t have = job.first;
+    if (job.dev_group) {
         const size_t rec = 2 + 4 * kGroupOutCap;
-        int *hg = ws.h_grp.as<int>();
-        unsigned long long *hh = ws.h_hits.as<unsigned long long>();
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hg, ws.grp.p, rec * batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh, ws.hits.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        drain_timer(ctx);
-        const unsigned long long total = hh[0];
-        if (hostprof) {
-            unsigned long long dc = 0;
-            (void)hipMemcpy(&dc, ws.deep.p, sizeof(dc), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[nvca host] deep windows %llu, raw candidates %llu (batch %d)\n", dc, total, batch);
-        }
-        if (total > cap) {
-            ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
-            return NVCA_ERR_OVERFLOW;
-        }
         bool need_raw = false;
         grouped->assign(batch, 1);
         for (int b = 0; b < batch; b++) {
-            const int *r = hg + rec * b;
+            const int *r = job.h_grp + rec * b;
             if (r[0] < 0 || r[0] > kGroupOutCap) { (*grouped)[b] = 0; need_raw = need_raw || r[1] > 0; continue; }
             raw[b].resize(r[0]);
             for (int k = 0; k < r[0]; k++) raw[b][k] = nvca_rect{r[2 + 4 * k], r[3 + 4 * k], r[4 + 4 * k], r[5 + 4 * k]};
         }
         if (!need_raw) return NVCA_OK;
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1, ws.hits.as<unsigned long long>() + 1, total * sizeof(unsigned long long),
+        have = 0;
+    }
+    if (total > have) {
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + have, job.d_hits + 1 + have, (total - have) * sizeof(unsigned long long),
                                            hipMemcpyDeviceToHost, ctx->stream));
         NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        std::sort(hh + 1, hh + 1 + total);
-        for (unsigned long long i = 0; i < total; i++) {
-            const int slot = (int)(hh[1 + i] >> 32);
-            if (!(*grouped)[slot]) raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
-        }
-        return NVCA_OK;
     }
-    // one D2H covers the count and (almost always) every candidate
-    unsigned long long *hh = ws.h_hits.as<unsigned long long>();
-    const size_t first = std::min<size_t>(cap, 2048);
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh, ws.hits.p, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    auto tp1 = std::chrono::steady_clock::now();
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    auto tp2 = std::chrono::steady_clock::now();
-    const unsigned long long total = hh[0];
-    if (total > cap) {
-        drain_timer(ctx);
-        ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
-        return NVCA_ERR_OVERFLOW;
-    }
-    if (total > first) {
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ws.hits.as<unsigned long long>() + 1 + first,
-                                           (total - first) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    drain_timer(ctx);
     std::sort(hh + 1, hh + 1 + total);
     for (unsigned long long i = 0; i < total; i++) {
-        const unsigned long long e = hh[1 + i];
-        const int slot = (int)(e >> 32);
-        raw[slot].push_back(dp.hit_rect((unsigned)e));
-    }
-    if (hostprof) {
-        auto tp3 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        fprintf(stderr, "[nvca host] cascade enqueue %ld us, wait %ld us, collect %ld us\n", us(tp0, tp1), us(tp1, tp2), us(tp2, tp3));
+        const int slot = (int)(hh[1 + i] >> 32);
+        if (!job.dev_group || !(*grouped)[slot]) raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
     }
     return NVCA_OK;
+}
+
+static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, int batch,
+                       std::vector<std::vector<nvca_rect>> &raw, const int *group_thr = nullptr,
+                       std::vector<char> *grouped = nullptr)
+{
+    CascadeJob job; job.n = batch; job.total = batch;
+    int rc = cascade_enqueue(ctx, dp, sum_slot, spitch, job, group_thr, grouped != nullptr);
+    if (rc) return rc;
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timer(ctx);
+    return cascade_collect(ctx, dp, job, raw, grouped);
 }
 
 static void group_all(std::vector<std::vector<nvca_rect>> &raw, int min_neighbors)
@@ -431,6 +443,8 @@ nvca_ctx::~nvca_ctx()
     if (identity_lut) (void)hipFree(identity_lut);
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -450,7 +464,8 @@ int nvca_ctx_create(int device_id, nvca_ctx **out)
     if (!ctx) return NVCA_ERR_NOMEM;
     ctx->device = device_id;
     ctx->ws.reset(new Workspace());
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NVCA_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NVCA_ERR_HIP; }
     *out = ctx;
     return NVCA_OK;
 }
@@ -603,32 +618,45 @@ static int check_img(nvca_ctx *ctx, const void *p, int w, int h, int stride, int
 }
 
 // stage `n` source frames (host or device) and return device pointers in ws.srcptrs
-static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx, int n, int bpp)
+static size_t staging_need(const nvca_frame *frames, const int *idx, int n)
 {
-    Workspace &ws = *ctx->ws;
-    if (ws.srcptrs.ensure((size_t)n * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)n * sizeof(void *))) {
-        ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
-    }
     size_t need = 0;
     for (int i = 0; i < n; i++) {
         const nvca_frame &f = frames[idx ? idx[i] : i];
         if (f.mem == NVCA_MEM_HOST) need += round_up((size_t)f.stride * f.height, 256);
     }
-    if (need && ws.staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
-    const void **hp = ws.h_srcptrs.as<const void *>();
-    size_t off = 0;
+    return need;
+}
+
+// frame pointers of n frames -> device pointer array entries [r0, r0 + n); host frames are copied into the staging
+// buffer first (from byte offset *off on, advanced).  `st`: the stream the copies are queued on.
+static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx, int n, int bpp, int r0 = 0,
+                        hipStream_t st = nullptr, size_t *off_io = nullptr)
+{
+    Workspace &ws = *ctx->ws;
+    if (!st) st = ctx->stream;
+    if (!off_io) {           // stand-alone call: size the buffers here
+        if (ws.srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
+            ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
+        }
+        const size_t need = staging_need(frames, idx, n);
+        if (need && ws.staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
+    }
+    const void **hp = ws.h_srcptrs.as<const void *>() + r0;
+    size_t off = off_io ? *off_io : 0;
     for (int i = 0; i < n; i++) {
         const nvca_frame &f = frames[idx ? idx[i] : i];
         if (f.mem == NVCA_MEM_HOST) {
             uint8_t *d = ws.staging.as<uint8_t>() + off;
             NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp,
-                                               hipMemcpyHostToDevice, ctx->stream));
+                                               hipMemcpyHostToDevice, st));
             hp[i] = d;
             off += round_up((size_t)f.stride * f.height, 256);
         } else
             hp[i] = f.data;
     }
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.srcptrs.p, hp, (size_t)n * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.srcptrs.as<const void *>() + r0, hp, (size_t)n * sizeof(void *), hipMemcpyHostToDevice, st));
+    if (off_io) *off_io = off;
     return NVCA_OK;
 }
 
@@ -1104,27 +1132,61 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
         const double sf = 1 + s0->p.scale_factor_pct * 1.0 / 100;      // MULTI_SCALE_FACTOR :142
         int rc = get_face_plan(ctx, s0->cascade, f0.width, f0.height, f0.stride, 3, cols, rows, sf, cols / 20, rows / 20, 0, 0, &gp);
         if (rc) return rc;
-        if ((rc = ensure_ws(ctx, gp->g, batch))) return rc;
-        if ((rc = stage_frames(ctx, frames, idx.data(), batch, 3))) return rc;
+        // Host frames: the batch goes through in chunks -- chunk c+1's H2D copies run on the copy stream while the
+        // kernels of chunk c execute (with pageable memory the host blocks in the copy, the queued kernels do not).
+        // Every chunk reuses planes [0, chunk); only its candidate list / box table are its own (CascadeJob).
+        bool any_host = false;
+        for (int b = 0; b < batch; b++) any_host = any_host || frames[idx[b]].mem == NVCA_MEM_HOST;
+        static const int chunk_env = getenv("NVCA_INGEST_CHUNK") ? atoi(getenv("NVCA_INGEST_CHUNK")) : 8;
+        const int chunk = (any_host && chunk_env > 0 && batch >= 2 * chunk_env) ? chunk_env : batch;
+        const bool piped = chunk < batch;
+        if ((rc = ensure_ws(ctx, gp->g, chunk))) return rc;
         Workspace &ws = *ctx->ws;
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)batch * 256 * sizeof(unsigned), ctx->stream));
-        { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
-          launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>(), gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
-                      gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
-                      ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), batch, frames_aligned4(frames, idx.data(), batch)); }
-        { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
-          launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), batch); }
-        run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), batch);
-        std::vector<std::vector<nvca_rect>> raw;
-        tq1 = std::chrono::steady_clock::now();
+        {
+            const size_t need = staging_need(frames, idx.data(), batch);
+            if (ws.srcptrs.ensure((size_t)batch * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)batch * sizeof(void *)) ||
+                (need && ws.staging.ensure(need))) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
+        }
         std::vector<int> gthr(batch);
-        std::vector<char> grouped;
         for (int b = 0; b < batch; b++) { const int mn = streams[idx[b]]->p.min_neighbors; gthr[b] = mn != 0 ? std::max(mn, 1) : 0; }
-        if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, batch, raw, gthr.data(), &grouped))) return rc;   // detectMultiScale :809-811
+        std::vector<CascadeJob> jobs;
+        size_t stage_off = 0;
+        tq1 = std::chrono::steady_clock::now();
+        for (int s0 = 0; s0 < batch; s0 += chunk) {
+            const int n = std::min(chunk, batch - s0);
+            if ((rc = stage_frames(ctx, frames, idx.data() + s0, n, 3, s0, piped ? ctx->copy_stream : ctx->stream, &stage_off))) return rc;
+            if (piped) {
+                while (ctx->chunk_events.size() <= jobs.size()) {
+                    hipEvent_t ev; NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    ctx->chunk_events.push_back(ev);
+                }
+                NVCA_HIP_CHECK(ctx, hipEventRecord(ctx->chunk_events[jobs.size()], ctx->copy_stream));
+                NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->chunk_events[jobs.size()], 0));
+            }
+            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)n * 256 * sizeof(unsigned), ctx->stream));
+            { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
+              launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>() + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
+                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
+                          ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), n, frames_aligned4(frames, idx.data() + s0, n)); }
+            { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
+              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), n); }
+            run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), n);
+            CascadeJob job; job.r0 = s0; job.n = n; job.total = batch;
+            if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
+            jobs.push_back(job);
+        }
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        drain_timer(ctx);
         tq2 = std::chrono::steady_clock::now();
-        for (int b = 0; b < batch; b++) {
-            if (gthr[b] != 0 && !grouped[b]) group_rectangles(raw[b], gthr[b], 0.2);
-            work[idx[b]].det.swap(raw[b]);
+        for (const CascadeJob &job : jobs) {
+            std::vector<std::vector<nvca_rect>> raw;
+            std::vector<char> grouped;
+            if ((rc = cascade_collect(ctx, gp->det, job, raw, &grouped))) return rc;
+            for (int b = 0; b < job.n; b++) {
+                const int gi = job.r0 + b;
+                if (gthr[gi] != 0 && !grouped[b]) group_rectangles(raw[b], gthr[gi], 0.2);
+                work[idx[gi]].det.swap(raw[b]);
+            }
         }
     }
     // ---- pass 3: temporal logic + emission, in frame order

@@ -168,6 +168,8 @@ struct nvca_cascade { nvca::Cascade c; nvca_ctx *ctx; };
 struct nvca_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
+    std::vector<hipEvent_t> chunk_events;
     std::string err;
     int hit_cap = 16384;
     int policy = NVCA_SUM_F32PAIR;

@@ -280,6 +280,30 @@ def test_face_batch_equals_sequential(ctx, casc, orc_cascade):
             assert np.array_equal(boxes, eb) and np.array_equal(ids, eid)
 
 
+def test_face_batch_chunked_ingest(ctx, casc, orc_cascade):
+    """a large batch of HOST frames goes through in chunks (H2D of the next chunk overlaps the kernels of the current
+    one, each chunk with its own candidate list / box table); device frames mixed in; min_neighbors differs per stream"""
+    import orc
+    import torch
+    from nubovca import capi, synth
+    W, H, N = 480, 360, 21
+    frames = [synth.make_bgr(W, H, 300 + i, "natural", [(30 + 9 * i, 40 + (i % 5) * 20, 120 + 4 * i)] if i % 4 != 3 else []) for i in range(N)]
+    props = [{"width_to_process": W, "multi_scale_factor": 10, "min_neighbors": 2 + (i % 3)} for i in range(N)]
+    streams = [capi.FaceStream(ctx, casc, **props[i]) for i in range(N)]
+    dev = {i: torch.from_numpy(frames[i]).cuda() for i in (5, 13)}
+    torch.cuda.synchronize()
+    fr = [capi.make_frame(dev[i].data_ptr(), W, H, W * 3, capi.MEM_DEVICE) if i in dev else capi.make_frame(frames[i]) for i in range(N)]
+    for rep in range(2):                               # the second pass exercises the temporal state as well
+        res = ctx.face_batch_process(streams, fr)
+        for i in range(N):
+            if rep == 0:
+                kw = {"width_to_process": "width_to_process", "multi_scale_factor": "scale_factor_pct", "min_neighbors": "min_neighbors"}
+                streams[i]._o = orc.FaceStream(orc_cascade, **{kw[k]: v for k, v in props[i].items()})
+            eb, eid = streams[i]._o.process(frames[i])
+            assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (rep, i)
+    assert sum(len(r[0]) for r in res) >= 10
+
+
 def test_face_stream_device_frames(ctx, casc, orc_cascade):
     """frames already resident in HBM (torch tensors) give the same boxes as host frames."""
     import orc
