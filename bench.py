@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--faces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
+    ap.add_argument("--pinned", action="store_true", help="with --host-frames: page-lock the frame buffers (nvca_host_register)")
     ap.add_argument("--workload", default="face1080p", choices=["face1080p", "streams720p", "face_tracker"],
                     help="face1080p: BASELINE configs[1] (default, the headline metric); streams720p: configs[3], "
                          "--streams-per-gpu 720p streams, one frame each per step; face_tracker: configs[4], "
@@ -131,6 +132,10 @@ def main():
     if args.host_frames:
         frames_t = [[capi.make_frame(f) for f in row] for row in frames_np]
         keep = frames_np
+        if args.pinned:
+            for row in frames_np:
+                for f in row:
+                    ctx.host_register(f)
     else:
         keep = [[torch.from_numpy(f).to(dev) for f in row] for row in frames_np]
         frames_t = [[capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in row] for row in keep]
@@ -226,7 +231,7 @@ def main():
                                      "NuboFaceDetector + NuboTracker %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F))
                                     ) % ((W, H) if not multi_stream else ()) +
                                    ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
-                       "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": "host" if args.host_frames else "hbm",
+                       "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
                        "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world},
             "roofline": roofline,
         }

@@ -77,6 +77,12 @@ int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
 int  nvca_ctx_synchronize(nvca_ctx *ctx);
 /* the hipStream_t the context launches on (for interop / profiling) */
 void *nvca_ctx_stream(nvca_ctx *ctx);
+/* Zero-copy ingest: page-lock caller-owned frame memory (e.g. the buffers of a GstBufferPool, mapped by
+ * kms_face_detect_conf_images, FACE/kmsfacedetect.cpp:282-306) so that the H2D copies of NVCA_MEM_HOST frames are true
+ * asynchronous DMA.  Optional: pageable frames work, they are just copied through the driver's staging buffers.
+ * Unregister before the memory is freed. */
+int  nvca_host_register(nvca_ctx *ctx, void *ptr, size_t bytes);
+int  nvca_host_unregister(nvca_ctx *ctx, void *ptr);
 
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,
  * every kernel launch is bracketed by events; nvca_ctx_kernel_timing drains them. */

@@ -501,6 +501,24 @@ int nvca_ctx_synchronize(nvca_ctx *ctx)
 }
 void *nvca_ctx_stream(nvca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int nvca_host_register(nvca_ctx *ctx, void *ptr, size_t bytes)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!ptr || !bytes) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    NVCA_HIP_CHECK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return NVCA_OK;
+}
+int nvca_host_unregister(nvca_ctx *ctx, void *ptr)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!ptr) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipHostUnregister(ptr));
+    return NVCA_OK;
+}
+
 int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
 {
     NVCA_LOCK_OR_FAIL(ctx);

@@ -67,6 +67,7 @@ SYMBOLS = [
     "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process", "nvca_flip_horizontal",
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
+    "nvca_host_register", "nvca_host_unregister",
 ]
 
 _lib = None
@@ -113,6 +114,8 @@ def load():
     L.nvca_ctx_set_sum_policy.argtypes = [vp, C.c_int]
     L.nvca_ctx_synchronize.argtypes = [vp]
     L.nvca_ctx_stream.argtypes = [vp]
+    L.nvca_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.nvca_host_unregister.argtypes = [vp, vp]
     L.nvca_ctx_stream.restype = vp
     L.nvca_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.nvca_ctx_kernel_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -202,6 +205,13 @@ class Context:
 
     def synchronize(self):
         self.check(self.L.nvca_ctx_synchronize(self.h))
+
+    def host_register(self, arr):
+        """page-lock a numpy frame (zero-copy ingest); pair with host_unregister before the array goes away"""
+        self.check(self.L.nvca_host_register(self.h, arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr):
+        self.check(self.L.nvca_host_unregister(self.h, arr.ctypes.data))
 
     def enable_kernel_timing(self, on=True):
         self.check(self.L.nvca_ctx_enable_kernel_timing(self.h, int(on)))

@@ -304,6 +304,25 @@ def test_face_batch_chunked_ingest(ctx, casc, orc_cascade):
     assert sum(len(r[0]) for r in res) >= 10
 
 
+def test_face_batch_registered_host_frames(ctx, casc, orc_cascade):
+    """page-locked (nvca_host_register) host frames: asynchronous H2D in the chunked ingest path, same boxes"""
+    import orc
+    from nubovca import capi, synth
+    W, H, N = 400, 300, 18
+    frames = [synth.make_bgr(W, H, 900 + i, "natural", [(20 + 10 * i, 30 + (i % 4) * 25, 110 + 5 * i)]) for i in range(N)]
+    for f in frames:
+        ctx.host_register(f)
+    try:
+        streams = [capi.FaceStream(ctx, casc, width_to_process=W, multi_scale_factor=10) for _ in range(N)]
+        res = ctx.face_batch_process(streams, [capi.make_frame(f) for f in frames])
+        for i in range(N):
+            eb, eid = orc.FaceStream(orc_cascade, width_to_process=W, scale_factor_pct=10).process(frames[i])
+            assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), i
+    finally:
+        for f in frames:
+            ctx.host_unregister(f)
+
+
 def test_face_stream_device_frames(ctx, casc, orc_cascade):
     """frames already resident in HBM (torch tensors) give the same boxes as host frames."""
     import orc
