@@ -42,31 +42,38 @@ int PinnedBuf::ensure(size_t n)
 }
 void PinnedBuf::release() { if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; } }
 
+static thread_local TimedLaunch *g_scope = nullptr;
 TimedLaunch::TimedLaunch(nvca_ctx *c, int kind) : ctx(c), k(kind)
 {
-    KernelTimer &t = ctx->timer;
-    if (!t.on) return;
+    if (!ctx->timer.on) return;
+    active = true; prev = g_scope; g_scope = this;
+}
+TimedLaunch::~TimedLaunch()
+{
+    if (active) g_scope = prev;
+}
+bool launch_events(hipEvent_t *a, hipEvent_t *b)
+{
+    TimedLaunch *sc = g_scope;
+    if (!sc) return false;
+    KernelTimer &t = sc->ctx->timer;
     auto get = [&]() {
         hipEvent_t e = nullptr;
         if (!t.pool.empty()) { e = t.pool.back(); t.pool.pop_back(); }
         else (void)hipEventCreate(&e);
         return e;
     };
-    a = get(); b = get();
-    (void)hipEventRecord(a, ctx->stream);
-}
-TimedLaunch::~TimedLaunch()
-{
-    if (!a) return;
-    (void)hipEventRecord(b, ctx->stream);
-    ctx->timer.pending.push_back(KernelTimer::Ev{a, b, k});
+    *a = get(); *b = get();
+    if (!*a || !*b) return false;
+    t.pending.push_back(KernelTimer::Ev{*a, *b, sc->k, sc->n++ == 0});
+    return true;
 }
 static void drain_timer(nvca_ctx *ctx)     // stream must be idle
 {
     KernelTimer &t = ctx->timer;
     for (auto &e : t.pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { t.total_ms[e.k] += ms; t.launches[e.k]++; }
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { t.total_ms[e.k] += ms; if (e.first) t.launches[e.k]++; }
         t.pool.push_back(e.a); t.pool.push_back(e.b);
     }
     t.pending.clear();

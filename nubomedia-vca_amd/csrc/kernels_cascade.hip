@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restr
 
 void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch)
 {
-    hipLaunchKernelGGL(k_group, dim3(batch), dim3(256), 0, st, a, group_thr, out, out_cap);
+    NVCA_LAUNCH(k_group, dim3(batch), dim3(256), 0, st, a, group_thr, out, out_cap);
 }
 
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which)
@@ -936,18 +936,18 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
     if (batch <= 0 || a.ntasks <= 0) return;
     if (which == 0) {
         const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
-        hipLaunchKernelGGL(k_stage0, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
+        NVCA_LAUNCH(k_stage0, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
     } else if (which == 4) {         // strips for the crowded first stages, global lists (full waves) for the thinned-out ones
         const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
         const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
         int from = a.list_from;
         if (from <= 1) {             // everything on lists
-            hipLaunchKernelGGL(k_list_seed, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
+            NVCA_LAUNCH(k_list_seed, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
             from = 1;
         } else if (a.blocks_per_frame > 0)
-            hipLaunchKernelGGL(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
+            NVCA_LAUNCH(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
         for (int sidx = from; sidx < last; sidx++)
-            hipLaunchKernelGGL(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
+            NVCA_LAUNCH(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
         if (a.tile_blocks_per_frame > 0) {
             static int lds_allowed = 0;          // dynamic LDS above 64 KiB has to be granted once
@@ -955,7 +955,7 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
                 lds_allowed = a.tile_lds;
             }
-            hipLaunchKernelGGL(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
+            NVCA_LAUNCH(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 5) {
         if (a.band_blocks_per_frame > 0) {
@@ -964,13 +964,13 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_band), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
                 lds_allowed_b = a.tile_lds;
             }
-            hipLaunchKernelGGL(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
+            NVCA_LAUNCH(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 1) {
         if (a.blocks_per_frame > 0)
-            hipLaunchKernelGGL(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
+            NVCA_LAUNCH(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
     } else if (a.deep_stage < a.nstages) {
-        hipLaunchKernelGGL(k_deep, dim3(8192), dim3(256), 0, st, a);    // grid-stride over the list, one window per workgroup at a time
+        NVCA_LAUNCH(k_deep, dim3(8192), dim3(256), 0, st, a);    // grid-stride over the list, one window per workgroup at a time
     }
 }
 

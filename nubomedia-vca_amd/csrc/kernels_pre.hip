@@ -147,11 +147,11 @@ void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, 
     const int gy = (g.h + kGrayRows - 1) / kGrayRows;
     if (mode == 0 && aligned4 && (g.cn == 3 || g.cn == 4)) {
         dim3 grid((g.w + 1023) / 1024, gy, batch);
-        if (g.cn == 3) hipLaunchKernelGGL(k_gray_fast4<3>, grid, dim3(256), 0, st, d_src, g, gray, hist);
-        else           hipLaunchKernelGGL(k_gray_fast4<4>, grid, dim3(256), 0, st, d_src, g, gray, hist);
+        if (g.cn == 3) NVCA_LAUNCH(k_gray_fast4<3>, grid, dim3(256), 0, st, d_src, g, gray, hist);
+        else           NVCA_LAUNCH(k_gray_fast4<4>, grid, dim3(256), 0, st, d_src, g, gray, hist);
     } else {
         dim3 grid((g.w + 255) / 256, gy, batch);
-        hipLaunchKernelGGL(k_gray_generic, grid, dim3(256), 0, st, d_src, g, mode, d_xofs, d_ialpha, d_yofs,
+        NVCA_LAUNCH(k_gray_generic, grid, dim3(256), 0, st, d_src, g, mode, d_xofs, d_ialpha, d_yofs,
                            d_ibeta, xmax, gray, hist);
     }
 }
@@ -240,7 +240,7 @@ void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
                     int xmax, uint8_t *dst, int dw, int dh, int dstride)
 {
     dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, 1);
-    hipLaunchKernelGGL(k_resize3, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs, d_ibeta, xmax,
+    NVCA_LAUNCH(k_resize3, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs, d_ibeta, xmax,
                        dst, dw, dh, dstride);
 }
 
@@ -249,7 +249,7 @@ void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
                     int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist)
 {
     dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, 1);
-    hipLaunchKernelGGL(k_resize1, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs,
+    NVCA_LAUNCH(k_resize1, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs,
                        d_ibeta, xmax, dst, dw, dh, dstride, hist);
 }
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_lut(const unsigned *__restrict__ hist, 
 
 void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch)
 {
-    hipLaunchKernelGGL(k_lut, dim3(batch), dim3(256), 0, st, hist, total, lut);
+    NVCA_LAUNCH(k_lut, dim3(batch), dim3(256), 0, st, hist, total, lut);
 }
 
 __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ gray, int w, int h, int pitch,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ gray, 
 void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist)
 {
     dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
-    hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, st, gray, w, h, pitch, hist);
+    NVCA_LAUNCH(k_hist, grid, dim3(256), 0, st, gray, w, h, pitch, hist);
 }
 
 __global__ __launch_bounds__(256) void k_apply_lut(const uint8_t *__restrict__ src, int w, int h, int spitch,
@@ -326,7 +326,7 @@ void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spit
                       uint8_t *dst, int dpitch)
 {
     dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
-    hipLaunchKernelGGL(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch);
+    NVCA_LAUNCH(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch);
 }
 
 // ---- cv::flip(src, dst, 1) (EAR/kmseardetect.cpp:800)
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_flip_h(const uint8_t *__restrict__ src,
 void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch)
 {
     dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
-    hipLaunchKernelGGL(k_flip_h, grid, dim3(256), 0, st, src, w, h, spitch, dst, dpitch);
+    NVCA_LAUNCH(k_flip_h, grid, dim3(256), 0, st, src, w, h, spitch, dst, dpitch);
 }
 
 // ---- K3a: per-band column sums of lut[gray] and its square
@@ -379,7 +379,7 @@ void launch_colsum(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int 
 {
     const int bpitch = (int)(g.band_slot / g.nbands);
     dim3 grid((bpitch / 4 + 255) / 256, g.nbands, batch);
-    hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, st, gray, lut, lut_stride, g, bandsum, bandsq);
+    NVCA_LAUNCH(k_colsum, grid, dim3(256), 0, st, gray, lut, lut_stride, g, bandsum, bandsq);
 }
 
 // ---- K3b: exclusive scan over bands, per column (in place)
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_bandscan(PreGeom g, unsigned *__restric
 void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsigned *bandsq, int batch)
 {
     const int bpitch = (int)(g.band_slot / g.nbands);
-    hipLaunchKernelGGL(k_bandscan, dim3((bpitch + 255) / 256, batch), dim3(256), 0, st, g, bandsum, bandsq);
+    NVCA_LAUNCH(k_bandscan, dim3((bpitch + 255) / 256, batch), dim3(256), 0, st, g, bandsum, bandsq);
 }
 
 // wave64 inclusive add-scan on the VALU (DPP row shifts inside each row of 16 lanes, then the three row totals
@@ -534,7 +534,7 @@ void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, in
                      const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
                      int batch)
 {
-    hipLaunchKernelGGL(k_integral, dim3(g.nbands, batch), dim3(kIntThreads), 0, st, gray, lut, lut_stride, g, bandsum,
+    NVCA_LAUNCH(k_integral, dim3(g.nbands, batch), dim3(kIntThreads), 0, st, gray, lut, lut_stride, g, bandsum,
                        bandsq, sum, (unsigned *)sqsum);
 }
 

@@ -171,15 +171,15 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     const TrkSlot *slots = (const TrkSlot *)d_slots;
     const int n = w * h;
     dim3 gp(((w + 3) / 4 + 255) / 256, h, batch);
-    if (vec4) hipLaunchKernelGGL(k_trk_pixel4, gp, dim3(256), 0, st, slots, w, h);
-    else hipLaunchKernelGGL(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h);
+    if (vec4) NVCA_LAUNCH(k_trk_pixel4, gp, dim3(256), 0, st, slots, w, h);
+    else NVCA_LAUNCH(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h);
     if (!run_ccl) return;
     dim3 g1((n + 255) / 256, batch), g2((w + 255) / 256, h, batch);
-    hipLaunchKernelGGL(k_ccl_init, g1, dim3(256), 0, st, slots, labels, n);
-    hipLaunchKernelGGL(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h);
-    hipLaunchKernelGGL(k_ccl_flatten, g1, dim3(256), 0, st, labels, (CompAcc *)acc, n);
-    hipLaunchKernelGGL(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h);
-    hipLaunchKernelGGL(k_ccl_collect, g1, dim3(256), 0, st, (const int *)labels, (const CompAcc *)acc, n, out, cap);
+    NVCA_LAUNCH(k_ccl_init, g1, dim3(256), 0, st, slots, labels, n);
+    NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h);
+    NVCA_LAUNCH(k_ccl_flatten, g1, dim3(256), 0, st, labels, (CompAcc *)acc, n);
+    NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h);
+    NVCA_LAUNCH(k_ccl_collect, g1, dim3(256), 0, st, (const int *)labels, (const CompAcc *)acc, n, out, cap);
 }
 
 

@@ -1,6 +1,7 @@
 // nvca_internal.h -- shared declarations of libnubovca_hip (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -154,7 +155,7 @@ struct Workspace;    // api.cpp
 
 struct KernelTimer {
     bool on = false;
-    struct Ev { hipEvent_t a, b; int k; };
+    struct Ev { hipEvent_t a, b; int k; bool first; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
     double total_ms[NVCA_K_COUNT] = {0};
@@ -188,12 +189,20 @@ struct nvca_ctx {
 
 namespace nvca {
 
-// RAII bracket: records events around a kernel class when timing is enabled
+// RAII bracket: while timing is enabled, every kernel launched inside the scope carries a start / stop event pair in
+// its dispatch packet (hipExtLaunchKernelGGL) -- no separate event-record packets on the stream
 struct TimedLaunch {
-    nvca_ctx *ctx; int k; hipEvent_t a = nullptr, b = nullptr;
+    nvca_ctx *ctx; int k; int n = 0; TimedLaunch *prev = nullptr; bool active = false;
     TimedLaunch(nvca_ctx *c, int kind);
     ~TimedLaunch();
 };
+bool launch_events(hipEvent_t *a, hipEvent_t *b);      // event pair for the next launch of the current scope, if any
+#define NVCA_LAUNCH(kern, grid, block, shmem, st, ...)                                                            \
+    do {                                                                                                          \
+        hipEvent_t ea__, eb__;                                                                                    \
+        if (nvca::launch_events(&ea__, &eb__)) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, ea__, eb__, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                       \
+    } while (0)
 
 // --------------------------------------------------------------------------
 // Kernel launch wrappers (kernels_pre.hip / kernels_cascade.hip)

@@ -18,6 +18,11 @@ for _ in range(10): ctx.L.nvca_face_batch_process(ctx.h,n,sh,fa,out,ids,cap,cnt)
 t1=time.perf_counter()
 kt=ctx.kernel_timing(); ksum=sum(v[0] for v in kt.values())/10
 print('raw C call %.3f ms/step; kernels %.3f ms; host+idle %.3f ms' % ((t1-t0)/10*1e3, ksum, (t1-t0)/10*1e3-ksum))
+ctx.enable_kernel_timing(False)
+t0=time.perf_counter()
+for _ in range(10): ctx.L.nvca_face_batch_process(ctx.h,n,sh,fa,out,ids,cap,cnt)
+t1=time.perf_counter()
+print('raw C call, kernel timing off %.3f ms/step' % ((t1-t0)/10*1e3))
 t0=time.perf_counter()
 for _ in range(10): ctx.face_batch_process([fs]*F, frames, cap=64)
 t1=time.perf_counter()
