@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_collect(const int *__restrict__ labels, const CompAcc *__restrict__ acc, int n,
+__global__ __launch_bounds__(256) void k_ccl_collect(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
+                                                     const CompAcc *__restrict__ acc, int n,
                                                      int *__restrict__ out /* [0]=count, then 6 ints per comp */, int cap)
 {
     const int slot = blockIdx.y;
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(256) void k_ccl_collect(const int *__restrict__ lab
     if (i >= n || lab[i] != i) return;
     const CompAcc c = ac[i];
     if (c.seed == 0x7fffffff) return;
+    {   // TRK/gstnubotracker.cpp:171-200: boxes outside the area window are erased and never merged with anything
+        const int area = (c.maxx - c.minx + 1) * (c.maxy - c.miny + 1);
+        if (!(area > slots[slot].min_area && (long long)area < slots[slot].max_area)) return;
+    }
     const int k = atomicAdd(&out[0], 1);
     if (k < cap) {
         int *o = out + 2 + (size_t)k * 6;
@@ -179,7 +184,7 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h);
     NVCA_LAUNCH(k_ccl_flatten, g1, dim3(256), 0, st, labels, (CompAcc *)acc, n);
     NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h);
-    NVCA_LAUNCH(k_ccl_collect, g1, dim3(256), 0, st, (const int *)labels, (const CompAcc *)acc, n, out, cap);
+    NVCA_LAUNCH(k_ccl_collect, g1, dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, n, out, cap);
 }
 
 

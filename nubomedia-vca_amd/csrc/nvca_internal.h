@@ -247,7 +247,8 @@ struct TrkSlot {                // per tracker in the batch
     int threshold;
     int has_prev;               // num_frames > 0
     int sstride;
-    int pad;
+    int min_area;               // __join_objects drops boxes outside (min_area, max_area) before anything else:
+    long long max_area;         // k_ccl_collect does not even report them
 };
 struct CompAcc { int minx, miny, maxx, maxy, seed, pad; };   // per root, stored at the root's pixel index
 // out: [0] = component count, [1] unused, then 6 ints per component: slot, first seed index, x, y, w, h

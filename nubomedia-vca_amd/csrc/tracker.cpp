@@ -4,6 +4,7 @@
 // k_trk_pixel + the connected-component kernels, then __join_objects on the host.
 #include "nvca_internal.h"
 #include "host_logic.h"
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 
@@ -71,6 +72,9 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
         for (int j = 0; j < i; j++) if (trackers[j] == trackers[i]) { ctx->set_error("a tracker may appear once per batch"); return NVCA_ERR_ARG; }
     }
     TrkWorkspace &ws = trk_ws(ctx);
+    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now(), tp1 = tp0, tp2 = tp0;
+    int total_comps = 0;
     std::vector<char> done(n, 0);
     for (int i0 = 0; i0 < n; i0++) {
         if (done[i0]) continue;
@@ -116,12 +120,14 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             s.ts = (float)timestamp; s.delbound = (float)(timestamp - t->p.mhi_duration);    // cvUpdateMotionHistory
             s.seg = (float)t->p.seg_thresh; s.threshold = t->p.threshold;
             s.has_prev = t->num_frames > 0; s.sstride = f.stride;
+            s.min_area = t->p.min_area; s.max_area = (long long)t->p.max_area;
         }
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->stream));
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->stream));
         { TimedLaunch tl(ctx, NVCA_K_TRACKER);
           launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl); }
         NVCA_HIP_CHECK(ctx, hipGetLastError());
+        tp1 = std::chrono::steady_clock::now();
         int *ho = ws.h_out.as<int>();
         int total = 0;
         if (any_ccl) {
@@ -137,6 +143,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             }
         } else
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        tp2 = std::chrono::steady_clock::now(); total_comps += total;
         // seed order (raster order of each component's first seed pixel) = cvSegmentMotion's output order
         std::vector<std::vector<std::pair<int, nvca_rect>>> comps(batch);
         for (int k = 0; k < total; k++) {
@@ -157,6 +164,11 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             }
             t->num_frames++;
         }
+    }
+    if (hostprof) {
+        auto tp3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[nvca host] tracker: enqueue %ld us, wait %ld us, host logic %ld us, %d components\n", us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), total_comps);
     }
     return NVCA_OK;
 }

@@ -436,20 +436,22 @@ class Tracker:
             pass
 
 
+_trk_bufs = {}
+
+
 def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
     n = len(frames)
     th = (C.c_void_p * n)(*[t.h for t in trackers])
     fr = (Frame * n)(*frames)
     ts = (C.c_double * n)(*[float(t) for t in timestamps])
-    out = (Rect * (n * cap))()
-    cnt = (C.c_int * n)()
+    key = (n, cap)
+    if key not in _trk_bufs:                       # result buffers are reused across calls (the library overwrites them)
+        _trk_bufs.clear()
+        _trk_bufs[key] = ((Rect * (n * cap))(), (C.c_int * n)())
+    out, cnt = _trk_bufs[key]
     ctx.check(ctx.L.nvca_tracker_batch_process(ctx.h, n, th, fr, ts, out, cap, cnt))
-    res = []
-    for i in range(n):
-        k = min(cnt[i], cap)
-        res.append(np.array([[out[i * cap + j].x, out[i * cap + j].y, out[i * cap + j].w, out[i * cap + j].h]
-                             for j in range(k)], np.int32).reshape(k, 4))
-    return res
+    boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)
+    return [boxes[i, :min(cnt[i], cap)].copy() for i in range(n)]
 
 
 class PartStream:

@@ -1,8 +1,5 @@
 #!/bin/bash
-for args in "--workload face1080p" "--workload streams720p" "--workload face_tracker" "--workload face1080p --width-to-process 160 --scale-factor-pct 25 --frames-per-step 64"; do
-  echo "== $args"
-  python bench.py --steps 8 --warmup 2 --no-cpu-baseline $args 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print('fps %.0f ms/step %.2f'%(d['value'], d['ms_per_step']), d['config']['workload'][:70], {n:round(v,3) for n,v in d['roofline']['detail_ms_per_launch'].items()})"
+for w in "--workload streams720p" "--workload face_tracker" "--width-to-process 160 --scale-factor-pct 25" "--width-to-process 640 --scale-factor-pct 25" "--workload streams720p --streams-per-gpu 64"; do
+  python bench.py --no-cpu-baseline --steps 10 --warmup 2 $w 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); x=d['roofline']['detail_ms_per_launch']; print('$w', 'fps', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: round(v,3) for k,v in x.items()})" || exit 1
 done
