@@ -92,12 +92,23 @@ __device__ __forceinline__ bool joined(float a, float b, float seg)
     return -seg <= d && d <= seg;
 }
 
-__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int n)
+// Labels start as horizontal runs: within a wave (64 consecutive pixels of a row) every pixel points at the first pixel
+// of its maximal run of joined neighbours, so the row direction needs no atomics except across wave boundaries.
+__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h)
 {
-    const TrkSlot s = slots[blockIdx.y];
-    int *lab = labels + (size_t)blockIdx.y * n;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) lab[i] = s.mhi[i] != 0.f ? i : -1;
+    const TrkSlot s = slots[blockIdx.z];
+    int *lab = labels + (size_t)blockIdx.z * w * h;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    const bool in = x < w;
+    const int i = y * w + x;
+    const float v = in ? s.mhi[i] : 0.f;
+    float l = __shfl_up(v, 1);
+    if (lane == 0) l = (in && x > 0) ? s.mhi[i - 1] : 0.f;
+    const bool link = v != 0.f && l != 0.f && joined(v, l, s.seg);
+    const unsigned long long starts = ~__ballot(link) | 1ull;                   // lanes that begin a run inside this wave
+    const unsigned long long upto = starts & (~0ull >> (63 - lane));            // ... at or left of this lane
+    const int head = 63 - __clzll((long long)upto);
+    if (in) lab[i] = v != 0.f ? i - (lane - head) : -1;
 }
 
 __global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h)
@@ -110,8 +121,18 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ s
     const int i = y * w + x;
     const float v = s.mhi[i];
     if (v == 0.f) return;
-    if (x > 0) { const float l = s.mhi[i - 1]; if (l != 0.f && joined(v, l, s.seg)) uf_union(lab, i, i - 1); }
-    if (y > 0) { const float u = s.mhi[i - w]; if (u != 0.f && joined(v, u, s.seg)) uf_union(lab, i, i - w); }
+    const float l = x > 0 ? s.mhi[i - 1] : 0.f;
+    const bool link_l = l != 0.f && joined(v, l, s.seg);
+    if ((threadIdx.x & 63) == 0 && link_l) uf_union(lab, i, i - 1);             // runs are cut at wave boundaries
+    if (y > 0) {
+        const float u = s.mhi[i - w];
+        if (u != 0.f && joined(v, u, s.seg)) {
+            // redundant when the left neighbour already ties the two rows together: v~l, l~ul, ul~u
+            const float ul = x > 0 ? s.mhi[i - w - 1] : 0.f;
+            const bool tied = link_l && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
+            if (!tied) uf_union(lab, i, i - w);
+        }
+    }
 }
 
 
@@ -180,7 +201,7 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     else NVCA_LAUNCH(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h);
     if (!run_ccl) return;
     dim3 g1((n + 255) / 256, batch), g2((w + 255) / 256, h, batch);
-    NVCA_LAUNCH(k_ccl_init, g1, dim3(256), 0, st, slots, labels, n);
+    NVCA_LAUNCH(k_ccl_init, g2, dim3(256), 0, st, slots, labels, w, h);
     NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h);
     NVCA_LAUNCH(k_ccl_flatten, g1, dim3(256), 0, st, labels, (CompAcc *)acc, n);
     NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h);
