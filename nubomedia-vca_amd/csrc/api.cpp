@@ -100,12 +100,18 @@ struct Workspace {
 };
 
 // one cached geometry: source frame -> working image -> scan tables
+struct PyrLevel { double f; int szw, szh, winw, winh; size_t gray_off; int gpitch; int plane_off; };
 struct GeomPlan {
     ResizeTab tab;
     DevBuf d_xofs, d_yofs, d_ialpha, d_ibeta;
     DetectPlan det;
     PreGeom g;
     bool has_det = false;
+    uint64_t last_use = 0;                                    // plan cache is LRU-bounded (store_plan)
+    // CV_HAAR_SCALE_IMAGE: pyramid levels, their resize tables, plane layout
+    std::vector<PyrLevel> lv;
+    std::vector<std::unique_ptr<GeomPlan>> level_tabs;
+    size_t gray_total = 0, plane_total = 0; int P = 0;
     ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); }
 };
 
@@ -409,7 +415,27 @@ static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, 
 static GeomPlan *find_plan(nvca_ctx *ctx, const std::string &key)
 {
     auto it = ctx->plans.find(key);
-    return it == ctx->plans.end() ? nullptr : it->second.get();
+    if (it == ctx->plans.end()) return nullptr;
+    it->second->last_use = ++ctx->next_uid;
+    return it->second.get();
+}
+
+// Plans are cached per (cascade, geometry).  ROI-driven callers (the part detectors) ask for ever new geometries, so the
+// cache is bounded: beyond kMaxPlans the least recently used plan goes (its device tables are idle: the stream is drained).
+static constexpr size_t kMaxPlans = 96;
+static GeomPlan *store_plan(nvca_ctx *ctx, const std::string &key, std::unique_ptr<GeomPlan> gp)
+{
+    if (ctx->plans.size() >= kMaxPlans) {
+        (void)hipStreamSynchronize(ctx->stream);
+        auto victim = ctx->plans.begin();
+        for (auto it = ctx->plans.begin(); it != ctx->plans.end(); ++it)
+            if (it->second->last_use < victim->second->last_use) victim = it;
+        ctx->plans.erase(victim);
+    }
+    gp->last_use = ++ctx->next_uid;
+    GeomPlan *p = gp.get();
+    ctx->plans[key] = std::move(gp);
+    return p;
 }
 
 // plan for "BGR frame -> working image -> scale-cascade scan"
@@ -432,8 +458,7 @@ static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, 
     rc = gp->det.upload(ctx);
     if (rc) return rc;
     gp->has_det = true;
-    *out = gp.get();
-    ctx->plans[key] = std::move(gp);
+    *out = store_plan(ctx, key, std::move(gp));
     return NVCA_OK;
 }
 
@@ -821,63 +846,74 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
     const Cascade &c = casc->c;
-    struct Level { double f; int szw, szh, winw, winh; size_t gray_off; int gpitch; int plane_off; };
-    std::vector<Level> lv;
-    const int P = (int)round_up(cols + 1, 8);
-    size_t gray_total = 0, plane_total = 0;
-    for (double factor = 1;; factor *= sf) {
-        const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
-        const int szw = cv_round(cols / factor), szh = cv_round(rows / factor);
-        if (szw - c.ow + 1 <= 0 || szh - c.oh + 1 <= 0) break;
-        if (winw > maxw || winh > maxh) break;
-        if (winw < minw || winh < minh) continue;
-        if (szw + 1 <= 1 + c.ow) continue;                   // HaarDetectObjects_ScaleImage_Invoker's early return
-        Level L; L.f = factor; L.szw = szw; L.szh = szh; L.winw = winw; L.winh = winh;
-        L.gpitch = (int)round_up(szw, 64); L.gray_off = gray_total; L.plane_off = (int)plane_total;
-        gray_total += round_up((size_t)L.gpitch * szh, 256);
-        plane_total += round_up((size_t)P * (szh + 1), 64);
-        lv.push_back(L);
-        if (lv.size() > 62) break;
-    }
     out.clear();
-    if (lv.empty()) return NVCA_OK;
-    PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
     int rc;
+    // pyramid layout, resize tables and scan tables depend only on (cascade, image size, parameters): built once
+    char key[256];
+    snprintf(key, sizeof(key), "SI|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, sf, minw, minh, maxw, maxh);
+    GeomPlan *pp = find_plan(ctx, key);
+    if (!pp) {
+        std::unique_ptr<GeomPlan> np(new GeomPlan());
+        np->P = (int)round_up(cols + 1, 8);
+        for (double factor = 1;; factor *= sf) {
+            const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
+            const int szw = cv_round(cols / factor), szh = cv_round(rows / factor);
+            if (szw - c.ow + 1 <= 0 || szh - c.oh + 1 <= 0) break;
+            if (winw > maxw || winh > maxh) break;
+            if (winw < minw || winh < minh) continue;
+            if (szw + 1 <= 1 + c.ow) continue;                   // HaarDetectObjects_ScaleImage_Invoker's early return
+            PyrLevel L; L.f = factor; L.szw = szw; L.szh = szh; L.winw = winw; L.winh = winh;
+            L.gpitch = (int)round_up(szw, 64); L.gray_off = np->gray_total; L.plane_off = (int)np->plane_total;
+            np->gray_total += round_up((size_t)L.gpitch * szh, 256);
+            np->plane_total += round_up((size_t)np->P * (szh + 1), 64);
+            np->lv.push_back(L);
+            if (np->lv.size() > 62) break;
+        }
+        std::vector<ScaleSpec> specs;
+        for (const PyrLevel &L : np->lv) {
+            std::unique_ptr<GeomPlan> gp(new GeomPlan());
+            build_resize_tab(cols, rows, L.szw, L.szh, gp->tab);
+            if ((rc = upload_tab(ctx, *gp))) return rc;
+            np->level_tabs.push_back(std::move(gp));
+            ScaleSpec sp;
+            sp.table_factor = 1.; sp.plane_off = L.plane_off; sp.pitch = np->P; sp.plane_rows = L.szh + 1; sp.adaptive = 0;
+            sp.out_factor = L.f; sp.out_w = L.winw; sp.out_h = L.winh;
+            const int ystep = L.f > 2 ? 1 : 2;
+            for (int x = 0; x < L.szw - c.ow; x += ystep) sp.xs.push_back(x);
+            for (int y = 0; y < L.szh - c.oh; y += ystep) sp.ys.push_back(y);
+            specs.push_back(std::move(sp));
+        }
+        if (!np->lv.empty()) {
+            std::string err;
+            if ((rc = np->det.build_custom(c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
+            if ((rc = np->det.upload(ctx))) return rc;
+        }
+        pp = store_plan(ctx, key, std::move(np));
+    }
+    if (pp->lv.empty()) return NVCA_OK;
+    const int P = pp->P;
+    const size_t gray_total = pp->gray_total, plane_total = pp->plane_total;
+    PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
     if ((rc = ensure_ws(ctx, g0, 1))) return rc;
     if (ws.aux.ensure(gray_total + 64) || ws.sum.ensure(plane_total * sizeof(int)) || ws.sqsum.ensure(plane_total * sizeof(unsigned long long))) {
         ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
     }
     if ((rc = stage_2d(ctx, ws.gray.p, g0.gpitch, gray, stride, cols, rows, mem))) return rc;
-    std::vector<ScaleSpec> specs;
-    std::vector<std::unique_ptr<GeomPlan>> tabs;             // resize tables stay alive until the stream drains
-    for (const Level &L : lv) {
-        std::unique_ptr<GeomPlan> gp(new GeomPlan());
-        build_resize_tab(cols, rows, L.szw, L.szh, gp->tab);
-        if ((rc = upload_tab(ctx, *gp))) return rc;
+    for (size_t li = 0; li < pp->lv.size(); li++) {
+        const PyrLevel &L = pp->lv[li];
+        GeomPlan *gp = pp->level_tabs[li].get();
         uint8_t *lg = ws.aux.as<uint8_t>() + L.gray_off;
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);               // cvResize(img, &img1, CV_INTER_LINEAR)
           launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax, lg, L.szw,
                          L.szh, L.gpitch, nullptr); }
-        tabs.push_back(std::move(gp));
         PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
         run_integral(ctx, g, nullptr, 1, lg, ws.sum.as<int>() + L.plane_off,
                      (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
-        ScaleSpec sp;
-        sp.table_factor = 1.; sp.plane_off = L.plane_off; sp.pitch = P; sp.plane_rows = L.szh + 1; sp.adaptive = 0;
-        sp.out_factor = L.f; sp.out_w = L.winw; sp.out_h = L.winh;
-        const int ystep = L.f > 2 ? 1 : 2;
-        for (int x = 0; x < L.szw - c.ow; x += ystep) sp.xs.push_back(x);
-        for (int y = 0; y < L.szh - c.oh; y += ystep) sp.ys.push_back(y);
-        specs.push_back(std::move(sp));
     }
-    DetectPlan dp;
-    std::string err;
-    if ((rc = dp.build_custom(c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
-    if ((rc = dp.upload(ctx))) return rc;
     std::vector<std::vector<nvca_rect>> raw;
-    rc = run_cascade(ctx, dp, plane_total, P, 1, raw);      // synchronises: tables may be released afterwards
+    rc = run_cascade(ctx, pp->det, plane_total, P, 1, raw);
     if (rc) return rc;
     if (!raw_only) group_all(raw, min_neighbors);
     out.swap(raw[0]);

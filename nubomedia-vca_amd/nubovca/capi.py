@@ -436,7 +436,8 @@ class Tracker:
             pass
 
 
-_trk_bufs = {}
+import threading
+_trk_tls = threading.local()
 
 
 def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
@@ -445,10 +446,9 @@ def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
     fr = (Frame * n)(*frames)
     ts = (C.c_double * n)(*[float(t) for t in timestamps])
     key = (n, cap)
-    if key not in _trk_bufs:                       # result buffers are reused across calls (the library overwrites them)
-        _trk_bufs.clear()
-        _trk_bufs[key] = ((Rect * (n * cap))(), (C.c_int * n)())
-    out, cnt = _trk_bufs[key]
+    if getattr(_trk_tls, "key", None) != key:      # result buffers are reused across calls of a thread (the library overwrites them)
+        _trk_tls.key, _trk_tls.bufs = key, ((Rect * (n * cap))(), (C.c_int * n)())
+    out, cnt = _trk_tls.bufs
     ctx.check(ctx.L.nvca_tracker_batch_process(ctx.h, n, th, fr, ts, out, cap, cnt))
     boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)
     return [boxes[i, :min(cnt[i], cap)].copy() for i in range(n)]
@@ -479,7 +479,7 @@ class PartStream:
         self.ctx.check(self.ctx.L.nvca_part_stream_push_faces(self.h, buf, len(faces)))
 
     def process(self, bgr, cap=64):
-        f = make_frame(np.ascontiguousarray(bgr, np.uint8))
+        f = bgr if isinstance(bgr, Frame) else make_frame(np.ascontiguousarray(bgr, np.uint8))
         a, b = (Rect * cap)(), (Rect * cap)()
         na, nb = C.c_int(), C.c_int()
         self.ctx.check(self.ctx.L.nvca_part_stream_process(self.h, C.byref(f), a, cap, C.byref(na), b, cap, C.byref(nb)))

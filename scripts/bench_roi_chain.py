@@ -1,0 +1,55 @@
+"""BASELINE config 3: 1080p face -> eye + nose + mouth + ear ROI chain on one stream, frames resident in
+HBM; the part detectors run in detect-event mode on the face boxes of the same frame (the reference's
+`nubofacedetector ! nuboeyedetector detect-event=1 ! ...` pipeline).  Prints frames/s and the per-element cost."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nubomedia-vca_amd"))
+import numpy as np, torch
+from nubovca import capi, synth
+
+W, H, N = 1920, 1080, 16
+ctx = capi.Context(0)
+face_c = ctx.load_cascade_xml(synth.synthetic_cascade_xml())
+pc = {n: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+face = capi.FaceStream(ctx, face_c, width_to_process=W, multi_scale_factor=10)
+parts = {"eye": capi.PartStream(ctx, 0, face_c, pc["righteye"], pc["lefteye"], detect_event=1),
+         "nose": capi.PartStream(ctx, 1, face_c, pc["nose"], None, detect_event=1),
+         "mouth": capi.PartStream(ctx, 2, face_c, pc["mouth"], None, detect_event=1),
+         "ear": capi.PartStream(ctx, 3, face_c, pc["leftear"], pc["rightear"], detect_event=1)}
+base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
+frames = [synth.make_bgr(W, H, 40 + i, "natural", [(x + 8 * i, y, s) for x, y, s in base]) for i in range(N)]
+keep = [torch.from_numpy(f).cuda() for f in frames]
+torch.cuda.synchronize()
+fr = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
+acc = {k: 0.0 for k in ["face"] + list(parts)}
+
+
+def step(i, timed):
+    t0 = time.perf_counter()
+    boxes, _ = face.process(fr[i % N]) if False else ctx.face_batch_process([face], [fr[i % N]])[0]
+    t1 = time.perf_counter()
+    if timed:
+        acc["face"] += t1 - t0
+    found = 0
+    for k, p in parts.items():
+        t0 = time.perf_counter()
+        p.push_faces(boxes)
+        a, b = p.process(fr[i % N])
+        found += len(a) + len(b)
+        if timed:
+            acc[k] += time.perf_counter() - t0
+    return len(boxes), found
+
+
+for i in range(4):
+    step(i, False)
+K = 48
+t0 = time.perf_counter()
+tot = [0, 0]
+for i in range(K):
+    nb, nf = step(i, True)
+    tot[0] += nb; tot[1] += nf
+ctx.synchronize()
+dt = time.perf_counter() - t0
+print("roi chain 1080p: %.1f frames/s (%.3f ms/frame); faces/frame %.2f, parts/frame %.2f; per element ms: %s" %
+      (K / dt, dt / K * 1e3, tot[0] / K, tot[1] / K, {k: round(v / K * 1e3, 3) for k, v in acc.items()}))
