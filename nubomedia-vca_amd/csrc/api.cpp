@@ -90,6 +90,7 @@ struct Workspace {
     DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off, grp, gthr;
     PinnedBuf h_hits, h_srcptrs, h_grp, h_gthr;
     std::vector<int> gthr_last;       // thresholds currently resident in gthr
+    int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
@@ -163,7 +164,7 @@ static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
     Workspace &ws = *ctx->ws;
     int e = 0;
     e |= ws.gray.ensure(g.gray_slot * batch + 64);
-    e |= ws.hist.ensure((size_t)batch * 256 * sizeof(unsigned));
+    { void *old = ws.hist.p; e |= ws.hist.ensure((size_t)batch * 256 * sizeof(unsigned)); if (ws.hist.p != old) ws.hist_clean = 0; }
     e |= ws.lut.ensure((size_t)batch * 256);
     e |= ws.bandsum.ensure(g.band_slot * batch * sizeof(unsigned));
     e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
@@ -219,11 +220,28 @@ static constexpr int kGroupOutCap = 64;      // final boxes per frame returned b
 struct CascadeJob {
     int r0 = 0, n = 0, total = 0;
     bool dev_group = false;
+    bool counters_zeroed = false;   // the caller's k_lut launch reset the two list counters (cascade_counters())
     unsigned cap = 0;
     size_t first = 0;         // raw candidates fetched with the count (raw mode)
     unsigned long long *d_hits = nullptr, *h_hits = nullptr;
     int *d_grp = nullptr, *h_grp = nullptr;
 };
+
+// the two list counters a job's kernels append to (so that the caller's k_lut launch can reset them); sizes the lists
+static int cascade_counters(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job, unsigned long long **hits, unsigned long long **deep)
+{
+    Workspace &ws = *ctx->ws;
+    const int total = std::max(job.total, job.r0 + job.n);
+    const size_t hits_stride = (size_t)ctx->hit_cap + 1;
+    const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * job.n + 64, 1u << 28);
+    if (ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
+        ws.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || ws.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
+        ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
+    }
+    *hits = ws.hits.as<unsigned long long>() + hits_stride * job.r0;
+    *deep = ws.deep.as<unsigned long long>();
+    return NVCA_OK;
+}
 
 static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, CascadeJob &job, const int *group_thr, bool want_group)
 {
@@ -241,19 +259,22 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     job.cap = cap;
     job.d_hits = ws.hits.as<unsigned long long>() + hits_stride * job.r0;
     job.h_hits = ws.h_hits.as<unsigned long long>() + hits_stride * job.r0;
-    NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->stream));
-    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (!job.counters_zeroed) {
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
+    }
     static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
     static const bool host_group = getenv("NVCA_HOST_GROUP") != nullptr;         // keep cv::groupRectangles on the host (A/B testing)
     const bool dev_group = group_thr && want_group && dp.device_group_ok && !host_group && !dp.tasks.empty() && !skip_cascade;
     job.dev_group = dev_group;
     const size_t rec = 2 + 4 * kGroupOutCap;
+    const size_t grp_stride = rec + 2;                                       // per result slot: a job's table is followed by the 64-bit raw count
     if (dev_group) {
-        if (ws.grp.ensure((size_t)total * rec * sizeof(int)) || ws.h_grp.ensure((size_t)total * rec * sizeof(int)) ||
+        if (ws.grp.ensure((size_t)total * grp_stride * sizeof(int)) || ws.h_grp.ensure((size_t)total * grp_stride * sizeof(int)) ||
             ws.gthr.ensure((size_t)total * sizeof(int)) || ws.h_gthr.ensure((size_t)total * sizeof(int))) {
             ctx->set_error("device allocation failed for the grouping workspace"); return NVCA_ERR_NOMEM;
         }
-        job.d_grp = ws.grp.as<int>() + rec * job.r0; job.h_grp = ws.h_grp.as<int>() + rec * job.r0;
+        job.d_grp = ws.grp.as<int>() + grp_stride * job.r0; job.h_grp = ws.h_grp.as<int>() + grp_stride * job.r0;
         if (ws.gthr_last.size() < (size_t)total) ws.gthr_last.resize(total, -1);
         if (memcmp(ws.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));             // h_gthr may still feed an earlier copy
@@ -318,8 +339,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, rec * batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, (rec * batch + 2) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     } else {              // one D2H covers the count and (almost always) every candidate
         job.first = std::min<size_t>(cap, 2048);
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, (job.first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -336,6 +356,10 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
     raw.assign(batch, {});
     if (grouped) grouped->assign(batch, 0);
     unsigned long long *hh = job.h_hits;
+    if (job.dev_group) {
+        const int *tail = job.h_grp + (size_t)(2 + 4 * kGroupOutCap) * batch;
+        hh[0] = ((unsigned long long)(unsigned)tail[1] << 32) | (unsigned)tail[0];
+    }
     const unsigned long long total = hh[0];
     if (hostprof) {
         unsigned long long dc = 0;
@@ -787,7 +811,7 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
     { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.hist.as<unsigned>()); }
-    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1); }
+    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1, 1); }   // slot 0 left zeroed again
     launch_apply_lut(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.lut.as<uint8_t>(), ws.aux.as<uint8_t>(), g.gpitch);
     return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
 }
@@ -1224,15 +1248,24 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
                 NVCA_HIP_CHECK(ctx, hipEventRecord(ctx->chunk_events[jobs.size()], ctx->copy_stream));
                 NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->chunk_events[jobs.size()], 0));
             }
-            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)n * 256 * sizeof(unsigned), ctx->stream));
+            int hist_clean = ws.hist_clean;                                // k_lut leaves the histograms it read zeroed again
+            if (hist_clean < n) {
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)n * 256 * sizeof(unsigned), ctx->stream));
+                hist_clean = n;
+            }
+            ws.hist_clean = 0;                                             // dirty until the LUT kernel is queued
+            CascadeJob job; job.r0 = s0; job.n = n; job.total = batch;
+            unsigned long long *z_hits = nullptr, *z_deep = nullptr;
+            if ((rc = cascade_counters(ctx, gp->det, job, &z_hits, &z_deep))) return rc;
             { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
               launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>() + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
                           gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
                           ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), n, frames_aligned4(frames, idx.data() + s0, n)); }
             { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
-              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), n); }
+              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), n, 1, z_hits, z_deep); }
+            job.counters_zeroed = true;
+            ws.hist_clean = hist_clean;
             run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), n);
-            CascadeJob job; job.r0 = s0; job.n = n; job.total = batch;
             if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
             jobs.push_back(job);
         }

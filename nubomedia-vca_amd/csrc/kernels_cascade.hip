@@ -803,6 +803,10 @@ __global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restr
     if (tid == 0) { n_s = 0; ncls_s = 0; fallback_s = 0; }
     __syncthreads();
     unsigned long long total = a.hits[0];
+    if (slot == 0 && tid == 0) {               // the raw candidate count travels with the box table (two words after the last record)
+        int *tail = out + (size_t)gridDim.x * (2 + 4 * out_cap);
+        tail[0] = (int)(unsigned)(total & 0xffffffffull); tail[1] = (int)(unsigned)(total >> 32);
+    }
     if (total > a.hit_cap) total = a.hit_cap;
     for (unsigned long long i = tid; i < total; i += 256) {
         const unsigned long long e = a.hits[1 + i];

@@ -254,12 +254,19 @@ void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
 }
 
 // ---- K2: equalizeHist LUT from the histogram (one block per slot)
-__global__ __launch_bounds__(256) void k_lut(const unsigned *__restrict__ hist, int total, uint8_t *__restrict__ lut)
+// `rezero`: the histogram is cleared again once read (the next frame's gray kernel accumulates into it) and the two
+// list counters of the cascade that follows are reset -- three fill launches less per batch.
+__global__ __launch_bounds__(256) void k_lut(unsigned *__restrict__ hist, int total, uint8_t *__restrict__ lut, int rezero,
+                                             unsigned long long *__restrict__ zero_a, unsigned long long *__restrict__ zero_b)
 {
     __shared__ unsigned wsum[4];
     __shared__ unsigned long long wmask[4];
+    __shared__ unsigned hs[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = blockIdx.x;
     const unsigned h = hist[slot * 256 + tid];
+    hs[tid] = h;
+    if (rezero) hist[slot * 256 + tid] = 0;
+    if (slot == 0 && tid == 0) { if (zero_a) *zero_a = 0; if (zero_b) *zero_b = 0; }
     unsigned incl = h;
     for (int d = 1; d < 64; d <<= 1) { unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
     const unsigned long long m = __ballot(h != 0);
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void k_lut(const unsigned *__restrict__ hist, 
     uint8_t out;
     if (first == 256) out = 0;
     else {
-        const unsigned hf = hist[slot * 256 + first];
+        const unsigned hf = hs[first];
         if (hf == (unsigned)total) out = (uint8_t)first;         // dst.setTo(i)
         else if (tid <= first) out = 0;
         else {
@@ -285,9 +292,10 @@ __global__ __launch_bounds__(256) void k_lut(const unsigned *__restrict__ hist, 
     lut[slot * 256 + tid] = out;
 }
 
-void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch)
+void launch_lut(hipStream_t st, unsigned *hist, int total, uint8_t *lut, int batch, int rezero, unsigned long long *zero_a,
+                unsigned long long *zero_b)
 {
-    NVCA_LAUNCH(k_lut, dim3(batch), dim3(256), 0, st, hist, total, lut);
+    NVCA_LAUNCH(k_lut, dim3(batch), dim3(256), 0, st, hist, total, lut, rezero, zero_a, zero_b);
 }
 
 __global__ __launch_bounds__(256) void k_hist(const uint8_t *__restrict__ gray, int w, int h, int pitch,

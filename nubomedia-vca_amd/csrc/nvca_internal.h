@@ -227,7 +227,8 @@ void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
                     int xmax, uint8_t *dst, int dw, int dh, int dstride);
 void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch);
 void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist);
-void launch_lut(hipStream_t st, const unsigned *hist, int total, uint8_t *lut, int batch);
+void launch_lut(hipStream_t st, unsigned *hist, int total, uint8_t *lut, int batch, int rezero = 0,
+                unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr);
 void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spitch, const uint8_t *lut,
                       uint8_t *dst, int dpitch);
 void launch_colsum(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
