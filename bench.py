@@ -150,18 +150,20 @@ def main():
         torch.cuda.synchronize()
     tick = [0]
     from nubovca import sharding
+    gather = sharding.TableGather(device=dev) if world > 1 else None
 
     def step():
         tick[0] += 1
         res = ctx.face_batch_process(streams, frames_t[tick[0] % TICKS], cap=MAX_BOXES)
         if trackers is not None:
             capi.tracker_batch_process(ctx, trackers, bgra_frames[tick[0] % TICKS], [33.3 * tick[0]] * F, cap=256)
-        if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL
-            sharding.gather_tables(sharding.pack_boxes(res, MAX_BOXES), device=dev)
+        if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL;
+            gather.submit(sharding.pack_boxes(res, MAX_BOXES))      # asynchronous: it overlaps the next tick's kernels
         return res
 
     def fence():
         if world > 1:
+            gather.finish()
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()

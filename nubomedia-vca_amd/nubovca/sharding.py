@@ -39,6 +39,44 @@ def gather_tables(local_tab, device=None):
     return out.cpu().numpy().reshape((world,) + tuple(t.shape))
 
 
+class TableGather:
+    """Per-tick result gather that stays off the critical path: the all_gather of tick k is started asynchronously and
+    only waited for when tick k+1 hands in its table (or at `finish`), so the collective overlaps the next tick's
+    kernels.  `last()` returns the most recently completed [world, n_local, cols] table."""
+
+    def __init__(self, device=None):
+        self.device, self.pending, self.done = device, None, None
+
+    def submit(self, local_tab):
+        self._complete()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        t = torch.from_numpy(np.ascontiguousarray(local_tab))
+        if self.device is not None:
+            t = t.to(self.device)
+        if world == 1:
+            self.done = (t, (1,) + tuple(t.shape))
+            return
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        work = dist.all_gather_into_tensor(out, t, async_op=True)
+        self.pending = (work, out, t, (world,) + tuple(t.shape))
+
+    def _complete(self):
+        if self.pending is not None:
+            work, out, _t, shape = self.pending
+            work.wait()
+            self.done, self.pending = (out, shape), None
+
+    def finish(self):
+        self._complete()
+
+    def last(self):
+        self._complete()
+        if self.done is None:
+            return None
+        out, shape = self.done
+        return out.cpu().numpy().reshape(shape)
+
+
 def merge_by_stream(gathered, n_streams, world):
     """gathered[r][j] belongs to stream streams_of_rank(...)[j]; returns per-stream list of boxes"""
     res = [None] * n_streams

@@ -37,10 +37,16 @@ def _worker(rank, world, port, xml, q):
     mine = sharding.streams_of_rank(N_STREAMS, world, rank)
     res = _run_streams(mine, xml)
     merged = []
+    tg = sharding.TableGather()            # the asynchronous gather bench.py uses: tick k completes when tick k+1 is handed in
     for i in range(N_FRAMES):
         tab = sharding.pack_boxes([res[s][i] for s in mine], MAXB)
         g = sharding.gather_tables(tab)
         merged.append(sharding.merge_by_stream(g, N_STREAMS, world))
+        tg.submit(tab)
+        if i > 0:
+            assert tg.done is not None       # the previous tick's table is complete by now
+        assert (tg.last() == g).all()
+    tg.finish()
     dist.barrier()
     if rank == 0:
         q.put([[b.tolist() for b in tick] for tick in merged])
