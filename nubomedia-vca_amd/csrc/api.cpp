@@ -118,7 +118,7 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_list_off.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -137,6 +137,7 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_tcoords, tcoords.data(), tcoords.size() * sizeof(unsigned short)},
         {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
+        {&d_deeprecs, deeprecs.data(), deeprecs.size() * sizeof(DeepRec)},
     };
     for (auto &it : items) {
         if (it.n == 0) continue;
@@ -302,6 +303,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.list_from = 0;
         a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
+        a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the GPU several times
         // over; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
         const char *band_e = getenv("NVCA_BAND");

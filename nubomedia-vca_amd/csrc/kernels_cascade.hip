@@ -715,9 +715,13 @@ __device__ __forceinline__ double wave_sum_exact(double v)
 
 __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
 {
-    // one workgroup per surviving window: every late stage (33..213 stumps) is one step, stump per thread
+    // one workgroup per surviving window: every late stage (33..213 stumps) is one step, stump per thread.  The first late
+    // stage reads the sum plane directly; a window that passes it gets the ncol x nrow samples all later stumps can touch
+    // staged in LDS (DeepRec), and the remaining ~1900 stumps x 8-12 corners become LDS reads.
     __shared__ double part[2][4];
     __shared__ double votes[256];
+    __shared__ int T[kDeepMaxSide * (kDeepMaxSide + 1)];
+    __shared__ unsigned short cmap[kDeepMaxSpan], rmap[kDeepMaxSpan];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long cnt = a.deep[0];
     if (cnt > a.deep_cap) {                              // list overflowed: poison the hit count (host reports it)
@@ -735,17 +739,36 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
         const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
         const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
         const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
-        bool alive = true;
+        DeepRec d; d.ncol = 0;
+        if (a.deeprecs) d = a.deeprecs[s];
+        CTStumpRec *trecs = (CTStumpRec *)(a.tstumps + d.stump_off);
+        bool alive = true, patch = false;
         for (int st_i = a.deep_stage; st_i < a.nstages; st_i++) {
             const StageRec st = a.stages[st_i];
             const bool pair = a.pair_policy && (st.flags & 1);
             double stage_sum = 0.0;
+            if (st_i == a.deep_stage + 1 && d.ncol > 0) {           // passed the first late stage: stage the patch
+                const unsigned short *__restrict__ cl = a.tcoords + d.col_off, *__restrict__ rl = a.tcoords + d.row_off;
+                const int pitchP = d.ncol | 1;
+                __syncthreads();                                  // previous window's patch reads are over
+                for (int c = tid; c < d.ncol; c += 256) cmap[cl[c]] = (unsigned short)c;
+                for (int r = tid; r < d.nrow; r += 256) rmap[rl[r]] = (unsigned short)(r * pitchP);
+                for (int q = tid; q < d.ncol * d.nrow; q += 256) {
+                    const int r = q / d.ncol, c = q - r * d.ncol;
+                    T[r * pitchP + c] = sum[off + (unsigned)rl[r] * (unsigned)sc.pitch + cl[c]];
+                }
+                __syncthreads();
+                patch = true;
+            }
+            auto vote = [&](int j) {
+                if (patch) return pair ? tile_vote<true, false>(T, cmap, rmap, 0, 0, vnf, trecs[st.first + j])
+                                       : tile_vote<false, false>(T, cmap, rmap, 0, 0, vnf, trecs[st.first + j]);
+                const StumpRec &f = recs[st.first + j];
+                return pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
+            };
             if (st.flags & 2) {                         // any summation order is exact
                 double p = 0.0;
-                for (int j = tid; j < st.count; j += 256) {
-                    const StumpRec &f = recs[st.first + j];
-                    p += pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
-                }
+                for (int j = tid; j < st.count; j += 256) p += vote(j);
                 p = wave_sum_exact(p);
                 if (lane == 0) part[flip][wave] = p;
                 __syncthreads();
@@ -754,13 +777,9 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
             } else {                                    // keep OpenCV's left-to-right order
                 for (int c = 0; c < st.count; c += 256) {
                     const int j = c + tid;
-                    double vote = 0.0;
-                    if (j < st.count) {
-                        const StumpRec &f = recs[st.first + j];
-                        vote = pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
-                    }
+                    const double v = j < st.count ? vote(j) : 0.0;
                     __syncthreads();
-                    votes[tid] = vote;
+                    votes[tid] = v;
                     __syncthreads();
                     const int m = st.count - c < 256 ? st.count - c : 256;
                     for (int l = 0; l < m; l++) stage_sum += votes[l];      // every thread walks the same order

@@ -93,6 +93,11 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
 };
 // A band is one row of tiles (<= 32 window rows of one scale, the full scan width): k_band walks it left to right in one
 // workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
+// Per scale: the distinct corner columns / rows (window-relative pixels) of the late stages' stumps.  k_deep stages that
+// ncol x nrow patch of a surviving window in LDS after the first late stage (ncol == 0: scale not eligible, global gathers).
+struct DeepRec { int col_off, ncol, row_off, nrow, span_x, span_y, stump_off, pad; };
+static constexpr int kDeepMaxSide = 64;            // patch side (distinct columns / rows)
+static constexpr int kDeepMaxSpan = 1280;          // largest corner offset + 1 the patch maps cover
 struct BandRec { int scale, iy0, ny, first_tile, ntiles, pad0, pad1, pad2; };
 static constexpr int kTileWin = 32;                 // windows per tile side (window id = ry * 32 + rx)
 static constexpr int kTileThreads = 1024;
@@ -266,6 +271,7 @@ struct CascadeArgs {
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
     const TStumpRec *tstumps; const unsigned short *tcoords; int tile_lds; int exp;
     const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch;   // k_band
+    const DeepRec *deeprecs;                  // [nscales] or null (k_deep: LDS patches)
     // global survivor lists (k_list_*): per-scale segments; counts per stage
     unsigned *list_cnt;            // [nstages][64]
     unsigned *list_ent;            // [2][list_cap]

@@ -328,6 +328,32 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     blocks_per_frame = build_xcd_order(strip_w, order);
     tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
     if (!strips.empty()) bands.clear();          // the band kernel has no strip counterpart: all scales tiled, or none
+    // late stages: per scale the distinct corner columns / rows of their stumps (k_deep's LDS patch of one window)
+    deeprecs.clear();
+    if (strips.empty() && !tiles.empty() && deep_stage < (int)stages.size() && getenv("NVCA_DEEP_LDS_OFF") == nullptr) {
+        deeprecs.resize(scales.size());
+        std::vector<int> scale_toff(scales.size(), -1);
+        for (const TileRec &t : tiles) scale_toff[t.scale] = t.stump_off;
+        const int k0 = stages[deep_stage].first, k1 = stages.back().first + stages.back().count;
+        for (size_t s = 0; s < scales.size(); s++) {
+            DeepRec d; memset(&d, 0, sizeof(d));
+            if (scale_toff[s] >= 0) {
+                const TStumpRec *tr = &tstumps[scale_toff[s]];
+                std::vector<int> ox, oy;
+                for (int k = k0; k < k1; k++)
+                    for (int q = 0; q < (tr[k].nrect & 255); q++) { ox.push_back(tr[k].x0[q]); ox.push_back(tr[k].x1[q]); oy.push_back(tr[k].y0[q]); oy.push_back(tr[k].y1[q]); }
+                std::sort(ox.begin(), ox.end()); ox.erase(std::unique(ox.begin(), ox.end()), ox.end());
+                std::sort(oy.begin(), oy.end()); oy.erase(std::unique(oy.begin(), oy.end()), oy.end());
+                if (!ox.empty() && (int)ox.size() <= kDeepMaxSide && (int)oy.size() <= kDeepMaxSide && ox.back() < kDeepMaxSpan && oy.back() < kDeepMaxSpan) {
+                    d.col_off = (int)tcoords.size(); for (int v : ox) tcoords.push_back((unsigned short)v);
+                    d.row_off = (int)tcoords.size(); for (int v : oy) tcoords.push_back((unsigned short)v);
+                    d.ncol = (int)ox.size(); d.nrow = (int)oy.size(); d.span_x = ox.back() + 1; d.span_y = oy.back() + 1;
+                    d.stump_off = scale_toff[s];
+                }
+            }
+            deeprecs[s] = d;
+        }
+    }
     {   // bands: longest first (a band is a serial walk over its tiles; the short ones fill the tail)
         band_order.resize(bands.size());
         for (size_t i = 0; i < bands.size(); i++) band_order[i] = (int)i;

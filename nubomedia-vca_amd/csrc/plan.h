@@ -38,6 +38,7 @@ struct DetectPlan {
     std::vector<TStumpRec> tstumps;
     std::vector<unsigned short> tcoords;
     int tile_lds = 0;            // dynamic LDS bytes of the largest tile
+    std::vector<DeepRec> deeprecs;  // per scale (k_deep LDS patches); empty: not used
     std::vector<BandRec> bands;  // rows of tiles (k_band); usable when every scale is tiled
     std::vector<int> band_order; int band_blocks_per_frame = 0;
     std::vector<unsigned> list_off;   // per-scale offsets (windows per frame) into the survivor lists
@@ -48,7 +49,7 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_bands, d_band_order, d_list_off;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off;
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
