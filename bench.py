@@ -212,6 +212,17 @@ def main():
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        lds = None
+        if dom and os.path.exists(tpath):
+            try:        # the dominant kernel works out of LDS: also price it against the LDS peak
+                lb = json.load(open(tpath)).get(dom, {}).get("lds_bytes_per_launch")
+                if lb:
+                    peak = 128.0 * 256 * 2.4                     # B/clk/CU x CUs x GHz = GB/s
+                    ach = lb / (kern[dom]["ms_per_launch"] * 1e-3) / 1e9
+                    lds = {"achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                           "source": "LDS wave instructions per launch from profiles/ (PMC) x 64 lanes x 3 B mean access, / live kernel time"}
+            except Exception:
+                lds = None
         roofline = None
         if dom:
             a = kern[dom]["achieved_GBs"]
@@ -219,7 +230,7 @@ def main():
                         "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                         "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
                         "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
-                        "kernels": kern,
+                        "kernels": kern, "lds": lds,
                         "detail_ms_per_launch": {k: v[0] / v[1] for k, v in ktimes.items() if v[1]}}
         out = {
             "metric": "1080p frames/sec/node (NuboFaceDetector); achieved HBM GB/s vs peak",
