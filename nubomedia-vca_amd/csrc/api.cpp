@@ -865,14 +865,16 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
 // cvHaarDetectObjectsForROC, CV_HAAR_SCALE_IMAGE branch (EYE/kmseyedetect.cpp:991-993, NOSE/kmsnosedetect.cpp:843-846,
 // MOUTH/kmsmouthdetect.cpp:845-848, EAR/kmseardetect.cpp:656-659): per factor the image is resized, integrated and
 // scanned with the unscaled window on a fixed grid.  All pyramid levels are evaluated by one launch set.
-static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int cols, int rows, int stride,
+// `nimg` images of one geometry (the ear detector scans an image and its mirror, EAR/kmseardetect.cpp:796-803) share
+// every launch: pyramid levels, integrals and the scan run with the images as batch slots.
+static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const void *const *grays, int nimg, int cols, int rows, int stride,
                               int mem, double sf, int min_neighbors, int minw, int minh, int maxw, int maxh, bool raw_only,
-                              std::vector<nvca_rect> &out)
+                              std::vector<nvca_rect> *outs)
 {
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
     const Cascade &c = casc->c;
-    out.clear();
+    for (int k = 0; k < nimg; k++) outs[k].clear();
     int rc;
     // pyramid layout, resize tables and scan tables depend only on (cascade, image size, parameters): built once
     char key[256];
@@ -920,11 +922,12 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
     const int P = pp->P;
     const size_t gray_total = pp->gray_total, plane_total = pp->plane_total;
     PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
-    if ((rc = ensure_ws(ctx, g0, 1))) return rc;
-    if (ws.aux.ensure(gray_total + 64) || ws.sum.ensure(plane_total * sizeof(int)) || ws.sqsum.ensure(plane_total * sizeof(unsigned long long))) {
+    if ((rc = ensure_ws(ctx, g0, nimg))) return rc;
+    if (ws.aux.ensure(gray_total * nimg + 64) || ws.sum.ensure(plane_total * nimg * sizeof(int)) || ws.sqsum.ensure(plane_total * nimg * sizeof(unsigned long long))) {
         ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
     }
-    if ((rc = stage_2d(ctx, ws.gray.p, g0.gpitch, gray, stride, cols, rows, mem))) return rc;
+    for (int k = 0; k < nimg; k++)
+        if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, grays[k], stride, cols, rows, mem))) return rc;
     for (size_t li = 0; li < pp->lv.size(); li++) {
         const PyrLevel &L = pp->lv[li];
         GeomPlan *gp = pp->level_tabs[li].get();
@@ -932,19 +935,30 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);               // cvResize(img, &img1, CV_INTER_LINEAR)
           launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax, lg, L.szw,
-                         L.szh, L.gpitch, nullptr); }
+                         L.szh, L.gpitch, nullptr, nimg, g0.gray_slot, gray_total); }
         PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
-        run_integral(ctx, g, nullptr, 1, lg, ws.sum.as<int>() + L.plane_off,
+        run_integral(ctx, g, nullptr, nimg, lg, ws.sum.as<int>() + L.plane_off,
                      (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
     }
     std::vector<std::vector<nvca_rect>> raw;
-    rc = run_cascade(ctx, pp->det, plane_total, P, 1, raw);
+    rc = run_cascade(ctx, pp->det, plane_total, P, nimg, raw);
     if (rc) return rc;
     if (!raw_only) group_all(raw, min_neighbors);
-    out.swap(raw[0]);
+    for (int k = 0; k < nimg; k++) outs[k].swap(raw[k]);
     return NVCA_OK;
 }
+
+} // extern "C"
+int nvca::detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
+                                  int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!casc || !(sf > 1.0) || check_img(ctx, img_a, w, h, stride, 1, mem) || check_img(ctx, img_b, w, h, stride, 1, mem)) return NVCA_ERR_ARG;
+    const void *imgs[2] = {img_a, img_b};
+    return detect_scale_image(ctx, casc, imgs, 2, w, h, stride, mem, sf, min_neighbors, minw, minh, w, h, false, outs);
+}
+extern "C" {
 
 // cvHaarDetectObjectsForROC with CV_HAAR_FIND_BIGGEST_OBJECT (NOSE/kmsnosedetect.cpp:870-873, MOUTH/kmsmouthdetect.cpp:870-873,
 // EAR/kmseardetect.cpp:712-715): scale-cascade scan from the largest factor down; after the first grouped detection
@@ -1040,7 +1054,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
         return detect_find_biggest(ctx, casc, gray, w, h, stride, mem, sf, min_neighbors, flags, minw, minh, maxw, maxh, out);
     }
     if (flags & NVCA_HAAR_SCALE_IMAGE)
-        return detect_scale_image(ctx, casc, gray, w, h, stride, mem, sf, min_neighbors, minw, minh, maxw, maxh, raw_only, out);
+        { const void *one[1] = {gray}; return detect_scale_image(ctx, casc, one, 1, w, h, stride, mem, sf, min_neighbors, minw, minh, maxw, maxh, raw_only, &out); }
     (void)hipSetDevice(ctx->device);
     GeomPlan *gp = nullptr;
     if ((rc = get_face_plan(ctx, casc, w, h, stride, 1, w, h, sf, minw, minh, maxw, maxh, &gp))) return rc;

@@ -161,12 +161,14 @@ __global__ __launch_bounds__(256) void k_resize1(
     const uint8_t *__restrict__ src, int sw, int sh, int sstride, int mode,
     const int *__restrict__ xofs, const short *__restrict__ ialpha,
     const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax,
-    uint8_t *__restrict__ dst, int dw, int dh, int dstride, unsigned *__restrict__ hist)
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride, unsigned *__restrict__ hist, size_t src_slot, size_t dst_slot)
 {
     __shared__ unsigned lh[4][256];
     const int tid = threadIdx.x, wave = tid >> 6;
     for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
     __syncthreads();
+    src += (size_t)blockIdx.z * src_slot; dst += (size_t)blockIdx.z * dst_slot;      // several images of one geometry
+    if (hist) hist += (size_t)blockIdx.z * 256;
     const int x = blockIdx.x * 256 + tid;
     for (int ry = 0; ry < kGrayRows; ry++) {
         const int y = blockIdx.y * kGrayRows + ry;
@@ -246,11 +248,11 @@ void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
 
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
-                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist)
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist, int batch, size_t src_slot, size_t dst_slot)
 {
-    dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, 1);
+    dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, batch);
     NVCA_LAUNCH(k_resize1, grid, dim3(256), 0, st, src, sw, sh, sstride, mode, d_xofs, d_ialpha, d_yofs,
-                       d_ibeta, xmax, dst, dw, dh, dstride, hist);
+                       d_ibeta, xmax, dst, dw, dh, dstride, hist, src_slot, dst_slot);
 }
 
 // ---- K2: equalizeHist LUT from the histogram (one block per slot)

@@ -226,7 +226,7 @@ void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, 
                  uint8_t *gray, unsigned *hist, int batch, bool aligned4);
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
-                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist);
+                    int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist, int batch = 1, size_t src_slot = 0, size_t dst_slot = 0);
 void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride);
@@ -290,6 +290,9 @@ struct CascadeArgs {
 };
 // which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage, 5 = k_band
 void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
+// detectMultiScale(CV_HAAR_SCALE_IMAGE) on two images of one geometry with shared launches (api.cpp; used by parts.cpp)
+int detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
+                            int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs /* [2] */);
 // groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
 void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch);
 

@@ -121,14 +121,14 @@ void to_global(RectV &v, const nvca_rect &face, int scale)
 }
 
 // kms_ear_detect_find_ears EAR/kmseardetect.cpp:644-729
-int find_ears(nvca_part_stream *s, const uint8_t *face_img, int fcols, int frows, const uint8_t *ear_img, int ecols, int erows,
+// `profile_faces`: the profile-face pass on this side's image (the image itself / its mirror), :656-659 -- both sides'
+// passes are run together by the caller (nvca::detect_scale_image_pair)
+int find_ears(nvca_part_stream *s, const std::vector<nvca_rect> &profile_faces, int fcols, int frows, const uint8_t *ear_img, int ecols, int erows,
               const nvca_cascade *ear_cascade, double scale_f2e, double scale_e2o, int side)
 {
-    nvca_rect buf[256]; int nf = 0;
-    int rc = nvca_detect_multiscale(s->ctx, s->face, face_img, fcols, frows, fcols, NVCA_MEM_DEVICE, 1 + s->p.scale_factor_pct * 1.0 / 100,
-                                    2, NVCA_HAAR_SCALE_IMAGE, 3, 3, 0, 0, buf, 256, &nf);
-    if (rc) return rc;
-    s->faces.assign(buf, buf + std::min(nf, 256));
+    int rc;
+    (void)frows;
+    s->faces.assign(profile_faces.begin(), profile_faces.begin() + std::min<size_t>(profile_faces.size(), 256));
     if (s->faces.empty()) return NVCA_OK;
     RectV &ears = side == 0 ? s->la : s->lb;
     if (!ears.empty()) ears.clear();
@@ -265,9 +265,12 @@ int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect
                 CK(nvca_equalize_hist(ctx, small, fw, fh, fw, D, small, fw));
                 CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, part, pw, ph, pw));
                 CK(nvca_equalize_hist(ctx, part, pw, ph, pw, D, part, pw));
-                CK(find_ears(s, small, fw, fh, part, pw, ph, s->a, scale_f2x, scale_x2o, 0));
                 CK(nvca_flip_horizontal(ctx, small, fw, fh, fw, D, s->d_flip.p, fw));                    // EAR :800
-                CK(find_ears(s, s->d_flip.as<uint8_t>(), fw, fh, part, pw, ph, s->b, scale_f2x, scale_x2o, 1));
+                std::vector<nvca_rect> pf[2];                // profile faces in the image and in its mirror: one launch set
+                CK(nvca::detect_scale_image_pair(ctx, s->face, small, s->d_flip.as<uint8_t>(), fw, fh, fw, D,
+                                                 1 + s->p.scale_factor_pct * 1.0 / 100, 2, 3, 3, pf));
+                CK(find_ears(s, pf[0], fw, fh, part, pw, ph, s->a, scale_f2x, scale_x2o, 0));
+                CK(find_ears(s, pf[1], fw, fh, part, pw, ph, s->b, scale_f2x, scale_x2o, 1));
             } else {
                 if (0 == s->p.detect_event) {
                     CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, small, fw, fh, fw));
