@@ -397,10 +397,12 @@ template <bool PAIR, bool UNI = true>
 __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *cmap, const unsigned short *rmap,
                                             int xw, int yw, double vnf, CTStumpRec &f)
 {
+    // the row map holds WORD offsets of the row starts from T, the column map BYTE offsets: a corner address is one shift-add
+    auto at = [&](int rw, int cb) { return *(const int *)((const char *)T + ((rw << 2) + cb)); };
     auto rs = [&](int q) {
         const int c0 = cmap[xw + f.x0[q]], c1 = cmap[xw + f.x1[q]];
         const int r0 = rmap[yw + f.y0[q]], r1 = rmap[yw + f.y1[q]];
-        return T[r0 + c0] - T[r0 + c1] - T[r1 + c0] + T[r1 + c1];
+        return at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
     };
     const int s0 = rs(0);
     const int s1 = rs(1);
@@ -454,7 +456,7 @@ __device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t
     if (tid < 3) L.qn[tid] = 0;
     if (tid < t.nx) L.winx[tid] = (unsigned short)(xpos[tid] - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
-    for (int c = tid; c < t.ncol; c += kTileThreads) L.cmap[cl[c] - t.x0] = (unsigned short)c;
+    for (int c = tid; c < t.ncol; c += kTileThreads) L.cmap[cl[c] - t.x0] = (unsigned short)(c * 4);
     for (int r = tid; r < t.nrow; r += kTileThreads) L.rmap[rl[r] - t.y0] = (unsigned short)(r * L.pitchT);
     // a wave per sample row (two rows in flight), lanes across the compacted columns
     const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
@@ -651,7 +653,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             if (active) {
                 const int xw = L.winx[rx], yw = L.winy[ry];
                 const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
-                const int ws = L.T[r0 + c0] - L.T[r0 + c1] - L.T[r1 + c0] + L.T[r1 + c1];
+                auto at = [&](int rw, int cb) { return *(const int *)((const char *)L.T + ((rw << 2) + cb)); };
+                const int ws = at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
                 const double mean = (double)ws * sc.inv_area;
                 const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
                 const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
                 const unsigned short *__restrict__ cl = a.tcoords + d.col_off, *__restrict__ rl = a.tcoords + d.row_off;
                 const int pitchP = d.ncol | 1;
                 __syncthreads();                                  // previous window's patch reads are over
-                for (int c = tid; c < d.ncol; c += 256) cmap[cl[c]] = (unsigned short)c;
+                for (int c = tid; c < d.ncol; c += 256) cmap[cl[c]] = (unsigned short)(c * 4);
                 for (int r = tid; r < d.nrow; r += 256) rmap[rl[r]] = (unsigned short)(r * pitchP);
                 for (int q = tid; q < d.ncol * d.nrow; q += 256) {
                     const int r = q / d.ncol, c = q - r * d.ncol;
