@@ -178,6 +178,38 @@ def test_device_grouping_sweep(ctx, casc_small, orc_small, w, h, kind, seed):
         assert np.array_equal(det, edet), (mn, nraw, len(det), len(edet))
 
 
+def test_detect_random_geometries(ctx, casc, casc_small, orc_cascade, orc_small):
+    """seeded sweep over odd image sizes, scale factors and size limits: tile / band planning (edge tiles, rows shorter
+    than a tile, scales with a handful of windows) must never change a candidate; both batch-1 and forced-band paths"""
+    import os
+    import orc
+    from nubovca import synth
+    rng = np.random.RandomState(20240611)
+    kinds = ["natural", "noise", "gradient"]
+    checked = 0
+    for it in range(28):
+        w, h = int(rng.randint(41, 700)), int(rng.randint(41, 500))
+        sf = float(rng.choice([1.1, 1.15, 1.2, 1.25, 1.3, 1.5]))
+        ms = (int(rng.randint(0, max(1, w // 6))), int(rng.randint(0, max(1, h // 6)))) if it % 3 else (0, 0)
+        mx = (0, 0) if it % 4 else (int(rng.randint(w // 3, w + 1)), int(rng.randint(h // 3, h + 1)))
+        s = int(min(w, h) * rng.uniform(0.3, 0.8))
+        faces = [(int(rng.randint(0, max(1, w - s))), int(rng.randint(0, max(1, h - s))), s)] if s >= 24 else []
+        g = orc.equalize_hist(synth.make_gray(w, h, 1000 + it, kinds[it % 3], faces))
+        c, oc = (casc_small, orc_small) if it % 5 == 0 else (casc, orc_cascade)
+        eraw = orc.detect_raw(oc, g, sf, 0, ms, mx)
+        for band in ("0", "1"):
+            os.environ["NVCA_BAND"] = band
+            try:
+                raw = ctx.detect_raw(c, g, sf, 0, ms, mx)
+            finally:
+                del os.environ["NVCA_BAND"]
+            assert np.array_equal(raw, eraw), (it, band, w, h, sf, ms, mx, len(raw), len(eraw))
+        det = ctx.detect_multiscale(c, g, sf, 2, 0, ms, mx)
+        assert np.array_equal(det, orc.detect_multiscale(oc, g, sf, 2, 0, ms, mx)), (it, w, h)
+        checked += len(eraw)
+    assert checked > 100
+
+
 def test_detect_f64_policy(ctx, casc, orc_cascade):
     import orc
     from nubovca import capi, synth
@@ -302,6 +334,29 @@ def test_face_batch_chunked_ingest(ctx, casc, orc_cascade):
             eb, eid = streams[i]._o.process(frames[i])
             assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (rep, i)
     assert sum(len(r[0]) for r in res) >= 10
+
+
+def test_face_batch_mixed_geometries(ctx, casc, orc_cascade):
+    """one batched call with streams of different frame sizes / properties: one launch set per distinct geometry,
+    results per stream as if each ran alone; three ticks so gating and tracking state take part"""
+    import orc
+    from nubovca import capi, synth
+    specs = [(640, 480, {}), (480, 360, {"width_to_process": 240}), (640, 480, {"process_x_every_4_frames": 2}),
+             (800, 450, {"width_to_process": 400, "multi_scale_factor": 15}), (480, 360, {"width_to_process": 240}),
+             (640, 480, {}), (322, 242, {"width_to_process": 161}), (800, 450, {"width_to_process": 400, "multi_scale_factor": 15})]
+    kw = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4", "multi_scale_factor": "scale_factor_pct"}
+    streams = [capi.FaceStream(ctx, casc, **p) for _, _, p in specs]
+    oracles = [orc.FaceStream(orc_cascade, **{kw[k]: v for k, v in p.items()}) for _, _, p in specs]
+    seen = 0
+    for tick in range(5):
+        frames = [synth.make_bgr(W, H, 5000 + 37 * i + tick, "natural", [(W // 6 + 7 * tick, H // 7, H // 2)] if (i + tick) % 4 else [])
+                  for i, (W, H, _) in enumerate(specs)]
+        res = ctx.face_batch_process(streams, [capi.make_frame(f) for f in frames])
+        for i in range(len(specs)):
+            eb, eid = oracles[i].process(frames[i])
+            assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (tick, i)
+            seen += len(eb)
+    assert seen > 8
 
 
 def test_face_batch_registered_host_frames(ctx, casc, orc_cascade):
