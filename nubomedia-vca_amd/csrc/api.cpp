@@ -433,6 +433,17 @@ static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, 
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                          ctx->stream));
+    if (mem == NVCA_MEM_DEVICE && ctx->defer_device_sync > 0) return NVCA_OK;   // consumer is queued on the same stream
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timer(ctx);
+    return NVCA_OK;
+}
+
+// end of a primitive that wrote device memory directly
+static int finish_device_op(nvca_ctx *ctx)
+{
+    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->defer_device_sync > 0) return NVCA_OK;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     drain_timer(ctx);
     return NVCA_OK;
@@ -762,6 +773,20 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     return unstage_2d(ctx, dst, dst_stride, ctx->ws->gray.p, g.gpitch, w, h, mem);
 }
 
+// resize coefficient tables for (source size -> destination size), cached with the other plans
+static int get_resize_plan(nvca_ctx *ctx, int sw, int sh, int dw, int dh, GeomPlan **out)
+{
+    char key[96];
+    snprintf(key, sizeof(key), "RZ|%d|%d|%d|%d", sw, sh, dw, dh);
+    if (GeomPlan *gp = find_plan(ctx, key)) { *out = gp; return NVCA_OK; }
+    std::unique_ptr<GeomPlan> gp(new GeomPlan());
+    build_resize_tab(sw, sh, dw, dh, gp->tab);
+    int rc = upload_tab(ctx, *gp);
+    if (rc) return rc;
+    *out = store_plan(ctx, key, std::move(gp));
+    return NVCA_OK;
+}
+
 int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstride, int channels, int mem, void *dst,
                        int dw, int dh, int dstride)
 {
@@ -774,11 +799,11 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
         const size_t sp = round_up((size_t)sw * 3, 64), dp3 = round_up((size_t)dw * 3, 64);
         if (w3.staging.ensure(sp * sh + 64) || w3.aux.ensure(dp3 * dh + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
         if ((rc3 = stage_2d(ctx, w3.staging.p, sp, src, sstride, (size_t)sw * 3, sh, mem))) return rc3;
-        GeomPlan gp3; build_resize_tab(sw, sh, dw, dh, gp3.tab);
-        if ((rc3 = upload_tab(ctx, gp3))) return rc3;
+        GeomPlan *gp3 = nullptr;
+        if ((rc3 = get_resize_plan(ctx, sw, sh, dw, dh, &gp3))) return rc3;
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-          launch_resize3(ctx->stream, w3.staging.as<uint8_t>(), sw, sh, (int)sp, gp3.tab.mode, gp3.d_xofs.as<int>(), gp3.d_ialpha.as<short>(),
-                         gp3.d_yofs.as<int>(), gp3.d_ibeta.as<short>(), gp3.tab.xmax, w3.aux.as<uint8_t>(), dw, dh, (int)dp3); }
+          launch_resize3(ctx->stream, w3.staging.as<uint8_t>(), sw, sh, (int)sp, gp3->tab.mode, gp3->d_xofs.as<int>(), gp3->d_ialpha.as<short>(),
+                         gp3->d_yofs.as<int>(), gp3->d_ibeta.as<short>(), gp3->tab.xmax, w3.aux.as<uint8_t>(), dw, dh, (int)dp3); }
         return unstage_2d(ctx, dst, dstride, w3.aux.p, dp3, (size_t)dw * 3, dh, mem);
     }
     if (channels != 1) return NVCA_ERR_ARG;
@@ -788,14 +813,21 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
     Workspace &ws = *ctx->ws;
     PreGeom gs; make_geom(gs, sw, sh, sstride, 1, sw, sh);
     PreGeom gd; make_geom(gd, sw, sh, sstride, 1, dw, dh);
+    GeomPlan *gp = nullptr;
+    if ((rc = get_resize_plan(ctx, sw, sh, dw, dh, &gp))) return rc;
+    if (mem == NVCA_MEM_DEVICE) {          // device images are read and written in place (ordered on the context's stream)
+        { TimedLaunch t(ctx, NVCA_K_RESIZE1);
+          launch_resize1(ctx->stream, (const uint8_t *)src, sw, sh, sstride, gp->tab.mode, gp->d_xofs.as<int>(),
+                         gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
+                         (uint8_t *)dst, dw, dh, dstride, nullptr); }
+        return finish_device_op(ctx);
+    }
     if ((rc = ensure_ws(ctx, gs, 1)) || (rc = ensure_ws(ctx, gd, 1))) return rc;
     if (ws.aux.ensure(gd.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
     if ((rc = stage_2d(ctx, ws.gray.p, gs.gpitch, src, sstride, sw, sh, mem))) return rc;
-    GeomPlan gp; build_resize_tab(sw, sh, dw, dh, gp.tab);
-    if ((rc = upload_tab(ctx, gp))) return rc;
     { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-      launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), sw, sh, gs.gpitch, gp.tab.mode, gp.d_xofs.as<int>(),
-                     gp.d_ialpha.as<short>(), gp.d_yofs.as<int>(), gp.d_ibeta.as<short>(), gp.tab.xmax,
+      launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), sw, sh, gs.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
+                     gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
                      ws.aux.as<uint8_t>(), dw, dh, gd.gpitch, nullptr); }
     return unstage_2d(ctx, dst, dstride, ws.aux.p, gd.gpitch, dw, dh, mem);
 }
@@ -809,6 +841,13 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     Workspace &ws = *ctx->ws;
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if (mem == NVCA_MEM_DEVICE) {          // histogram of the caller's image, LUT applied straight into the destination (in place allowed)
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
+        { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->stream, (const uint8_t *)src, w, h, stride, ws.hist.as<unsigned>()); }
+        { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1, 1); }
+        launch_apply_lut(ctx->stream, (const uint8_t *)src, w, h, stride, ws.lut.as<uint8_t>(), (uint8_t *)dst, dst_stride);
+        return finish_device_op(ctx);
+    }
     if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
     if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
     NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
@@ -826,6 +865,10 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int strid
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
+    if (mem == NVCA_MEM_DEVICE && src != dst) {
+        launch_flip_h(ctx->stream, (const uint8_t *)src, w, h, stride, (uint8_t *)dst, dst_stride);
+        return finish_device_op(ctx);
+    }
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
     if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
     if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;

@@ -176,6 +176,8 @@ struct nvca_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
+    int defer_device_sync = 0;                // > 0: primitives that write device memory return without draining the stream
+                                              // (internal callers chaining primitives on the context's stream, parts.cpp)
     std::string err;
     int hit_cap = 16384;
     int policy = NVCA_SUM_F32PAIR;

@@ -218,6 +218,8 @@ int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect
     nvca_ctx *ctx = s->ctx;
     NVCA_LOCK_OR_FAIL(ctx);
     (void)hipSetDevice(ctx->device);
+    // the image primitives below hand device buffers to each other on the context's stream: no drain in between
+    struct Defer { nvca_ctx *c; Defer(nvca_ctx *x) : c(x) { c->defer_device_sync++; } ~Defer() { c->defer_device_sync--; } } defer(ctx);
     const int kind = s->p.kind, W = f->width, H = f->height;
     // conf_images: float arithmetic (EYE/kmseyedetect.cpp:331-339 and siblings)
     const float o2f = (kind != NVCA_PART_EAR && s->p.detect_event) ? ((float)W) / ((float)W) : ((float)W) / ((float)160);
