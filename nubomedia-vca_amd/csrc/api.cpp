@@ -30,7 +30,7 @@ int DevBuf::ensure(size_t n)
     bytes = want;
     return 0;
 }
-void DevBuf::release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+void DevBuf::release() { if (p && bytes) (void)hipFree(p); p = nullptr; bytes = 0; }     // bytes == 0: a view into another buffer
 int PinnedBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
@@ -113,12 +113,13 @@ struct GeomPlan {
     std::vector<PyrLevel> lv;
     std::vector<std::unique_ptr<GeomPlan>> level_tabs;
     size_t gray_total = 0, plane_total = 0; int P = 0;
-    ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); }
+    DevBuf d_pyr; int pyr_maxw = 0, pyr_maxh = 0; bool pyr_ok = false;   // device level table (one-launch pyramid kernels)
+    ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); d_pyr.release(); }
 };
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release();
+    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -139,10 +140,20 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
         {&d_deeprecs, deeprecs.data(), deeprecs.size() * sizeof(DeepRec)},
     };
+    // one device allocation and one copy for all tables (a FIND_BIGGEST scan builds a plan per scale, per call)
+    size_t total = 0;
+    for (auto &it : items) total += (it.n + 255) & ~(size_t)255;
+    if (total == 0) return NVCA_OK;
+    std::vector<unsigned char> blob(total);
+    size_t off = 0;
+    for (auto &it : items) { if (it.n) memcpy(blob.data() + off, it.h, it.n); off += (it.n + 255) & ~(size_t)255; }
+    for (auto &it : items) it.d->release();
+    if (d_blob.ensure(total)) { ctx->set_error("hipMalloc failed for plan tables"); return NVCA_ERR_NOMEM; }
+    NVCA_HIP_CHECK(ctx, hipMemcpy(d_blob.p, blob.data(), total, hipMemcpyHostToDevice));
+    off = 0;
     for (auto &it : items) {
-        if (it.n == 0) continue;
-        if (it.d->ensure(it.n)) { ctx->set_error("hipMalloc failed for plan tables"); return NVCA_ERR_NOMEM; }
-        NVCA_HIP_CHECK(ctx, hipMemcpy(it.d->p, it.h, it.n, hipMemcpyHostToDevice));
+        it.d->p = it.n ? (unsigned char *)d_blob.p + off : nullptr; it.d->bytes = 0;       // views
+        off += (it.n + 255) & ~(size_t)255;
     }
     return NVCA_OK;
 }
@@ -958,6 +969,19 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
             std::string err;
             if ((rc = np->det.build_custom(c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
             if ((rc = np->det.upload(ctx))) return rc;
+            std::vector<PyrLevelDev> dl(np->lv.size());
+            np->pyr_ok = getenv("NVCA_PYR_OFF") == nullptr;
+            for (size_t li = 0; li < np->lv.size(); li++) {
+                const PyrLevel &L = np->lv[li]; GeomPlan *t = np->level_tabs[li].get();
+                PyrLevelDev &d = dl[li]; memset(&d, 0, sizeof(d));
+                d.szw = L.szw; d.szh = L.szh; d.gpitch = L.gpitch; d.mode = t->tab.mode; d.xmax = t->tab.xmax; d.plane_off = L.plane_off;
+                d.gray_off = (long long)L.gray_off;
+                d.xofs = t->d_xofs.as<int>(); d.ialpha = t->d_ialpha.as<short>(); d.yofs = t->d_yofs.as<int>(); d.ibeta = t->d_ibeta.as<short>();
+                np->pyr_maxw = std::max(np->pyr_maxw, L.szw); np->pyr_maxh = std::max(np->pyr_maxh, L.szh);
+                if (L.szw > 1023) np->pyr_ok = false;            // one column per thread, plus the zero column
+            }
+            if (np->d_pyr.ensure(dl.size() * sizeof(PyrLevelDev))) { ctx->set_error("allocation failed (pyramid table)"); return NVCA_ERR_NOMEM; }
+            NVCA_HIP_CHECK(ctx, hipMemcpy(np->d_pyr.p, dl.data(), dl.size() * sizeof(PyrLevelDev), hipMemcpyHostToDevice));
         }
         pp = store_plan(ctx, key, std::move(np));
     }
@@ -971,6 +995,14 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
     }
     for (int k = 0; k < nimg; k++)
         if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, grays[k], stride, cols, rows, mem))) return rc;
+    if (pp->pyr_ok) {            // all levels of all images: one resize launch, one integral launch
+        { TimedLaunch t(ctx, NVCA_K_RESIZE1);
+          launch_pyr_resize(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, g0.gray_slot, pp->d_pyr.as<PyrLevelDev>(),
+                            (int)pp->lv.size(), nimg, pp->pyr_maxw, pp->pyr_maxh, ws.aux.as<uint8_t>(), gray_total); }
+        { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
+          launch_pyr_integral(ctx->stream, ws.aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
+                              ws.sum.as<int>(), ws.sqsum.as<unsigned>(), plane_total, P); }
+    } else
     for (size_t li = 0; li < pp->lv.size(); li++) {
         const PyrLevel &L = pp->lv[li];
         GeomPlan *gp = pp->level_tabs[li].get();

@@ -157,6 +157,30 @@ void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, 
 }
 
 // ---- 8UC1 resize (gray-then-resize order of the part detectors, pyramid levels)
+// one destination sample of cv::resize(INTER_LINEAR) 8UC1 (mode 0: copy, 2: exact 2x area-fast, 1: fixed-point bilinear)
+__device__ __forceinline__ int resize1_value(const uint8_t *__restrict__ src, int sh, int sstride, int mode,
+                                             const int *__restrict__ xofs, const short *__restrict__ ialpha,
+                                             const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax, int x, int y)
+{
+    if (mode == 0) return src[(size_t)y * sstride + x];
+    if (mode == 2) {
+        const uint8_t *s0 = src + (size_t)(2 * y) * sstride + 2 * x, *s1 = s0 + sstride;
+        return (s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2;
+    }
+    int sy0 = yofs[y], sy1 = sy0 + 1;
+    sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+    sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+    const int sx = xofs[x];
+    const uint8_t *s0 = src + (size_t)sy0 * sstride + sx, *s1 = src + (size_t)sy1 * sstride + sx;
+    const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+    int h0, h1;
+    if (x < xmax) {
+        const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
+        h0 = s0[0] * a0 + s0[1] * a1; h1 = s1[0] * a0 + s1[1] * a1;
+    } else { h0 = s0[0] * 2048; h1 = s1[0] * 2048; }
+    return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
+}
+
 __global__ __launch_bounds__(256) void k_resize1(
     const uint8_t *__restrict__ src, int sw, int sh, int sstride, int mode,
     const int *__restrict__ xofs, const short *__restrict__ ialpha,
@@ -174,25 +198,7 @@ __global__ __launch_bounds__(256) void k_resize1(
         const int y = blockIdx.y * kGrayRows + ry;
         if (y >= dh) break;
         if (x < dw) {
-            int v;
-            if (mode == 0) v = src[(size_t)y * sstride + x];
-            else if (mode == 2) {
-                const uint8_t *s0 = src + (size_t)(2 * y) * sstride + 2 * x, *s1 = s0 + sstride;
-                v = (s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2;
-            } else {
-                int sy0 = yofs[y], sy1 = sy0 + 1;
-                sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
-                sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
-                const int sx = xofs[x];
-                const uint8_t *s0 = src + (size_t)sy0 * sstride + sx, *s1 = src + (size_t)sy1 * sstride + sx;
-                const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
-                int h0, h1;
-                if (x < xmax) {
-                    const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
-                    h0 = s0[0] * a0 + s0[1] * a1; h1 = s1[0] * a0 + s1[1] * a1;
-                } else { h0 = s0[0] * 2048; h1 = s1[0] * 2048; }
-                v = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
-            }
+            const int v = resize1_value(src, sh, sstride, mode, xofs, ialpha, yofs, ibeta, xmax, x, y);
             dst[(size_t)y * dstride + x] = (uint8_t)v;
             if (hist) atomicAdd(&lh[wave][v], 1u);
         }
@@ -546,6 +552,74 @@ void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, in
 {
     NVCA_LAUNCH(k_integral, dim3(g.nbands, batch), dim3(kIntThreads), 0, st, gray, lut, lut_stride, g, bandsum,
                        bandsq, sum, (unsigned *)sqsum);
+}
+
+// ---- CV_HAAR_SCALE_IMAGE pyramids: every level of every image in one launch per step -----------------------------
+// The levels of a pyramid are small (the part detectors work at 320 pixels width) and there are ~15 of them: resizing
+// and integrating them one level at a time is a chain of ~60 tiny dependent launches.  k_pyr_resize writes all levels
+// (grid.z = level x image); k_pyr_integral gives each (level, image) one workgroup that walks the rows with one column
+// per thread: running column sums in registers, one workgroup-wide scan per row (sum i32, squared sum u64 -> two u32
+// planes, same layout as k_integral).  Levels wider than 1024 pixels take the general three-kernel path.
+__global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride, size_t src_slot,
+                                                    const PyrLevelDev *__restrict__ levels, int nimg,
+                                                    uint8_t *__restrict__ aux, size_t aux_slot)
+{
+    const int lev = blockIdx.z / nimg, img = blockIdx.z - lev * nimg;
+    const PyrLevelDev L = levels[lev];
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= L.szw || blockIdx.y * kGrayRows >= L.szh) return;
+    const uint8_t *s = src + (size_t)img * src_slot;
+    uint8_t *d = aux + (size_t)img * aux_slot + L.gray_off;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y >= L.szh) break;
+        if (x < L.szw) d[(size_t)y * L.gpitch + x] = (uint8_t)resize1_value(s, sh, sstride, L.mode, L.xofs, L.ialpha, L.yofs, L.ibeta, L.xmax, x, y);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict__ aux, size_t aux_slot,
+                                                       const PyrLevelDev *__restrict__ levels, int nimg,
+                                                       int *__restrict__ sum, unsigned *__restrict__ sq32, size_t sum_slot, int P)
+{
+    __shared__ unsigned wt_s[2][16];
+    __shared__ unsigned long long wt_q[2][16];
+    const int lev = blockIdx.x / nimg, img = blockIdx.x - lev * nimg;
+    const PyrLevelDev L = levels[lev];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = L.szw, h = L.szh;
+    const uint8_t *g = aux + (size_t)img * aux_slot + L.gray_off;
+    int *s = sum + (size_t)img * sum_slot + L.plane_off;
+    unsigned *lo = sq32 + (size_t)img * 2 * sum_slot + L.plane_off, *hi = lo + sum_slot;
+    if (tid <= w) { s[tid] = 0; lo[tid] = 0; hi[tid] = 0; }            // integral row 0
+    unsigned cs = 0; unsigned long long cq = 0;                          // running sums of this thread's column
+    unsigned pix = (tid < w && h > 0) ? g[tid] : 0;
+    int par = 0;
+    for (int y = 0; y < h; y++) {
+        const unsigned cur = pix;
+        if (tid < w && y + 1 < h) pix = g[(size_t)(y + 1) * L.gpitch + tid];      // next row in flight during the scan
+        cs += cur; cq += (unsigned long long)(cur * cur);
+        unsigned is = wave_incl_scan_u32(cs, lane);
+        unsigned long long iq = cq;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long b = __shfl_up(iq, d); if (lane >= d) iq += b; }
+        if (lane == 63) { wt_s[par][wave] = is; wt_q[par][wave] = iq; }
+        __syncthreads();
+        for (int j = 0; j < wave; j++) { is += wt_s[par][j]; iq += wt_q[par][j]; }
+        par ^= 1;
+        const size_t row = (size_t)(y + 1) * P;
+        if (tid < w) { s[row + tid + 1] = (int)is; lo[row + tid + 1] = (unsigned)iq; hi[row + tid + 1] = (unsigned)(iq >> 32); }
+        if (tid == 0) { s[row] = 0; lo[row] = 0; hi[row] = 0; }
+    }
+}
+
+void launch_pyr_resize(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, size_t src_slot, const PyrLevelDev *levels,
+                       int nlev, int nimg, int maxw, int maxh, uint8_t *aux, size_t aux_slot)
+{
+    dim3 grid((maxw + 255) / 256, (maxh + kGrayRows - 1) / kGrayRows, nlev * nimg);
+    NVCA_LAUNCH(k_pyr_resize, grid, dim3(256), 0, st, src, sw, sh, sstride, src_slot, levels, nimg, aux, aux_slot);
+}
+void launch_pyr_integral(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
+                         int *sum, unsigned *sq32, size_t sum_slot, int P)
+{
+    NVCA_LAUNCH(k_pyr_integral, dim3(nlev * nimg), dim3(1024), 0, st, aux, aux_slot, levels, nimg, sum, sq32, sum_slot, P);
 }
 
 } // namespace nvca

@@ -226,6 +226,16 @@ struct PreGeom {
 void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, int mode,
                  const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta, int xmax,
                  uint8_t *gray, unsigned *hist, int batch, bool aligned4);
+// one pyramid level of a CV_HAAR_SCALE_IMAGE scan (device copy): all levels are resized / integrated by one launch each
+struct PyrLevelDev {
+    int szw, szh, gpitch, mode, xmax, plane_off, pad0, pad1;
+    long long gray_off;
+    const int *xofs; const short *ialpha; const int *yofs; const short *ibeta;
+};
+void launch_pyr_resize(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, size_t src_slot, const PyrLevelDev *levels,
+                       int nlev, int nimg, int maxw, int maxh, uint8_t *aux, size_t aux_slot);
+void launch_pyr_integral(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
+                         int *sum, unsigned *sq32, size_t sum_slot, int P);
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist, int batch = 1, size_t src_slot = 0, size_t dst_slot = 0);

@@ -7,6 +7,7 @@
 // std::vector idioms of the reference that rely on libstdc++ behaviour (erase through a reverse iterator,
 // erase(end()-i) inside a counting loop) are written out as the index operations they perform.
 #include "nvca_internal.h"
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <climits>
@@ -268,11 +269,19 @@ int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect
                 CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, part, pw, ph, pw));
                 CK(nvca_equalize_hist(ctx, part, pw, ph, pw, D, part, pw));
                 CK(nvca_flip_horizontal(ctx, small, fw, fh, fw, D, s->d_flip.p, fw));                    // EAR :800
+                static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+                auto e0 = std::chrono::steady_clock::now();
                 std::vector<nvca_rect> pf[2];                // profile faces in the image and in its mirror: one launch set
                 CK(nvca::detect_scale_image_pair(ctx, s->face, small, s->d_flip.as<uint8_t>(), fw, fh, fw, D,
                                                  1 + s->p.scale_factor_pct * 1.0 / 100, 2, 3, 3, pf));
+                auto e1 = std::chrono::steady_clock::now();
                 CK(find_ears(s, pf[0], fw, fh, part, pw, ph, s->a, scale_f2x, scale_x2o, 0));
                 CK(find_ears(s, pf[1], fw, fh, part, pw, ph, s->b, scale_f2x, scale_x2o, 1));
+                if (hostprof) {
+                    auto e2 = std::chrono::steady_clock::now();
+                    auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+                    fprintf(stderr, "[nvca host] ear: profile-face pair %ld us (%zu + %zu faces, %dx%d), ear search %ld us\n", us(e0, e1), pf[0].size(), pf[1].size(), fw, fh, us(e1, e2));
+                }
             } else {
                 if (0 == s->p.detect_event) {
                     CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, small, fw, fh, fw));

@@ -49,7 +49,7 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off;
+    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off, d_blob;   // the table buffers are views into d_blob
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
