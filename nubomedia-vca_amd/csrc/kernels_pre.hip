@@ -581,8 +581,7 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
                                                        const PyrLevelDev *__restrict__ levels, int nimg,
                                                        int *__restrict__ sum, unsigned *__restrict__ sq32, size_t sum_slot, int P)
 {
-    __shared__ unsigned wt_s[2][16];
-    __shared__ unsigned long long wt_q[2][16];
+    __shared__ unsigned wt_s[2][16], wt_l[2][16], wt_h[2][16];
     const int lev = blockIdx.x / nimg, img = blockIdx.x - lev * nimg;
     const PyrLevelDev L = levels[lev];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = L.szw, h = L.szh;
@@ -590,20 +589,22 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
     int *s = sum + (size_t)img * sum_slot + L.plane_off;
     unsigned *lo = sq32 + (size_t)img * 2 * sum_slot + L.plane_off, *hi = lo + sum_slot;
     if (tid <= w) { s[tid] = 0; lo[tid] = 0; hi[tid] = 0; }            // integral row 0
-    unsigned cs = 0; unsigned long long cq = 0;                          // running sums of this thread's column
+    // running sums of this thread's column; the squared one stays below 2^32 (rows x 255^2), so its row prefix can be
+    // scanned as two 32-bit halves (low 16 bits / the rest) on the VALU and recombined in 64 bits
+    unsigned cs = 0, cq = 0;
     unsigned pix = (tid < w && h > 0) ? g[tid] : 0;
     int par = 0;
     for (int y = 0; y < h; y++) {
         const unsigned cur = pix;
         if (tid < w && y + 1 < h) pix = g[(size_t)(y + 1) * L.gpitch + tid];      // next row in flight during the scan
-        cs += cur; cq += (unsigned long long)(cur * cur);
+        cs += cur; cq += cur * cur;
         unsigned is = wave_incl_scan_u32(cs, lane);
-        unsigned long long iq = cq;
-        for (int d = 1; d < 64; d <<= 1) { const unsigned long long b = __shfl_up(iq, d); if (lane >= d) iq += b; }
-        if (lane == 63) { wt_s[par][wave] = is; wt_q[par][wave] = iq; }
+        unsigned il = wave_incl_scan_u32(cq & 0xffffu, lane), ih = wave_incl_scan_u32(cq >> 16, lane);
+        if (lane == 63) { wt_s[par][wave] = is; wt_l[par][wave] = il; wt_h[par][wave] = ih; }
         __syncthreads();
-        for (int j = 0; j < wave; j++) { is += wt_s[par][j]; iq += wt_q[par][j]; }
+        for (int j = 0; j < wave; j++) { is += wt_s[par][j]; il += wt_l[par][j]; ih += wt_h[par][j]; }
         par ^= 1;
+        const unsigned long long iq = ((unsigned long long)ih << 16) + il;
         const size_t row = (size_t)(y + 1) * P;
         if (tid < w) { s[row + tid + 1] = (int)is; lo[row + tid + 1] = (unsigned)iq; hi[row + tid + 1] = (unsigned)(iq >> 32); }
         if (tid == 0) { s[row] = 0; lo[row] = 0; hi[row] = 0; }
