@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
                     for (int j = pu; j < st.count; j += P)
-                        part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
+                        part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
                 } else {
                     for (int j = p; j < st.count; j += P)
                         part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
@@ -532,15 +531,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 const double vnf = vnf_of(w);
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
-                    int j = pu;
-                    for (; j + P < st.count; j += 2 * P) {       // two independent stumps in flight (any order is exact here)
-                        const double v0 = pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
-                                               : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
-                        const double v1 = pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j + P])
-                                               : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j + P]);
-                        part += v0; part += v1;
-                    }
-                    if (j < st.count)
+                    for (int j = pu; j < st.count; j += P)
                         part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
                                      : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 } else {
