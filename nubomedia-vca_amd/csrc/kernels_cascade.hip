@@ -586,7 +586,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     }
 }
 
-__global__ __launch_bounds__(kTileThreads) void k_tile(CascadeArgs a)
+__global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(CascadeArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x;
