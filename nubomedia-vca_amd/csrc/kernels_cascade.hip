@@ -435,7 +435,7 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
     L.psum = (double *)lds;
     L.q0 = (unsigned short *)(lds + kTileThreads * 8);
     L.winx = L.q0 + 2 * kTileWin * kTileWin; L.winy = L.winx + kTileWin;
-    L.qn = (int *)(L.winy + kTileWin);                       // qn[0], qn[1], qn[2] = list base
+    L.qn = (int *)(L.winy + kTileWin);                       // qn[0..2] rotating queue counters, qn[3] = list base
     L.vnf_s = (double *)((unsigned char *)L.qn + 64);
     L.rej = (unsigned *)(L.vnf_s + kTileWin * kTileWin);
     L.carry = (int *)(L.rej + kTileWin);
@@ -453,7 +453,7 @@ __device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t
     const unsigned short *__restrict__ cl = a.tcoords + t.col_off, *__restrict__ rl = a.tcoords + t.row_off;
     const int *__restrict__ xpos = a.pos + sc.xpos_off + t.ix0;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + t.iy0;
-    if (tid < 3) L.qn[tid] = 0;
+    if (tid < 3) L.qn[tid] = 0;          // the three rotating queue counters (qn[3]: list base scratch)
     if (tid < t.nx) L.winx[tid] = (unsigned short)(xpos[tid] - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
     for (int c = tid; c < t.ncol; c += kTileThreads) L.cmap[cl[c] - t.x0] = (unsigned short)(c * 4);
@@ -504,14 +504,17 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         return vnfp[((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
     };
     int cur = 0;
+    // queue counters rotate over three words: stage s reads qn[cin], appends to qn[cout] and clears the third one, which
+    // nobody touches during this stage and which the next stage appends to -- one barrier per stage instead of two
+    int cin = 0;
     int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
     if (a.exp >= 10 && a.exp - 10 < last) last = a.exp - 10;
     for (int s = 1; s < last; s++) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
-        const int n = L.qn[cur];
+        const int n = L.qn[cin];
         if (n == 0) break;
-        if (tid == 0) L.qn[cur ^ 1] = 0;
-        __syncthreads();
+        const int cout = cin == 2 ? 0 : cin + 1;
+        if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
         const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
         unsigned short *qo = L.q0 + (cur ^ 1) * kTileWin * kTileWin;
         const StageRec st = a.stages[s];
@@ -549,7 +552,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 pass = !(tot < (double)st.thr);
                 w = qi[tid];
             }
-            queue_push(pass, w, qo, &L.qn[cur ^ 1]);
+            queue_push(pass, w, qo, &L.qn[cout]);
         } else
         for (int base = 0; base < n; base += kTileThreads) {
             const int i = base + tid;
@@ -563,20 +566,20 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 else for (int j = 0; j < st.count; j++) stage_sum += tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
                 pass = !(stage_sum < (double)st.thr);
             }
-            queue_push(pass, w, qo, &L.qn[cur ^ 1]);
+            queue_push(pass, w, qo, &L.qn[cout]);
         }
-        cur ^= 1;
+        cur ^= 1; cin = cout;
     }
     __syncthreads();
     if (a.exp) return;
-    const int nh = L.qn[cur];
+    const int nh = L.qn[cin];
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
-    if (tid == 0) L.qn[2] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
+    if (tid == 0) L.qn[3] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
     __syncthreads();
-    const unsigned gb = (unsigned)L.qn[2];
+    const unsigned gb = (unsigned)L.qn[3];
     const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
     for (int i = tid; i < nh; i += kTileThreads) {
         const int w = qi[i], ix = t.ix0 + (w & 31);
