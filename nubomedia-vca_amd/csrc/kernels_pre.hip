@@ -406,10 +406,22 @@ __global__ __launch_bounds__(256) void k_bandscan(PreGeom g, unsigned *__restric
     if (x >= bpitch) return;
     unsigned rs = 0, rq = 0;
     size_t o = (size_t)slot * g.band_slot + x;
-    for (int b = 0; b < g.nbands; b++, o += bpitch) {
-        const unsigned ts = bandsum[o], tq = bandsq[o];
-        bandsum[o] = rs; bandsq[o] = rq;
-        rs += ts; rq += tq;
+    // 16 bands at a time: the loads of a chunk are all in flight before the first store (a load-add-store loop
+    // serialises on the round trip: the stores may alias the next loads as far as the compiler knows)
+    for (int b0 = 0; b0 < g.nbands; b0 += 16) {
+        unsigned ts[16], tq[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool in = b0 + k < g.nbands;
+            ts[k] = in ? bandsum[o + (size_t)k * bpitch] : 0u; tq[k] = in ? bandsq[o + (size_t)k * bpitch] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (b0 + k < g.nbands) {
+                bandsum[o + (size_t)k * bpitch] = rs; bandsq[o + (size_t)k * bpitch] = rq;
+                rs += ts[k]; rq += tq[k];
+            }
+        o += (size_t)16 * bpitch;
     }
 }
 void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsigned *bandsq, int batch)
