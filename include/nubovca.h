@@ -193,6 +193,12 @@ int  nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca
 int  nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams,
                              const nvca_frame *frames, nvca_rect *out, int *ids, int cap,
                              int *n_out);
+/* The same in two halves, for a serving loop that keeps the GPU busy across batches: submit() gates the frames and queues
+ * every launch, collect() waits for that batch and runs the temporal logic (Faces::track_faces, FACE/Faces.cpp:78-153).
+ * Up to two batches may be in flight; they are collected in submission order.  Frame memory must stay valid until the
+ * batch has been collected. */
+int  nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames, int *ticket);
+int  nvca_face_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out, int *ids, int cap, int *n_out);
 
 /* ---- part detectors: NuboEyeDetector / NuboNoseDetector / NuboMouthDetector / NuboEarDetector ----
  * One handle == one element instance.  Replaces kms_{eye,nose,mouth,ear}_detect_conf_images +

@@ -71,12 +71,15 @@ bool launch_events(hipEvent_t *a, hipEvent_t *b)
 static void drain_timer(nvca_ctx *ctx)     // stream must be idle
 {
     KernelTimer &t = ctx->timer;
+    std::vector<KernelTimer::Ev> later;
     for (auto &e : t.pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { t.total_ms[e.k] += ms; if (e.first) t.launches[e.k]++; }
+        const hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
+        if (r == hipErrorNotReady) { later.push_back(e); continue; }       // a batch still in flight (submit / collect)
+        if (r == hipSuccess) { t.total_ms[e.k] += ms; if (e.first) t.launches[e.k]++; }
         t.pool.push_back(e.a); t.pool.push_back(e.b);
     }
-    t.pending.clear();
+    t.pending.swap(later);
 }
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -86,17 +89,25 @@ static inline int cv_round(double v)
     return (int)lrint(v);
 }
 
-struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, hits, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off, grp, gthr;
-    PinnedBuf h_hits, h_srcptrs, h_grp, h_gthr;
+// what a cascade job leaves behind for the host: candidate list, box table, thresholds.  Three sets: [0] the synchronous
+// entry points, [1] / [2] the two batches that may be in flight through nvca_face_batch_submit / _collect
+struct ResultBufs {
+    DevBuf hits, grp, gthr;
+    PinnedBuf h_hits, h_grp, h_gthr, h_srcptrs;   // h_srcptrs: frame pointers on their way to the device array
     std::vector<int> gthr_last;       // thresholds currently resident in gthr
+    void release() { hits.release(); grp.release(); gthr.release(); h_hits.release(); h_grp.release(); h_gthr.release(); h_srcptrs.release(); gthr_last.clear(); }
+};
+struct Workspace {
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
+    ResultBufs res[3];
+    int cur_res = 0;
     int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
-        sqsum.release(); hits.release(); srcptrs.release(); staging.release(); aux.release();
-        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release(); grp.release(); gthr.release();
-        h_hits.release(); h_srcptrs.release(); h_grp.release(); h_gthr.release(); gthr_last.clear();
+        sqsum.release(); srcptrs.release(); staging.release(); aux.release();
+        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
+        for (ResultBufs &r : res) r.release();
     }
 };
 
@@ -109,6 +120,7 @@ struct GeomPlan {
     PreGeom g;
     bool has_det = false;
     uint64_t last_use = 0;                                    // plan cache is LRU-bounded (store_plan)
+    int inflight = 0;                                         // batches in flight that reference this plan: never evicted
     // CV_HAAR_SCALE_IMAGE: pyramid levels, their resize tables, plane layout
     std::vector<PyrLevel> lv;
     std::vector<std::unique_ptr<GeomPlan>> level_tabs;
@@ -182,10 +194,8 @@ static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
     e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
     e |= ws.sum.ensure(g.sum_slot * batch * sizeof(int));
     e |= ws.sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
-    e |= ws.hits.ensure(((size_t)ctx->hit_cap * batch + 1) * sizeof(unsigned long long));
     e |= ws.srcptrs.ensure((size_t)batch * sizeof(void *));
-    e |= ws.h_srcptrs.ensure((size_t)batch * sizeof(void *));
-    e |= ws.h_hits.ensure(((size_t)ctx->hit_cap * batch + 1) * sizeof(unsigned long long));
+    e |= ws.res[ws.cur_res].h_srcptrs.ensure((size_t)batch * sizeof(void *));
     if (e) { ctx->set_error("device/pinned allocation failed for the workspace"); return NVCA_ERR_NOMEM; }
     return NVCA_OK;
 }
@@ -243,14 +253,15 @@ struct CascadeJob {
 static int cascade_counters(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job, unsigned long long **hits, unsigned long long **deep)
 {
     Workspace &ws = *ctx->ws;
+    ResultBufs &rb = ws.res[ws.cur_res];
     const int total = std::max(job.total, job.r0 + job.n);
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * job.n + 64, 1u << 28);
     if (ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
-        ws.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || ws.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
+        rb.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || rb.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
         ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
     }
-    *hits = ws.hits.as<unsigned long long>() + hits_stride * job.r0;
+    *hits = rb.hits.as<unsigned long long>() + hits_stride * job.r0;
     *deep = ws.deep.as<unsigned long long>();
     return NVCA_OK;
 }
@@ -258,6 +269,7 @@ static int cascade_counters(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job
 static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, CascadeJob &job, const int *group_thr, bool want_group)
 {
     Workspace &ws = *ctx->ws;
+    ResultBufs &rb = ws.res[ws.cur_res];
     const int batch = job.n, total = std::max(job.total, job.r0 + job.n);
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;                 // u64 words per result slot
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
@@ -265,12 +277,12 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     if (ws.failbits.ensure(dp.tasks.size() * sizeof(unsigned long long) * batch + 8) ||
         ws.vnf.ensure(dp.tasks.size() * 64 * sizeof(double) * batch + 8) ||
         ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
-        ws.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || ws.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
+        rb.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || rb.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
         ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
     }
     job.cap = cap;
-    job.d_hits = ws.hits.as<unsigned long long>() + hits_stride * job.r0;
-    job.h_hits = ws.h_hits.as<unsigned long long>() + hits_stride * job.r0;
+    job.d_hits = rb.hits.as<unsigned long long>() + hits_stride * job.r0;
+    job.h_hits = rb.h_hits.as<unsigned long long>() + hits_stride * job.r0;
     if (!job.counters_zeroed) {
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->stream));
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
@@ -282,17 +294,17 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     const size_t rec = 2 + 4 * kGroupOutCap;
     const size_t grp_stride = rec + 2;                                       // per result slot: a job's table is followed by the 64-bit raw count
     if (dev_group) {
-        if (ws.grp.ensure((size_t)total * grp_stride * sizeof(int)) || ws.h_grp.ensure((size_t)total * grp_stride * sizeof(int)) ||
-            ws.gthr.ensure((size_t)total * sizeof(int)) || ws.h_gthr.ensure((size_t)total * sizeof(int))) {
+        if (rb.grp.ensure((size_t)total * grp_stride * sizeof(int)) || rb.h_grp.ensure((size_t)total * grp_stride * sizeof(int)) ||
+            rb.gthr.ensure((size_t)total * sizeof(int)) || rb.h_gthr.ensure((size_t)total * sizeof(int))) {
             ctx->set_error("device allocation failed for the grouping workspace"); return NVCA_ERR_NOMEM;
         }
-        job.d_grp = ws.grp.as<int>() + grp_stride * job.r0; job.h_grp = ws.h_grp.as<int>() + grp_stride * job.r0;
-        if (ws.gthr_last.size() < (size_t)total) ws.gthr_last.resize(total, -1);
-        if (memcmp(ws.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
+        job.d_grp = rb.grp.as<int>() + grp_stride * job.r0; job.h_grp = rb.h_grp.as<int>() + grp_stride * job.r0;
+        if (rb.gthr_last.size() < (size_t)total) rb.gthr_last.resize(total, -1);
+        if (memcmp(rb.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));             // h_gthr may still feed an earlier copy
-            memcpy(ws.h_gthr.as<int>() + job.r0, group_thr, batch * sizeof(int));
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.gthr.as<int>() + job.r0, ws.h_gthr.as<int>() + job.r0, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-            std::copy(group_thr, group_thr + batch, ws.gthr_last.begin() + job.r0);
+            memcpy(rb.h_gthr.as<int>() + job.r0, group_thr, batch * sizeof(int));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(rb.gthr.as<int>() + job.r0, rb.h_gthr.as<int>() + job.r0, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            std::copy(group_thr, group_thr + batch, rb.gthr_last.begin() + job.r0);
         }
     }
     if (!dp.tasks.empty() && !skip_cascade) {
@@ -348,7 +360,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
         }
         { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
-        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, ws.gthr.as<int>() + job.r0, job.d_grp, kGroupOutCap, batch); }
+        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, job.d_grp, kGroupOutCap, batch); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
@@ -475,10 +487,10 @@ static GeomPlan *store_plan(nvca_ctx *ctx, const std::string &key, std::unique_p
 {
     if (ctx->plans.size() >= kMaxPlans) {
         (void)hipStreamSynchronize(ctx->stream);
-        auto victim = ctx->plans.begin();
+        auto victim = ctx->plans.end();
         for (auto it = ctx->plans.begin(); it != ctx->plans.end(); ++it)
-            if (it->second->last_use < victim->second->last_use) victim = it;
-        ctx->plans.erase(victim);
+            if (it->second->inflight == 0 && (victim == ctx->plans.end() || it->second->last_use < victim->second->last_use)) victim = it;
+        if (victim != ctx->plans.end()) ctx->plans.erase(victim);
     }
     gp->last_use = ++ctx->next_uid;
     GeomPlan *p = gp.get();
@@ -523,6 +535,7 @@ nvca_ctx::~nvca_ctx()
     if (identity_lut) (void)hipFree(identity_lut);
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
     for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
@@ -734,13 +747,13 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
     Workspace &ws = *ctx->ws;
     if (!st) st = ctx->stream;
     if (!off_io) {           // stand-alone call: size the buffers here
-        if (ws.srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
+        if (ws.srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
             ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
         }
         const size_t need = staging_need(frames, idx, n);
         if (need && ws.staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
     }
-    const void **hp = ws.h_srcptrs.as<const void *>() + r0;
+    const void **hp = ws.res[ws.cur_res].h_srcptrs.as<const void *>() + r0;
     size_t off = off_io ? *off_io : 0;
     for (int i = 0; i < n; i++) {
         const nvca_frame &f = frames[idx ? idx[i] : i];
@@ -1263,21 +1276,41 @@ int nvca_face_stream_motion_event(nvca_face_stream *s)
     return NVCA_OK;
 }
 
-int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames,
-                            nvca_rect *out, int *ids, int cap, int *n_out)
+} // extern "C"
+
+// A batch between its two halves: everything the second half (results -> temporal logic -> boxes) needs.
+namespace nvca {
+struct FaceTicket {
+    bool pending = false;
+    uint64_t serial = 0;
+    int n = 0;
+    std::vector<nvca_face_stream *> streams;
+    std::vector<FrameWork> work;
+    struct Group { GeomPlan *gp; std::vector<int> idx, gthr; std::vector<CascadeJob> jobs; };
+    std::vector<Group> groups;
+    hipEvent_t done = nullptr;
+};
+}
+
+// first half: gating, then every launch of the batch queued on the context's stream (result set `res`); no waiting
+static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames, int res, FaceTicket &tk)
 {
-    NVCA_LOCK_OR_FAIL(ctx);
-    if (!ctx || n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    if (n < 0 || (n > 0 && (!streams || !frames))) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
-    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
-    auto tq0 = std::chrono::steady_clock::now(), tq1 = tq0, tq2 = tq0;
-    std::vector<FrameWork> work(n);
+    Workspace &ws = *ctx->ws;
+    ws.cur_res = res;
+    tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();
+    std::vector<FrameWork> &work = tk.work;
     // ---- pass 1: geometry + gating, in frame order
     for (int i = 0; i < n; i++) {
         nvca_face_stream *s = streams[i];
         const nvca_frame &f = frames[i];
         if (!s || s->ctx != ctx || check_img(ctx, f.data, f.width, f.height, f.stride, 3, f.mem)) return NVCA_ERR_ARG;
         if (s->p.width_to_process <= 0) { ctx->set_error("width-to-process must be > 0"); return NVCA_ERR_ARG; }
+    }
+    for (int i = 0; i < n; i++) {
+        nvca_face_stream *s = streams[i];
+        const nvca_frame &f = frames[i];
         FrameWork &w = work[i];
         // kms_face_detect_conf_images :304 -- INTEGER ratio kept in a float; kms_face_send_event :190
         const float fscale = (float)(f.width / s->p.width_to_process);
@@ -1288,13 +1321,16 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
         if (cv_round(f.width / scale) > 0) w.cols = cv_round(f.width / scale); else scale = 1;
         w.analysed = face_gate(s);
     }
-    // ---- pass 2: one launch set per distinct geometry
+    // ---- pass 2: one launch set per distinct geometry; result slots are numbered over the whole batch
     std::vector<char> done(n, 0);
+    int gbase = 0;
     for (int i = 0; i < n; i++) {
         if (!work[i].analysed || done[i]) continue;
         const nvca_face_stream *s0 = streams[i];
         const nvca_frame &f0 = frames[i];
-        std::vector<int> idx;
+        tk.groups.emplace_back();
+        FaceTicket::Group &grp = tk.groups.back();
+        std::vector<int> &idx = grp.idx;
         for (int j = i; j < n; j++) {
             const nvca_face_stream *sj = streams[j];
             const nvca_frame &fj = frames[j];
@@ -1308,6 +1344,7 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
         const double sf = 1 + s0->p.scale_factor_pct * 1.0 / 100;      // MULTI_SCALE_FACTOR :142
         int rc = get_face_plan(ctx, s0->cascade, f0.width, f0.height, f0.stride, 3, cols, rows, sf, cols / 20, rows / 20, 0, 0, &gp);
         if (rc) return rc;
+        grp.gp = gp; gp->inflight++;
         // Host frames: the batch goes through in chunks -- chunk c+1's H2D copies run on the copy stream while the
         // kernels of chunk c execute (with pageable memory the host blocks in the copy, the queued kernels do not).
         // Every chunk reuses planes [0, chunk); only its candidate list / box table are its own (CascadeJob).
@@ -1317,20 +1354,19 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
         const int chunk = (any_host && chunk_env > 0 && batch >= 2 * chunk_env) ? chunk_env : batch;
         const bool piped = chunk < batch;
         if ((rc = ensure_ws(ctx, gp->g, chunk))) return rc;
-        Workspace &ws = *ctx->ws;
         {
             const size_t need = staging_need(frames, idx.data(), batch);
-            if (ws.srcptrs.ensure((size_t)batch * sizeof(void *)) || ws.h_srcptrs.ensure((size_t)batch * sizeof(void *)) ||
+            if (ws.srcptrs.ensure((size_t)(gbase + batch) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(gbase + batch) * sizeof(void *)) ||
                 (need && ws.staging.ensure(need))) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
         }
-        std::vector<int> gthr(batch);
+        std::vector<int> &gthr = grp.gthr;
+        gthr.resize(batch);
         for (int b = 0; b < batch; b++) { const int mn = streams[idx[b]]->p.min_neighbors; gthr[b] = mn != 0 ? std::max(mn, 1) : 0; }
-        std::vector<CascadeJob> jobs;
+        std::vector<CascadeJob> &jobs = grp.jobs;
         size_t stage_off = 0;
-        tq1 = std::chrono::steady_clock::now();
         for (int s0 = 0; s0 < batch; s0 += chunk) {
-            const int n = std::min(chunk, batch - s0);
-            if ((rc = stage_frames(ctx, frames, idx.data() + s0, n, 3, s0, piped ? ctx->copy_stream : ctx->stream, &stage_off))) return rc;
+            const int nc = std::min(chunk, batch - s0);
+            if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->stream, &stage_off))) return rc;
             if (piped) {
                 while (ctx->chunk_events.size() <= jobs.size()) {
                     hipEvent_t ev; NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1340,44 +1376,70 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
                 NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->chunk_events[jobs.size()], 0));
             }
             int hist_clean = ws.hist_clean;                                // k_lut leaves the histograms it read zeroed again
-            if (hist_clean < n) {
-                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)n * 256 * sizeof(unsigned), ctx->stream));
-                hist_clean = n;
+            if (hist_clean < nc) {
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)nc * 256 * sizeof(unsigned), ctx->stream));
+                hist_clean = nc;
             }
             ws.hist_clean = 0;                                             // dirty until the LUT kernel is queued
-            CascadeJob job; job.r0 = s0; job.n = n; job.total = batch;
+            CascadeJob job; job.r0 = gbase + s0; job.n = nc; job.total = n;
             unsigned long long *z_hits = nullptr, *z_deep = nullptr;
             if ((rc = cascade_counters(ctx, gp->det, job, &z_hits, &z_deep))) return rc;
             { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
-              launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>() + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
+              launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>() + gbase + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
                           gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
-                          ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), n, frames_aligned4(frames, idx.data() + s0, n)); }
+                          ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), nc, frames_aligned4(frames, idx.data() + s0, nc)); }
             { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
-              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), n, 1, z_hits, z_deep); }
+              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), nc, 1, z_hits, z_deep); }
             job.counters_zeroed = true;
             ws.hist_clean = hist_clean;
-            run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), n);
+            run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), nc);
             if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
             jobs.push_back(job);
         }
-        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        drain_timer(ctx);
-        tq2 = std::chrono::steady_clock::now();
-        for (const CascadeJob &job : jobs) {
+        gbase += batch;
+    }
+    if (!tk.done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
+    NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->stream));
+    // a later batch's host-frame copies (copy stream) must not overtake this batch's reads of the staging buffer
+    NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, tk.done, 0));
+    tk.pending = true;
+    return NVCA_OK;
+}
+
+static void face_release(FaceTicket &tk)
+{
+    for (FaceTicket::Group &g : tk.groups) if (g.gp) g.gp->inflight--;
+    tk.groups.clear(); tk.pending = false;
+}
+
+// second half: wait for the batch, turn candidates into tracked faces and boxes (frame order)
+static int face_collect(nvca_ctx *ctx, int res, FaceTicket &tk, nvca_rect *out, int *ids, int cap, int *n_out)
+{
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    ws.cur_res = res;
+    const int n = tk.n;
+    hipError_t he = hipEventSynchronize(tk.done);
+    if (he != hipSuccess) { ctx->set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); face_release(tk); return NVCA_ERR_HIP; }
+    drain_timer(ctx);
+    int rc = NVCA_OK;
+    for (FaceTicket::Group &grp : tk.groups) {
+        int gi0 = grp.jobs.empty() ? 0 : grp.jobs.front().r0;
+        for (const CascadeJob &job : grp.jobs) {
             std::vector<std::vector<nvca_rect>> raw;
             std::vector<char> grouped;
-            if ((rc = cascade_collect(ctx, gp->det, job, raw, &grouped))) return rc;
+            if ((rc = cascade_collect(ctx, grp.gp->det, job, raw, &grouped))) { face_release(tk); return rc; }
             for (int b = 0; b < job.n; b++) {
-                const int gi = job.r0 + b;
-                if (gthr[gi] != 0 && !grouped[b]) group_rectangles(raw[b], gthr[gi], 0.2);
-                work[idx[gi]].det.swap(raw[b]);
+                const int gi = job.r0 - gi0 + b;                         // position inside the group
+                if (grp.gthr[gi] != 0 && !grouped[b]) group_rectangles(raw[b], grp.gthr[gi], 0.2);
+                tk.work[grp.idx[gi]].det.swap(raw[b]);
             }
         }
     }
     // ---- pass 3: temporal logic + emission, in frame order
     for (int i = 0; i < n; i++) {
-        nvca_face_stream *s = streams[i];
-        FrameWork &w = work[i];
+        nvca_face_stream *s = tk.streams[i];
+        FrameWork &w = tk.work[i];
         if (w.analysed) {
             if (!w.det.empty()) s->faces.track(w.det, s->p.track_threshold);           // :813-816
             else if (s->frames_with_no_detection < kMaxNoDetection) s->frames_with_no_detection += 1;   // :817-826
@@ -1393,12 +1455,66 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
             if (ids) ids[(size_t)i * cap + k] = s->faces.faces[k].id;
         }
     }
-    if (hostprof) {
-        auto tq3 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        fprintf(stderr, "[nvca host] batch: before cascade %ld us, cascade %ld us, after %ld us\n", us(tq0, tq1), us(tq1, tq2), us(tq2, tq3));
-    }
+    face_release(tk);
     return NVCA_OK;
+}
+
+void nvca::free_face_ticket(FaceTicket *t)
+{
+    if (!t) return;
+    if (t->done) (void)hipEventDestroy(t->done);
+    delete t;
+}
+
+static FaceTicket &ticket_slot(nvca_ctx *ctx, int k)
+{
+    if (!ctx->face_tickets[k]) ctx->face_tickets[k] = new FaceTicket();
+    return *ctx->face_tickets[k];
+}
+
+extern "C" {
+
+int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames,
+                            nvca_rect *out, int *ids, int cap, int *n_out)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    for (int k = 1; k < 3; k++)
+        if (ctx->face_tickets[k] && ctx->face_tickets[k]->pending) { ctx->set_error("collect the submitted batches first"); return NVCA_ERR_ARG; }
+    FaceTicket &tk = ticket_slot(ctx, 0);
+    int rc = face_submit(ctx, n, streams, frames, 0, tk);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); face_release(tk); return rc; }
+    return face_collect(ctx, 0, tk, out, ids, cap, n_out);
+}
+
+// Pipelined form of nvca_face_batch_process for a serving loop: submit() queues a batch and returns, collect() waits for
+// the oldest submitted batch and delivers its boxes.  Up to two batches may be in flight, so the host-side work between
+// batches (result unpacking, the caller's own bookkeeping) overlaps the GPU.  Batches are collected in submission order.
+int nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames, int *ticket)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!ticket) return NVCA_ERR_ARG;
+    int k = 0;
+    for (int c = 1; c < 3; c++) if (!(ctx->face_tickets[c] && ctx->face_tickets[c]->pending)) { k = c; break; }
+    if (!k) { ctx->set_error("two batches are in flight: collect one first"); return NVCA_ERR_ARG; }
+    FaceTicket &tk = ticket_slot(ctx, k);
+    tk.serial = ++ctx->face_serial;
+    int rc = face_submit(ctx, n, streams, frames, k, tk);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); face_release(tk); return rc; }
+    *ticket = k;
+    return NVCA_OK;
+}
+int nvca_face_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out, int *ids, int cap, int *n_out)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (ticket < 1 || ticket > 2 || !ctx->face_tickets[ticket] || !ctx->face_tickets[ticket]->pending) { ctx->set_error("no such batch in flight"); return NVCA_ERR_ARG; }
+    FaceTicket &tk = *ctx->face_tickets[ticket];
+    const int other = 3 - ticket;
+    if (ctx->face_tickets[other] && ctx->face_tickets[other]->pending && ctx->face_tickets[other]->serial < tk.serial) {
+        ctx->set_error("batches are collected in submission order"); return NVCA_ERR_ARG;
+    }
+    if (cap < 0 || (cap > 0 && !out) || (tk.n > 0 && !n_out)) return NVCA_ERR_ARG;
+    return face_collect(ctx, ticket, tk, out, ids, cap, n_out);
 }
 
 int nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca_rect *out, int *ids, int cap, int *n_out)

@@ -155,6 +155,8 @@ struct PinnedBuf {
 };
 
 struct DetectPlan;   // plan.cpp
+struct FaceTicket;   // api.cpp
+void free_face_ticket(FaceTicket *t);
 struct GeomPlan;     // api.cpp
 struct Workspace;    // api.cpp
 
@@ -176,6 +178,8 @@ struct nvca_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
+    nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect
+    uint64_t face_serial = 0;
     int defer_device_sync = 0;                // > 0: primitives that write device memory return without draining the stream
                                               // (internal callers chaining primitives on the context's stream, parts.cpp)
     std::string err;

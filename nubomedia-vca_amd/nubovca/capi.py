@@ -67,7 +67,7 @@ SYMBOLS = [
     "nvca_tracker_set_params", "nvca_tracker_process", "nvca_tracker_batch_process", "nvca_flip_horizontal",
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
-    "nvca_host_register", "nvca_host_unregister",
+    "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
 ]
 
 _lib = None
@@ -144,6 +144,8 @@ def load():
     L.nvca_face_stream_motion_event.argtypes = [vp]
     L.nvca_face_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), ip, C.c_int, ip]
     L.nvca_face_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(Rect), ip, C.c_int, ip]
+    L.nvca_face_batch_submit.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), ip]
+    L.nvca_face_batch_collect.argtypes = [vp, C.c_int, C.POINTER(Rect), ip, C.c_int, ip]
     L.nvca_tracker_params_default.argtypes = [C.POINTER(TrackerParams)]
     L.nvca_tracker_params_default.restype = None
     L.nvca_tracker_create.argtypes = [vp, C.POINTER(TrackerParams), C.POINTER(vp)]
@@ -314,6 +316,26 @@ class Context:
             k = min(cnt[i], cap)
             res.append((boxes[i, :k].copy(), idv[i, :k].copy()))
         return res
+
+
+    def face_batch_submit(self, streams, frames):
+        """first half of face_batch_process: queues the batch and returns a ticket (at most two in flight)"""
+        n = len(frames)
+        sh = (C.c_void_p * n)(*[s.h for s in streams])
+        fr = (Frame * n)(*frames)
+        tk = C.c_int()
+        self.check(self.L.nvca_face_batch_submit(self.h, n, sh, fr, C.byref(tk)))
+        return (tk.value, n, sh, fr)          # the argument arrays stay referenced until the batch is collected
+
+    def face_batch_collect(self, ticket, cap=64):
+        tk, n = ticket[0], ticket[1]
+        out = (Rect * (n * cap))()
+        ids = (C.c_int * (n * cap))()
+        cnt = (C.c_int * n)()
+        self.check(self.L.nvca_face_batch_collect(self.h, tk, out, ids, cap, cnt))
+        boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)
+        idv = np.frombuffer(ids, dtype=np.int32).reshape(n, cap)
+        return [(boxes[i, :min(cnt[i], cap)].copy(), idv[i, :min(cnt[i], cap)].copy()) for i in range(n)]
 
 
 class Cascade:

@@ -359,6 +359,47 @@ def test_face_batch_mixed_geometries(ctx, casc, orc_cascade):
     assert seen > 8
 
 
+def test_face_batch_submit_collect(ctx, casc, orc_cascade):
+    """two batches in flight (submit k+1 before collect k), the same streams in consecutive batches, host and device
+    frames, mixed geometries: boxes and ids as if every frame went through the synchronous call"""
+    import orc
+    import torch
+    from nubovca import capi, synth
+    specs = [(640, 480, {"width_to_process": 640, "multi_scale_factor": 10}), (480, 360, {"width_to_process": 240}),
+             (640, 480, {"width_to_process": 640, "multi_scale_factor": 10}), (640, 480, {"width_to_process": 320})]
+    kw = {"width_to_process": "width_to_process", "multi_scale_factor": "scale_factor_pct"}
+    streams = [capi.FaceStream(ctx, casc, **p) for _, _, p in specs]
+    oracles = [orc.FaceStream(orc_cascade, **{kw[k]: v for k, v in p.items()}) for _, _, p in specs]
+    T = 7
+    frames = [[synth.make_bgr(W, H, 7000 + 31 * i + t, "natural", [(W // 5 + 9 * t, H // 6, H // 2)] if (i + t) % 5 else [])
+               for i, (W, H, _) in enumerate(specs)] for t in range(T)]
+    keep = [[torch.from_numpy(f).cuda() if (i + t) % 2 else None for i, f in enumerate(row)] for t, row in enumerate(frames)]
+    torch.cuda.synchronize()
+
+    def fr(t):
+        return [capi.make_frame(keep[t][i].data_ptr(), specs[i][0], specs[i][1], specs[i][0] * 3, capi.MEM_DEVICE)
+                if keep[t][i] is not None else capi.make_frame(frames[t][i]) for i in range(len(specs))]
+
+    got = []
+    pending = ctx.face_batch_submit(streams, fr(0))
+    for t in range(1, T):
+        nxt = ctx.face_batch_submit(streams, fr(t))
+        got.append(ctx.face_batch_collect(pending))
+        pending = nxt
+    with pytest.raises(capi.NvcaError):
+        ctx.face_batch_process(streams, fr(0))                 # synchronous call while a batch is in flight: refused
+    got.append(ctx.face_batch_collect(pending))
+    seen = 0
+    for t in range(T):
+        for i in range(len(specs)):
+            eb, eid = oracles[i].process(frames[t][i])
+            assert np.array_equal(got[t][i][0], eb) and np.array_equal(got[t][i][1], eid), (t, i)
+            seen += len(eb)
+    assert seen > 8
+    res = ctx.face_batch_process(streams, fr(0))                # and the synchronous form works again afterwards
+    assert len(res) == len(specs)
+
+
 def test_face_batch_registered_host_frames(ctx, casc, orc_cascade):
     """page-locked (nvca_host_register) host frames: asynchronous H2D in the chunked ingest path, same boxes"""
     import orc
