@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--faces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
+    ap.add_argument("--pipeline", action="store_true", help="nvca_face_batch_submit / _collect with two batches in flight instead of one synchronous "
+                    "nvca_face_batch_process per step (faster without per-kernel timing, NVCA_BENCH_NOTIMING=1; the per-kernel events cost more than it gains)")
     ap.add_argument("--pinned", action="store_true", help="with --host-frames: page-lock the frame buffers (nvca_host_register)")
     ap.add_argument("--workload", default="face1080p", choices=["face1080p", "streams720p", "face_tracker"],
                     help="face1080p: BASELINE configs[1] (default, the headline metric); streams720p: configs[3], "
@@ -152,9 +154,19 @@ def main():
     from nubovca import sharding
     gather = sharding.TableGather(device=dev) if world > 1 else None
 
+    # serving loop: two batches in flight -- the next batch is queued before the previous one is unpacked, so the host
+    # work between batches overlaps the GPU.  K steps = K submits + K collects; one batch stays in flight across steps.
+    pipelined = args.pipeline
+    inflight = [ctx.face_batch_submit(streams, frames_t[0])] if pipelined else [None]
+
     def step():
         tick[0] += 1
-        res = ctx.face_batch_process(streams, frames_t[tick[0] % TICKS], cap=MAX_BOXES)
+        if pipelined:
+            nxt = ctx.face_batch_submit(streams, frames_t[tick[0] % TICKS])
+            res = ctx.face_batch_collect(inflight[0], cap=MAX_BOXES)
+            inflight[0] = nxt
+        else:
+            res = ctx.face_batch_process(streams, frames_t[tick[0] % TICKS], cap=MAX_BOXES)
         if trackers is not None:
             capi.tracker_batch_process(ctx, trackers, bgra_frames[tick[0] % TICKS], [33.3 * tick[0]] * F, cap=256)
         if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL;
@@ -178,6 +190,9 @@ def main():
         res = step()
     fence()
     dt = time.perf_counter() - t0
+    if pipelined:               # the batch queued by the last step has finished inside the timed region; unpack it now
+        res = ctx.face_batch_collect(inflight[0], cap=MAX_BOXES)
+        inflight[0] = None
     ktimes = ctx.kernel_timing()
     ctx.enable_kernel_timing(False)
     n_boxes = float(np.mean([len(b) for b, _ in res]))
@@ -245,7 +260,8 @@ def main():
                                     ) % ((W, H) if not multi_stream else ()) +
                                    ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
                        "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
-                       "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world},
+                       "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world,
+                       "batches_in_flight": 2 if pipelined else 1},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -68,18 +68,28 @@ bool launch_events(hipEvent_t *a, hipEvent_t *b)
     t.pending.push_back(KernelTimer::Ev{*a, *b, sc->k, sc->n++ == 0});
     return true;
 }
-static void drain_timer(nvca_ctx *ctx)     // stream must be idle
+static void drain_timer_now(nvca_ctx *ctx)
 {
     KernelTimer &t = ctx->timer;
     std::vector<KernelTimer::Ev> later;
+    bool stop = false;
     for (auto &e : t.pending) {
         float ms = 0;
+        // kernels finish in launch order: after the first pair that is not ready (a batch still in flight between
+        // submit and collect) nothing later is either, and asking again for every one of them is not free
+        if (stop || hipEventQuery(e.b) == hipErrorNotReady) { stop = true; later.push_back(e); continue; }
         const hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
-        if (r == hipErrorNotReady) { later.push_back(e); continue; }       // a batch still in flight (submit / collect)
+        if (r == hipErrorNotReady) { stop = true; later.push_back(e); continue; }
         if (r == hipSuccess) { t.total_ms[e.k] += ms; if (e.first) t.launches[e.k]++; }
         t.pool.push_back(e.a); t.pool.push_back(e.b);
     }
     t.pending.swap(later);
+}
+// Event pairs are turned into times when somebody asks (nvca_ctx_kernel_timing) or when many have piled up: querying them
+// after every batch costs more than it looks while another batch is executing.
+static void drain_timer(nvca_ctx *ctx)
+{
+    if (ctx->timer.pending.size() > 4096) drain_timer_now(ctx);
 }
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -627,7 +637,7 @@ int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    drain_timer(ctx);
+    drain_timer_now(ctx);
     for (int k = 0; k < NVCA_K_COUNT; k++) {
         if (total_ms) total_ms[k] = ctx->timer.total_ms[k];
         if (launches) launches[k] = ctx->timer.launches[k];
