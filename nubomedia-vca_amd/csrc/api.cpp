@@ -1308,7 +1308,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     if (n < 0 || (n > 0 && (!streams || !frames))) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
-    ws.cur_res = res;
+    struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);   // every other entry point works on set 0
     tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();
     std::vector<FrameWork> &work = tk.work;
     // ---- pass 1: geometry + gating, in frame order
@@ -1427,7 +1427,7 @@ static int face_collect(nvca_ctx *ctx, int res, FaceTicket &tk, nvca_rect *out, 
 {
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
-    ws.cur_res = res;
+    struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);
     const int n = tk.n;
     hipError_t he = hipEventSynchronize(tk.done);
     if (he != hipSuccess) { ctx->set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); face_release(tk); return NVCA_ERR_HIP; }

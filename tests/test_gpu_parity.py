@@ -388,6 +388,8 @@ def test_face_batch_submit_collect(ctx, casc, orc_cascade):
         pending = nxt
     with pytest.raises(capi.NvcaError):
         ctx.face_batch_process(streams, fr(0))                 # synchronous call while a batch is in flight: refused
+    g = orc.equalize_hist(synth.make_gray(320, 240, 5, "natural", [(60, 40, 120)]))
+    assert np.array_equal(ctx.detect_multiscale(casc, g, 1.2, 3), orc.detect_multiscale(orc_cascade, g, 1.2, 3))   # other entry points may run meanwhile
     got.append(ctx.face_batch_collect(pending))
     seen = 0
     for t in range(T):
