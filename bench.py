@@ -109,10 +109,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hook for a one-GPU box: NVCA_BENCH_REHEARSAL=1 runs every rank on device 0 with the gloo backend, so the
+    # N > 1 code path (barriers, max-over-ranks clock, per-tick gather) can be exercised without N GPUs
+    rehearsal = os.environ.get("NVCA_BENCH_REHEARSAL") is not None
+    if rehearsal:
+        local_rank = 0
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if rehearsal else dev
 
     from nubovca import capi, synth
     if args.workload == "streams720p":
@@ -172,7 +181,7 @@ def main():
         torch.cuda.synchronize()
     tick = [0]
     from nubovca import sharding
-    gather = sharding.TableGather(device=dev) if world > 1 else None
+    gather = sharding.TableGather(device=coll_dev) if world > 1 else None
 
     # serving loop: two batches in flight -- the next batch is queued before the previous one is unpacked, so the host
     # work between batches overlaps the GPU.  K steps = K submits + K collects; one batch stays in flight across steps.
@@ -217,7 +226,7 @@ def main():
     ctx.enable_kernel_timing(False)
     n_boxes = float(np.mean([len(b) for b, _ in res]))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
