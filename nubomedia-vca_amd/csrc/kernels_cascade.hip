@@ -979,19 +979,21 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
             NVCA_LAUNCH(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
         if (a.tile_blocks_per_frame > 0) {
-            static int lds_allowed = 0;          // dynamic LDS above 64 KiB has to be granted once
-            if (a.tile_lds > lds_allowed) {
+            static int lds_allowed[64] = {0};    // dynamic LDS above 64 KiB has to be granted once per device (entry points hold the context lock)
+            int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+            if (a.tile_lds > lds_allowed[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
-                lds_allowed = a.tile_lds;
+                lds_allowed[dev] = a.tile_lds;
             }
             NVCA_LAUNCH(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 5) {
         if (a.band_blocks_per_frame > 0) {
-            static int lds_allowed_b = 0;
-            if (a.tile_lds > lds_allowed_b) {
+            static int lds_allowed_b[64] = {0};
+            int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+            if (a.tile_lds > lds_allowed_b[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_band), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
-                lds_allowed_b = a.tile_lds;
+                lds_allowed_b[dev] = a.tile_lds;
             }
             NVCA_LAUNCH(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
