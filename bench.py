@@ -251,13 +251,22 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if dom and os.path.exists(tpath):
+        # the PMC-derived per-launch figures only describe the configuration they were collected on
+        pmc_ok = False
+        if os.path.exists(tpath):
+            try:
+                cfg = json.load(open(tpath)).get("_config", {})
+                pmc_ok = (cfg.get("workload") == args.workload and cfg.get("width") == W and cfg.get("height") == H and
+                          cfg.get("frames_per_launch") == F and not args.host_frames and (w, h) == (W, H))
+            except Exception:
+                pmc_ok = False
+        if dom and pmc_ok:
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         lds = None
-        if dom and os.path.exists(tpath):
+        if dom and pmc_ok:
             try:        # the dominant kernel works out of LDS: also price it against the LDS peak
                 lb = json.load(open(tpath)).get(dom, {}).get("lds_bytes_per_launch")
                 if lb:
