@@ -210,6 +210,61 @@ def test_detect_random_geometries(ctx, casc, casc_small, orc_cascade, orc_small)
     assert checked > 100
 
 
+def _rect_cascade_xml(ow, oh, seed, stage_sizes=(3, 8, 12, 16, 20, 24, 28)):
+    """a stump cascade with a RECTANGULAR window, like haarcascade_mcs_mouth (25x15), _nose (18x15), _eyes (18x12), _ears
+    (12x20): random 2- and 3-rect features inside ow x oh, vote sums symmetric around 0 (about half of all windows pass a
+    stage), so a handful of windows survive seven stages on any image."""
+    from nubovca import synth
+    rng = np.random.RandomState(seed)
+    stages = []
+    for n in stage_sizes:
+        feats, thr, lv, rv = [], [], [], []
+        for _ in range(n):
+            while True:
+                w, h = int(rng.randint(2, ow + 1)), int(rng.randint(2, oh + 1))
+                x, y = int(rng.randint(0, ow - w + 1)), int(rng.randint(0, oh - h + 1))
+                kind = int(rng.randint(0, 4))
+                if kind == 0 and w % 2 == 0:
+                    f = [(x, y, w, h, -1.0), (x + w // 2, y, w // 2, h, 2.0)]; break
+                if kind == 1 and h % 2 == 0:
+                    f = [(x, y, w, h, -1.0), (x, y + h // 2, w, h // 2, 2.0)]; break
+                if kind == 2 and w % 3 == 0:
+                    f = [(x, y, w, h, -1.0), (x + w // 3, y, w // 3, h, 3.0)]; break
+                if kind == 3 and w % 2 == 0 and h % 2 == 0:
+                    f = [(x, y, w, h, -1.0), (x, y, w // 2, h // 2, 2.0), (x + w // 2, y + h // 2, w // 2, h // 2, 2.0)]; break
+            a = float(rng.uniform(0.3, 1.0))
+            feats.append(f); thr.append(float(rng.normal(0, 0.02))); lv.append(-a if rng.rand() < 0.5 else a); rv.append(-lv[-1])
+        stages.append(dict(features=feats, thresholds=thr, left=lv, right=rv, stage_threshold=float(rng.uniform(-0.3, 0.1))))
+    return synth.cascade_to_xml(dict(name="rect_window_%dx%d" % (ow, oh), size=(ow, oh), stages=stages))
+
+
+@pytest.mark.parametrize("ow,oh", [(25, 15), (18, 12), (12, 20), (18, 15)])
+def test_rectangular_window_cascades(ctx, ow, oh):
+    """the mcs_* cascades the part detectors load have non-square windows: all three scan variants, both policies"""
+    import orc
+    from nubovca import capi, synth
+    xml = _rect_cascade_xml(ow, oh, 7 * ow + oh)
+    c, oc = ctx.load_cascade_xml(xml), orc.parse_cascade_xml(xml)
+    total = 0
+    for it, (w, h, kind, sf) in enumerate([(333, 251, "natural", 1.1), (200, 150, "noise", 1.2), (640, 360, "gradient", 1.15)]):
+        g = orc.equalize_hist(synth.make_gray(w, h, 50 + it, kind))
+        eraw = orc.detect_raw(oc, g, sf, 0, (0, 0))
+        assert np.array_equal(ctx.detect_raw(c, g, sf, 0, (0, 0)), eraw), (ow, oh, w, h)
+        total += len(eraw)
+        assert np.array_equal(ctx.detect_multiscale(c, g, sf, 2, 0, (ow + 5, oh + 3)), orc.detect_multiscale(oc, g, sf, 2, 0, (ow + 5, oh + 3)))
+        assert np.array_equal(ctx.detect_multiscale(c, g, sf, 2, capi.HAAR_SCALE_IMAGE, (3, 3)),
+                              orc.detect_multiscale(oc, g, sf, 2, capi.HAAR_SCALE_IMAGE, (3, 3)))
+        assert np.array_equal(ctx.detect_multiscale(c, g, sf, 3, capi.HAAR_FIND_BIGGEST_OBJECT, (1, 1)),
+                              orc.detect_multiscale(oc, g, sf, 3, capi.HAAR_FIND_BIGGEST_OBJECT, (1, 1)))
+    assert total > 20
+    ctx.set_sum_policy(capi.SUM_F64)
+    try:
+        g = orc.equalize_hist(synth.make_gray(300, 200, 9, "natural"))
+        assert np.array_equal(ctx.detect_raw(c, g, 1.1, 0, (0, 0)), orc.detect_raw(oc, g, 1.1, 0, (0, 0), policy=orc.SUM_F64))
+    finally:
+        ctx.set_sum_policy(capi.SUM_F32PAIR)
+
+
 def test_detect_f64_policy(ctx, casc, orc_cascade):
     import orc
     from nubovca import capi, synth
