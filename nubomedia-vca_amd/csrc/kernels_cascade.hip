@@ -507,8 +507,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     // queue counters rotate over three words: stage s reads qn[cin], appends to qn[cout] and clears the third one, which
     // nobody touches during this stage and which the next stage appends to -- one barrier per stage instead of two
     int cin = 0;
-    int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    if (a.exp >= 10 && a.exp - 10 < last) last = a.exp - 10;
+    const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
     for (int s = 1; s < last; s++) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
         const int n = L.qn[cin];
@@ -571,7 +570,6 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         cur ^= 1; cin = cout;
     }
     __syncthreads();
-    if (a.exp) return;
     const int nh = L.qn[cin];
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
@@ -601,7 +599,6 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileLds L = carve_tile(lds, t);
     tile_fill(a, t, sc, slot, L);
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
-    if (a.exp == 1) return;
     __syncthreads();                 // qn zeroed
     // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
     for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
@@ -614,7 +611,6 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
         }
         queue_push(keep, w, L.q0, &L.qn[0]);
     }
-    if (a.exp == 2) return;
     tile_stages<false>(a, t, sc, slot, L);
 }
 
