@@ -89,3 +89,38 @@ def test_integral_ones_and_random():
 def test_flip():
     img = np.arange(12, dtype=np.uint8).reshape(3, 4)
     assert np.array_equal(orc.flip_h(img), img[:, ::-1])
+
+
+def test_gray_of_grey_pixels_is_identity():
+    """the fixed-point weights add up to 1 << 14: (v, v, v) -> v for every v"""
+    import orc
+    v = np.arange(256, dtype=np.uint8)
+    img = np.repeat(v[None, :, None], 3, axis=2).copy()
+    assert np.array_equal(orc.bgr2gray(img)[0], v)
+
+
+def test_integral_closed_forms():
+    """horizontal ramp p(x, y) = x: sum[y][x] = y * x (x - 1) / 2, sqsum[y][x] = y * (x - 1) x (2 x - 1) / 6"""
+    import orc
+    w, h = 200, 37
+    img = np.tile(np.arange(w, dtype=np.uint8), (h, 1))
+    s, q = orc.integral(img)
+    X, Y = np.meshgrid(np.arange(w + 1, dtype=np.int64), np.arange(h + 1, dtype=np.int64))
+    assert np.array_equal(s.astype(np.int64), Y * X * (X - 1) // 2)
+    assert np.array_equal(q, (Y * (X - 1) * X * (2 * X - 1) // 6).astype(np.float64))
+
+
+def test_equalize_ramp_with_equal_bins():
+    """256 levels, n pixels each: lut[j] = cvRound(j * n * 255 / (256 n - n)) = j (the scale is exactly 1 / n)"""
+    import orc
+    n = 5
+    img = np.repeat(np.arange(256, dtype=np.uint8), n).reshape(16, 16 * n)
+    assert np.array_equal(orc.equalize_hist(img), img)
+
+
+def test_resize_constant_rows_stay_constant():
+    """bilinear weights of a destination pixel add up to 2048 * 2048: a constant image stays constant at any ratio"""
+    import orc
+    for (sw, sh, dw, dh) in [(97, 61, 41, 29), (640, 480, 213, 160), (33, 17, 100, 50)]:
+        img = np.full((sh, sw), 173, np.uint8)
+        assert np.all(orc.resize_linear(img, dw, dh) == 173)
