@@ -141,14 +141,14 @@ struct GeomPlan {
 
 DetectPlan::~DetectPlan()
 {
-    d_scales.release(); d_stumps.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tstumps.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release(); d_blob.release();
+    release_tables();
+    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
 {
     struct Item { DevBuf *d; const void *h; size_t n; } items[] = {
         {&d_scales, scales.data(), scales.size() * sizeof(ScaleRec)},
-        {&d_stumps, stumps.data(), stumps.size() * sizeof(StumpRec)},
         {&d_stages, stages.data(), stages.size() * sizeof(StageRec)},
         {&d_strips, strips.data(), strips.size() * sizeof(StripRec)},
         {&d_pos, pos.data(), pos.size() * sizeof(int)},
@@ -156,7 +156,6 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_tasks, tasks.data(), tasks.size() * sizeof(unsigned)},
         {&d_tiles, tiles.data(), tiles.size() * sizeof(TileRec)},
         {&d_tile_order, tile_order.data(), tile_order.size() * sizeof(int)},
-        {&d_tstumps, tstumps.data(), tstumps.size() * sizeof(TStumpRec)},
         {&d_tcoords, tcoords.data(), tcoords.size() * sizeof(unsigned short)},
         {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
@@ -321,7 +320,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         CascadeArgs a;
         a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
         a.sum_slot = sum_slot; a.spitch = spitch;
-        a.scales = dp.d_scales.as<ScaleRec>(); a.stumps = dp.d_stumps.as<StumpRec>();
+        a.scales = dp.d_scales.as<ScaleRec>();
         a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
@@ -330,7 +329,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.deep_stage = dp.deep_stage; a.deep = ws.deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
-        a.tile_blocks_per_frame = dp.tile_blocks_per_frame; a.tstumps = dp.d_tstumps.as<TStumpRec>();
+        a.tile_blocks_per_frame = dp.tile_blocks_per_frame;
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
         a.list_from = 0;
         a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
@@ -521,7 +520,7 @@ static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, 
     int rc = upload_tab(ctx, *gp);
     if (rc) return rc;
     std::string err;
-    rc = gp->det.build_scale_cascade(casc->c, cols, rows, gp->g.spitch, sf, minw, minh, maxw, maxh, err);
+    rc = gp->det.build_scale_cascade(ctx, casc->c, cols, rows, gp->g.spitch, sf, minw, minh, maxw, maxh, err);
     if (rc) { ctx->set_error(err); return rc; }
     if (gp->det.scales.size() > 63) { ctx->set_error("too many scales"); return NVCA_ERR_ARG; }
     rc = gp->det.upload(ctx);
@@ -540,6 +539,7 @@ nvca_ctx::nvca_ctx() {}
 nvca_ctx::~nvca_ctx()
 {
     plans.clear();
+    nvca::free_scale_tables(this);
     if (ws) ws->release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     for (auto e : timer.pool) (void)hipEventDestroy(e);
@@ -691,7 +691,11 @@ void nvca_cascade_free(nvca_cascade *c)
         for (auto it = c->ctx->plans.begin(); it != c->ctx->plans.end();) {
             const std::string &k = it->first;
             snprintf(pre, sizeof(pre), "|%llu|", (unsigned long long)c->c.uid);
-            if (k.size() > 1 && k.compare(1, strlen(pre), pre) == 0) { (void)hipDeviceSynchronize(); it = c->ctx->plans.erase(it); }
+            if (k.find(pre) != std::string::npos && it->second->inflight == 0) { (void)hipDeviceSynchronize(); it = c->ctx->plans.erase(it); }
+            else ++it;
+        }
+        for (auto it = c->ctx->scale_tables.begin(); it != c->ctx->scale_tables.end();) {      // and its stump tables
+            if (it->first.first == (uint64_t)c->c.uid && it->second->refs == 0) { (void)hipDeviceSynchronize(); delete it->second; it = c->ctx->scale_tables.erase(it); }
             else ++it;
         }
     }
@@ -989,7 +993,7 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         }
         if (!np->lv.empty()) {
             std::string err;
-            if ((rc = np->det.build_custom(c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
+            if ((rc = np->det.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
             if ((rc = np->det.upload(ctx))) return rc;
             std::vector<PyrLevelDev> dl(np->lv.size());
             np->pyr_ok = getenv("NVCA_PYR_OFF") == nullptr;
@@ -1103,10 +1107,17 @@ static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const vo
             if (!sp.xs.empty() && !sp.ys.empty() && !neg) {
                 std::vector<ScaleSpec> one; one.push_back(std::move(sp));
                 DetectPlan dp; std::string err;
-                if ((rc = dp.build_custom(c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
+                auto h0 = std::chrono::steady_clock::now();
+                if ((rc = dp.build_custom(ctx, c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
+                auto h1 = std::chrono::steady_clock::now();
                 if ((rc = dp.upload(ctx))) return rc;
+                auto h2 = std::chrono::steady_clock::now();
                 std::vector<std::vector<nvca_rect>> raw;
                 if ((rc = run_cascade(ctx, dp, g.sum_slot, g.spitch, 1, raw))) return rc;
+                auto h3 = std::chrono::steady_clock::now();
+                { static const bool hp = getenv("NVCA_HOST_PROFILE") != nullptr;
+                  if (hp) { auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+                            fprintf(stderr, "[nvca host] find-biggest scale %.3f: build %ld us, upload %ld us, run %ld us (%zu x %zu grid)\n", factor, us(h0, h1), us(h1, h2), us(h2, h3), dp.specs[0].xs.size(), dp.specs[0].ys.size()); } }
                 all.insert(all.end(), raw[0].begin(), raw[0].end());
             }
         }

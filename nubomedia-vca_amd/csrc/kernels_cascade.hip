@@ -31,24 +31,22 @@ namespace nvca {
 
 // Wave-uniform table records are read through the constant address space: the compiler then issues scalar loads
 // (s_load) for them even though the kernels also store to global memory.  The tables are never written by a kernel.
-typedef const __attribute__((address_space(4))) StumpRec CStumpRec;
 typedef const __attribute__((address_space(4))) TStumpRec CTStumpRec;
 
 __device__ __forceinline__ int ldsum(const int *__restrict__ sum, unsigned idx) { return sum[idx]; }
 
-template <class IntPtr>
-__device__ __forceinline__ int rect_sum(const int *__restrict__ sum, unsigned off, IntPtr p)
-{
-    return ldsum(sum, off + (unsigned)p[0]) - ldsum(sum, off + (unsigned)p[1]) - ldsum(sum, off + (unsigned)p[2]) +
-           ldsum(sum, off + (unsigned)p[3]);
-}
-
-// feature value of one stump on one window (v) against its threshold: returns the vote
+// feature value of one stump on one window (v) against its threshold: returns the vote.  Records hold corner columns /
+// rows relative to the window (geometry-independent tables); the plane offset is row * pitch + column.
 template <bool PAIR, class Rec, bool UNI = false>
-__device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, double vnf, Rec &f)
+__device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsigned off, int pitch, double vnf, Rec &f)
 {
-    const int s0 = rect_sum(sum, off, f.p[0]);
-    const int s1 = rect_sum(sum, off, f.p[1]);
+    auto rs = [&](int q) {
+        const unsigned r0 = off + (unsigned)(f.y0[q] * pitch), r1 = off + (unsigned)(f.y1[q] * pitch);
+        return ldsum(sum, r0 + (unsigned)f.x0[q]) - ldsum(sum, r0 + (unsigned)f.x1[q]) - ldsum(sum, r1 + (unsigned)f.x0[q]) +
+               ldsum(sum, r1 + (unsigned)f.x1[q]);
+    };
+    const int s0 = rs(0);
+    const int s1 = rs(1);
     const double t = f.thr * vnf;                       // node->threshold * variance_norm_factor
     double v;
     if (PAIR) {
@@ -58,7 +56,7 @@ __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsign
         v = (double)((float)s0 * f.w[0]);
         v += (double)((float)s1 * f.w[1]);
         if (f.nrect == 3) {
-            const int s2 = rect_sum(sum, off, f.p[2]);
+            const int s2 = rs(2);
             v += (double)((float)s2 * f.w[2]);
         }
     }
@@ -69,19 +67,19 @@ __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsign
 
 // one stage on one window per lane; recs are wave-uniform (scalar loads)
 template <bool PAIR>
-__device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned off, double vnf,
-                                           CStumpRec *recs, int count, float stage_thr)
+__device__ __forceinline__ bool eval_stage(const int *__restrict__ sum, unsigned off, int pitch, double vnf,
+                                           CTStumpRec *recs, int count, float stage_thr)
 {
     double stage_sum = 0.0;
-    for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR, CStumpRec, true>(sum, off, vnf, recs[j]);
+    for (int j = 0; j < count; j++) stage_sum += stump_vote<PAIR, CTStumpRec, true>(sum, off, pitch, vnf, recs[j]);
     return !(stage_sum < (double)stage_thr);
 }
 
-__device__ __forceinline__ bool run_stage(const int *__restrict__ sum, unsigned off, double vnf,
-                                          CStumpRec *recs, const StageRec &st, int pair_policy)
+__device__ __forceinline__ bool run_stage(const int *__restrict__ sum, unsigned off, int pitch, double vnf,
+                                          CTStumpRec *recs, const StageRec &st, int pair_policy)
 {
-    if (pair_policy && (st.flags & 1)) return eval_stage<true>(sum, off, vnf, recs + st.first, st.count, st.thr);
-    return eval_stage<false>(sum, off, vnf, recs + st.first, st.count, st.thr);
+    if (pair_policy && (st.flags & 1)) return eval_stage<true>(sum, off, pitch, vnf, recs + st.first, st.count, st.thr);
+    return eval_stage<false>(sum, off, pitch, vnf, recs + st.first, st.count, st.thr);
 }
 
 // block -> (slot, local index): 1-D grid, frame-major (few integral planes live at a time); within a
@@ -126,7 +124,7 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
         vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
         vnf = vnf * sc.inv_area - mean * mean;
         vnf = vnf >= 0. ? sqrt(vnf) : 1.;
-        pass0 = run_stage(sum, off, vnf, (CStumpRec *)(a.stumps + sc.stump_off), a.stages[0], a.pair_policy);
+        pass0 = run_stage(sum, off, sc.pitch, vnf, (CTStumpRec *)sc.trecs, a.stages[0], a.pair_policy);
     }
     const unsigned long long fb = __ballot(active && !pass0);
     const size_t o = (size_t)slot * a.ntasks + t;
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     // a strip covers columns [ix0, ix0 + ncols) of nrows scan rows (rows longer than a strip are cut into segments)
     const int endX = strip.ncols, ix0 = strip.ix0, nwin = strip.nrows * endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-    CStumpRec *recs = (CStumpRec *)(a.stumps + sc.stump_off);
+    CTStumpRec *recs = (CTStumpRec *)sc.trecs;
     const int *__restrict__ xpos = a.pos + sc.xpos_off;
     const int *__restrict__ ypos = a.pos + sc.ypos_off + strip.iy0;
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)strip.iy0 * sc.wpr;
@@ -226,10 +224,10 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
                     for (int j = pu; j < st.count; j += P)
-                        part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
+                        part += pair ? stump_vote<true>(sum, off, sc.pitch, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, sc.pitch, vnf, recs[st.first + j]);
                 } else {
                     for (int j = p; j < st.count; j += P)
-                        part += pair ? stump_vote<true>(sum, off, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, vnf, recs[st.first + j]);
+                        part += pair ? stump_vote<true>(sum, off, sc.pitch, vnf, recs[st.first + j]) : stump_vote<false>(sum, off, sc.pitch, vnf, recs[st.first + j]);
                 }
             }
             psum[tid] = part;
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
                 const int r = w / endX, ix = ix0 + (w - r * endX);
                 const unsigned off = (unsigned)(ypos[r] * sc.pitch + xpos[ix]);
                 const double vnf = vnfp[((size_t)r * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-                pass = run_stage(sum, off, vnf, recs, st, a.pair_policy);
+                pass = run_stage(sum, off, sc.pitch, vnf, recs, st, a.pair_policy);
             }
             const unsigned long long pm = __ballot(pass);
             if (pm) {
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
             const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
             const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
             const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-            pass = run_stage(sum, off, vnf, (CStumpRec *)(a.stumps + sc.stump_off), st, a.pair_policy);
+            pass = run_stage(sum, off, sc.pitch, vnf, (CTStumpRec *)sc.trecs, st, a.pair_policy);
         }
         const unsigned long long pm = __ballot(pass);
         if (!pm) continue;
@@ -495,7 +493,7 @@ template <bool VNF_LDS>
 __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L)
 {
     const int tid = threadIdx.x;
-    CTStumpRec *recs = (CTStumpRec *)(a.tstumps + t.stump_off);
+    CTStumpRec *recs = (CTStumpRec *)sc.trecs;
     const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
     const double *__restrict__ vnfp = a.vnf + vbase;
     auto vnf_of = [&](int w) {
@@ -641,7 +639,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         __syncthreads();             // previous tile completely done with LDS
         const TileRec t = a.tiles[b.first_tile + ti];
         const TileLds L = carve_tile(lds, t);
-        CTStumpRec *recs = (CTStumpRec *)(a.tstumps + t.stump_off);
+        CTStumpRec *recs = (CTStumpRec *)sc.trecs;
         tile_fill(a, t, sc, slot, L);
         __syncthreads();
         // variance + stage 0 for every window of the tile; a wave covers two window rows
@@ -740,10 +738,9 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
         const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
         const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
         const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-        const StumpRec *__restrict__ recs = a.stumps + sc.stump_off;
         DeepRec d; d.ncol = 0;
         if (a.deeprecs) d = a.deeprecs[s];
-        CTStumpRec *trecs = (CTStumpRec *)(a.tstumps + d.stump_off);
+        CTStumpRec *trecs = (CTStumpRec *)sc.trecs;
         bool alive = true, patch = false;
         for (int st_i = a.deep_stage; st_i < a.nstages; st_i++) {
             const StageRec st = a.stages[st_i];
@@ -765,8 +762,7 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
             auto vote = [&](int j) {
                 if (patch) return pair ? tile_vote<true, false>(T, cmap, rmap, 0, 0, vnf, trecs[st.first + j])
                                        : tile_vote<false, false>(T, cmap, rmap, 0, 0, vnf, trecs[st.first + j]);
-                const StumpRec &f = recs[st.first + j];
-                return pair ? stump_vote<true>(sum, off, vnf, f) : stump_vote<false>(sum, off, vnf, f);
+                return pair ? stump_vote<true>(sum, off, sc.pitch, vnf, trecs[st.first + j]) : stump_vote<false>(sum, off, sc.pitch, vnf, trecs[st.first + j]);
             };
             if (st.flags & 2) {                         // any summation order is exact
                 double p = 0.0;

@@ -34,6 +34,7 @@ struct Cascade {
     std::vector<float> alpha;
     bool stump_based = true;
     uint64_t uid = 0;       // identity for plan caching
+    mutable std::vector<unsigned char> stage_rec_cache;   // StageRec[] (plan.cpp, built on first use: the summation-order proof is per cascade)
 };
 
 // returns NVCA_OK or NVCA_ERR_PARSE / NVCA_ERR_UNSUPPORTED; err gets a message
@@ -42,16 +43,6 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
 // --------------------------------------------------------------------------
 // Device-side records (plain structs shared by host table builder and kernels)
 // --------------------------------------------------------------------------
-struct StumpRec {           // one weak classifier at one scale: 24 dwords
-    int    p[3][4];         // corner offsets (elements of the pitched sum plane), relative to the window origin
-    float  w[3];            // hidden weights (rect 0 re-balanced)
-    int    nrect;
-    double thr;             // (double)node->threshold           (float -> double is exact)
-    double a0, a1;          // (double)alpha[0] (sum < t), (double)alpha[1] (sum >= t)
-    double pad;
-};
-static_assert(sizeof(StumpRec) == 96, "StumpRec layout");
-
 struct StageRec {
     int first, count; float thr;
     int flags;              // bit 0: two_rects (every stump has 2 rects); bit 1: votes may be summed in any order
@@ -64,12 +55,13 @@ struct ScaleRec {           // one evaluated scale
     int    endX, endY;      // scan grid: ix in [0,endX), iy in [0,endY)
     int    eq[4];           // equRect corner offsets
     int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
-    int    stump_off;       // first StumpRec of this scale
+    int    stump_off;       // (unused)
     int    task_off;        // first stage-0 wave task (64 windows) of this scale
     int    wpr;             // wave tasks (64-bit reject words) per scan row
     int    adaptive;        // 1: OpenCV's adaptive x step applies (scale-cascade scan); 0: every grid point is visited
     double inv_area;
     double factor;
+    const struct TStumpRec *trecs;   // the cascade's stumps at this scale's factor (device; shared by every plan that uses the factor)
 };
 
 struct StripRec { int scale, iy0, nrows, ix0, ncols, pad0, pad1, pad2; };   // a block's share of the scan: nrows x ncols windows
@@ -155,6 +147,7 @@ struct PinnedBuf {
 };
 
 struct DetectPlan;   // plan.cpp
+struct ScaleTable;   // plan.cpp: one cascade at one scale factor (geometry-independent stump records), cached in the context
 struct FaceTicket;   // api.cpp
 void free_face_ticket(FaceTicket *t);
 struct GeomPlan;     // api.cpp
@@ -188,6 +181,7 @@ struct nvca_ctx {
     uint64_t next_uid = 1;
     nvca::KernelTimer timer;
     std::map<std::string, std::unique_ptr<nvca::GeomPlan>> plans;
+    std::map<std::pair<uint64_t, uint64_t>, nvca::ScaleTable *> scale_tables;   // (cascade uid, factor bits)
     std::unique_ptr<nvca::Workspace> ws;
     void *identity_lut = nullptr;     // 256 B on device
     std::recursive_mutex mu;          // serialises entry points: elements on different streaming threads share one context
@@ -281,11 +275,11 @@ struct CascadeArgs {
     const int *sum; const unsigned long long *sqsum;
     size_t sum_slot;               // elements between slots
     int spitch;
-    const ScaleRec *scales; const StumpRec *stumps; const StageRec *stages;
+    const ScaleRec *scales; const StageRec *stages;
     const StripRec *strips; const int *pos;
     const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
-    const TStumpRec *tstumps; const unsigned short *tcoords; int tile_lds;
+    const unsigned short *tcoords; int tile_lds;
     const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch;   // k_band
     const DeepRec *deeprecs;                  // [nscales] or null (k_deep: LDS patches)
     // global survivor lists (k_list_*): per-scale segments; counts per stage

@@ -74,34 +74,33 @@ void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw
     }
 }
 
-// cvSetImagesForHaarClassifierCascade for one scale; offsets use `pitch` (elements).
-void build_scale_tables(const Cascade &c, double factor, int pitch, ScaleRec &sr, StumpRec *out)
+// cvSetImagesForHaarClassifierCascade for one factor, geometry-independent (see plan.h)
+void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
 {
-    int ex = cv_round(factor), ey = ex;
-    int ew = cv_round((c.ow - 2) * factor), eh = cv_round((c.oh - 2) * factor);
-    double weight_scale = 1. / (ew * eh);
-    sr.winw = cv_round(c.ow * factor); sr.winh = cv_round(c.oh * factor);
-    sr.inv_area = weight_scale; sr.factor = factor;
-    sr.eq[0] = ey * pitch + ex;          sr.eq[1] = ey * pitch + ex + ew;
-    sr.eq[2] = (ey + eh) * pitch + ex;   sr.eq[3] = (ey + eh) * pitch + ex + ew;
+    t.factor = factor;
+    t.ex = cv_round(factor); t.ey = t.ex;
+    t.ew = cv_round((c.ow - 2) * factor); t.eh = cv_round((c.oh - 2) * factor);
+    const double weight_scale = 1. / (t.ew * t.eh);
+    t.winw = cv_round(c.ow * factor); t.winh = cv_round(c.oh * factor);
+    t.inv_area = weight_scale;
+    t.host.assign(c.cls.size(), TStumpRec());
     size_t k = 0;
     for (const HaarClassifier &hc : c.cls) {
         const HaarNode &n = c.nodes[hc.first_node];     // stump
-        StumpRec &r = out[k++];
+        TStumpRec &r = t.host[k++];
         memset(&r, 0, sizeof(r));
         double sum0 = 0, area0 = 0;
         for (int q = 0; q < n.nrect; q++) {
             int tx = cv_round(n.rect[q][0] * factor), tw = cv_round(n.rect[q][2] * factor);
             int ty = cv_round(n.rect[q][1] * factor), th = cv_round(n.rect[q][3] * factor);
             double correction_ratio = weight_scale;       // upright feature, CV_ADJUST_WEIGHTS 0
-            r.p[q][0] = ty * pitch + tx;        r.p[q][1] = ty * pitch + tx + tw;
-            r.p[q][2] = (ty + th) * pitch + tx; r.p[q][3] = (ty + th) * pitch + tx + tw;
+            r.x0[q] = tx; r.x1[q] = tx + tw; r.y0[q] = ty; r.y1[q] = ty + th;
             r.w[q] = (float)(n.weight[q] * correction_ratio);
             if (q == 0) area0 = tw * th;
             else {
-                float t = r.w[q] * tw;      // float * int -> float, evaluated left to right
-                t = t * th;
-                sum0 += t;
+                float tt = r.w[q] * tw;      // float * int -> float, evaluated left to right
+                tt = tt * th;
+                sum0 += tt;
             }
         }
         r.w[0] = (float)(-sum0 / area0);
@@ -179,36 +178,38 @@ nvca_rect DetectPlan::hit_rect(unsigned key) const
     return nvca_rect{x, y, sp.out_w, sp.out_h};
 }
 
-int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool allow_tiles, std::string &err)
+int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&in, bool allow_tiles, std::string &err)
 {
     if (!c.stump_based) { err = "tree weak classifiers are not supported by the device evaluator yet"; return NVCA_ERR_UNSUPPORTED; }
     specs = std::move(in);
     nstumps = (int)c.cls.size();
-    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); stumps.clear();
+    scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); release_tables();
     if (const char *e = getenv("NVCA_DEEP_STAGE")) deep_stage = std::max(1, atoi(e));
     // stages 1 .. deep_stage-1 run on LDS lattice tiles (k_tile); NVCA_TILES=0 selects the older row strips (k_strip)
     bool use_tiles = true;
     if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
     (void)allow_tiles;
-    tstumps.clear(); tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
+    tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
     if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
-    build_stage_recs(c, stages);
+    if (c.stage_rec_cache.empty()) {            // once per cascade
+        std::vector<StageRec> tmp; build_stage_recs(c, tmp);
+        c.stage_rec_cache.resize(tmp.size() * sizeof(StageRec));
+        if (!tmp.empty()) memcpy(c.stage_rec_cache.data(), tmp.data(), c.stage_rec_cache.size());
+    }
+    stages.resize(c.stage_rec_cache.size() / sizeof(StageRec));
+    if (!stages.empty()) memcpy(stages.data(), c.stage_rec_cache.data(), c.stage_rec_cache.size());
     std::vector<long long> strip_w, tile_w;
-    double last_tf = -1; int last_pitch = -1, last_off = 0, last_toff = -1, last_tstump_src = -1;
     for (size_t s = 0; s < specs.size(); s++) {
         const ScaleSpec &sp = specs[s];
         const int pitch = sp.pitch;
         ScaleRec sr; memset(&sr, 0, sizeof(sr));
-        if (sp.table_factor == last_tf && pitch == last_pitch) {      // pyramid levels share one table
-            std::vector<StumpRec> tmp(nstumps);
-            build_scale_tables(c, sp.table_factor, pitch, sr, tmp.data());
-            sr.stump_off = last_off;
-        } else {
-            sr.stump_off = (int)stumps.size();
-            stumps.resize(stumps.size() + nstumps);
-            build_scale_tables(c, sp.table_factor, pitch, sr, &stumps[sr.stump_off]);
-            last_tf = sp.table_factor; last_pitch = pitch; last_off = sr.stump_off;
-        }
+        ScaleTable *tabp = get_scale_table(ctx, c, sp.table_factor);     // pyramid levels (factor 1) all share one table
+        if (!tabp) { err = "allocation failed (stump tables)"; return NVCA_ERR_NOMEM; }
+        tabp->refs++; tabs.push_back(tabp);
+        sr.winw = tabp->winw; sr.winh = tabp->winh; sr.inv_area = tabp->inv_area; sr.factor = tabp->factor;
+        sr.eq[0] = tabp->ey * pitch + tabp->ex;               sr.eq[1] = tabp->ey * pitch + tabp->ex + tabp->ew;
+        sr.eq[2] = (tabp->ey + tabp->eh) * pitch + tabp->ex;  sr.eq[3] = (tabp->ey + tabp->eh) * pitch + tabp->ex + tabp->ew;
+        sr.trecs = tabp->dev.as<TStumpRec>();
         sr.plane_off = sp.plane_off; sr.pitch = pitch; sr.adaptive = sp.adaptive;
         sr.endX = (int)sp.xs.size(); sr.endY = (int)sp.ys.size();
         if (sr.endX > 8191 || sr.endY > 8191) { err = "image too large for the candidate key"; return NVCA_ERR_ARG; }
@@ -223,7 +224,6 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
         scales.push_back(sr);
         if (sr.endX <= 0 || sr.endY <= 0) continue;
         const int *xp = &pos[sr.xpos_off], *yp = &pos[sr.ypos_off];
-        const StumpRec *tab = &stumps[sr.stump_off];
         // ---- LDS lattice tiles: stages 1 .. early_last-1 read only (window origin + scaled corner) samples; per tile of
         // n x n windows those are ~2.7 (n + 20) distinct columns and rows whatever the scale.  Stage exactly them.
         int tw = 0;
@@ -232,15 +232,7 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
         if (use_tiles && early_last > 1) {
             // stage 0 and the variance rectangle included: the band kernel evaluates them from the tile as well
             const int k0 = stages[0].first, k1 = stages[early_last - 1].first + stages[early_last - 1].count;
-            offx.push_back(sr.eq[0] % pitch); offx.push_back(sr.eq[3] % pitch);
-            offy.push_back(sr.eq[0] / pitch); offy.push_back(sr.eq[3] / pitch);
-            for (int k = k0; k < k1; k++)
-                for (int q = 0; q < tab[k].nrect; q++) {
-                    offx.push_back(tab[k].p[q][0] % pitch); offx.push_back(tab[k].p[q][3] % pitch);
-                    offy.push_back(tab[k].p[q][0] / pitch); offy.push_back(tab[k].p[q][3] / pitch);
-                }
-            std::sort(offx.begin(), offx.end()); offx.erase(std::unique(offx.begin(), offx.end()), offx.end());
-            std::sort(offy.begin(), offy.end()); offy.erase(std::unique(offy.begin(), offy.end()), offy.end());
+            { const auto &co = tabp->corner_offsets(k0, k1, true); offx = co.first; offy = co.second; }
             // distinct sample coordinates of windows [i0, i1) along one axis
             auto coords = [](const int *p, int i0, int i1, const std::vector<int> &off, std::vector<int> &out) {
                 out.clear();
@@ -264,20 +256,6 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
                 if (ok) break;
             }
             if (tw >= 1) {
-                const bool shared = sr.stump_off == last_tstump_src && last_toff >= 0;     // pyramid levels share one table
-                const int toff = shared ? last_toff : (int)tstumps.size();
-                last_toff = toff; last_tstump_src = sr.stump_off;
-                for (int k = 0; k < nstumps && !shared; k++) {
-                    TStumpRec r; memset(&r, 0, sizeof(r));
-                    const StumpRec &f = tab[k];
-                    for (int q = 0; q < f.nrect; q++) {
-                        r.x0[q] = f.p[q][0] % pitch; r.x1[q] = f.p[q][3] % pitch;
-                        r.y0[q] = f.p[q][0] / pitch; r.y1[q] = f.p[q][3] / pitch;
-                        r.w[q] = f.w[q];
-                    }
-                    r.nrect = f.nrect; r.thr = f.thr; r.a0 = f.a0; r.a1 = f.a1;
-                    tstumps.push_back(r);
-                }
                 for (int iy0 = 0; iy0 < sr.endY; iy0 += tw) {
                     coords(yp, iy0, std::min(iy0 + tw, sr.endY), offy, cy);
                     BandRec b; memset(&b, 0, sizeof(b));
@@ -296,7 +274,6 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
                         t.span_x = cx.back() - t.x0 + 1; t.span_y = cy.back() - t.y0 + 1;
                         t.col_off = (int)tcoords.size(); t.row_off = row_off;
                         for (int v : cx) tcoords.push_back((unsigned short)v);
-                        t.stump_off = toff;
                         tile_lds = std::max(tile_lds, tile_lds_bytes(t.ncol, t.nrow, t.span_x, t.span_y));
                         tiles.push_back(t);
                         tile_w.push_back((long long)t.nx * t.ny + 256);
@@ -332,23 +309,18 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
     deeprecs.clear();
     if (strips.empty() && !tiles.empty() && deep_stage < (int)stages.size() && getenv("NVCA_DEEP_LDS_OFF") == nullptr) {
         deeprecs.resize(scales.size());
-        std::vector<int> scale_toff(scales.size(), -1);
-        for (const TileRec &t : tiles) scale_toff[t.scale] = t.stump_off;
+        std::vector<char> tiled(scales.size(), 0);
+        for (const TileRec &t : tiles) tiled[t.scale] = 1;
         const int k0 = stages[deep_stage].first, k1 = stages.back().first + stages.back().count;
         for (size_t s = 0; s < scales.size(); s++) {
             DeepRec d; memset(&d, 0, sizeof(d));
-            if (scale_toff[s] >= 0) {
-                const TStumpRec *tr = &tstumps[scale_toff[s]];
-                std::vector<int> ox, oy;
-                for (int k = k0; k < k1; k++)
-                    for (int q = 0; q < (tr[k].nrect & 255); q++) { ox.push_back(tr[k].x0[q]); ox.push_back(tr[k].x1[q]); oy.push_back(tr[k].y0[q]); oy.push_back(tr[k].y1[q]); }
-                std::sort(ox.begin(), ox.end()); ox.erase(std::unique(ox.begin(), ox.end()), ox.end());
-                std::sort(oy.begin(), oy.end()); oy.erase(std::unique(oy.begin(), oy.end()), oy.end());
+            if (tiled[s]) {
+                const auto &co = tabs[s]->corner_offsets(k0, k1, false);
+                const std::vector<int> &ox = co.first, &oy = co.second;
                 if (!ox.empty() && (int)ox.size() <= kDeepMaxSide && (int)oy.size() <= kDeepMaxSide && ox.back() < kDeepMaxSpan && oy.back() < kDeepMaxSpan) {
                     d.col_off = (int)tcoords.size(); for (int v : ox) tcoords.push_back((unsigned short)v);
                     d.row_off = (int)tcoords.size(); for (int v : oy) tcoords.push_back((unsigned short)v);
                     d.ncol = (int)ox.size(); d.nrow = (int)oy.size(); d.span_x = ox.back() + 1; d.span_y = oy.back() + 1;
-                    d.stump_off = scale_toff[s];
                 }
             }
             deeprecs[s] = d;
@@ -376,7 +348,7 @@ int DetectPlan::build_custom(const Cascade &c, std::vector<ScaleSpec> &&in, bool
 
 // cvHaarDetectObjectsForROC, scale-cascade branch (flags without SCALE_IMAGE): one pair of integral planes,
 // features scaled by each factor, stride max(2, factor), adaptive x step.
-int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
+int DetectPlan::build_scale_cascade(nvca_ctx *ctx, const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                                     int minw, int minh, int maxw, int maxh, std::string &err)
 {
     std::vector<double> factors;
@@ -396,7 +368,58 @@ int DetectPlan::build_scale_cascade(const Cascade &c, int cols, int rows, int pi
         }
         sp.push_back(std::move(s));
     }
-    return build_custom(c, std::move(sp), true, err);
+    return build_custom(ctx, c, std::move(sp), true, err);
+}
+
+const std::pair<std::vector<int>, std::vector<int>> &ScaleTable::corner_offsets(int k0, int k1, bool with_eq)
+{
+    const auto key = std::make_pair(with_eq ? k0 : -1 - k0, k1);
+    auto it = offsets.find(key);
+    if (it != offsets.end()) return it->second;
+    std::vector<int> ox, oy;
+    if (with_eq) { ox.push_back(ex); ox.push_back(ex + ew); oy.push_back(ey); oy.push_back(ey + eh); }
+    for (int k = k0; k < k1; k++)
+        for (int q = 0; q < (host[k].nrect & 255); q++) { ox.push_back(host[k].x0[q]); ox.push_back(host[k].x1[q]); oy.push_back(host[k].y0[q]); oy.push_back(host[k].y1[q]); }
+    std::sort(ox.begin(), ox.end()); ox.erase(std::unique(ox.begin(), ox.end()), ox.end());
+    std::sort(oy.begin(), oy.end()); oy.erase(std::unique(oy.begin(), oy.end()), oy.end());
+    return offsets.emplace(key, std::make_pair(std::move(ox), std::move(oy))).first->second;
+}
+
+void DetectPlan::release_tables()
+{
+    for (ScaleTable *t : tabs) if (t && t->refs > 0) t->refs--;
+    tabs.clear();
+}
+
+// Stump tables depend on (cascade, factor) only -- not on the image: every scale-cascade plan draws on the same ladder
+// of factors 1.1^k, and a new ROI size (the part detectors meet one per face per frame) costs no table work at all.
+ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor)
+{
+    uint64_t fb; memcpy(&fb, &factor, sizeof(fb));
+    const auto key = std::make_pair((uint64_t)c.uid, fb);
+    auto it = ctx->scale_tables.find(key);
+    if (it != ctx->scale_tables.end()) { it->second->last_use = ++ctx->next_uid; return it->second; }
+    if (ctx->scale_tables.size() >= 768) {          // bounded: drop the least recently used table nobody references
+        auto victim = ctx->scale_tables.end();
+        for (auto jt = ctx->scale_tables.begin(); jt != ctx->scale_tables.end(); ++jt)
+            if (jt->second->refs == 0 && (victim == ctx->scale_tables.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+        if (victim != ctx->scale_tables.end()) { (void)hipStreamSynchronize(ctx->stream); delete victim->second; ctx->scale_tables.erase(victim); }
+    }
+    std::unique_ptr<ScaleTable> t(new ScaleTable());
+    build_scale_table(c, factor, *t);
+    const size_t bytes = t->host.size() * sizeof(TStumpRec);
+    if (t->dev.ensure(bytes ? bytes : 8)) { ctx->set_error("hipMalloc failed for a stump table"); return nullptr; }
+    if (bytes && hipMemcpy(t->dev.p, t->host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy failed for a stump table"); return nullptr; }
+    t->last_use = ++ctx->next_uid;
+    ScaleTable *raw = t.release();
+    ctx->scale_tables[key] = raw;
+    return raw;
+}
+
+void free_scale_tables(nvca_ctx *ctx)
+{
+    for (auto &kv : ctx->scale_tables) delete kv.second;
+    ctx->scale_tables.clear();
 }
 
 } // namespace nvca

@@ -6,7 +6,22 @@ namespace nvca {
 
 void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw, int minh,
                 int maxw, int maxh, bool findBiggest, std::vector<double> &factors);
-void build_scale_tables(const Cascade &c, double factor, int pitch, ScaleRec &sr, StumpRec *out);
+// cvSetImagesForHaarClassifierCascade for one factor, independent of the image geometry: corner columns / rows relative to
+// the window, re-balanced weights, equRect.  Cached per (cascade, factor) in the context and shared by all plans.
+struct ScaleTable {
+    std::vector<TStumpRec> host;
+    DevBuf dev;
+    int winw = 0, winh = 0, ex = 0, ey = 0, ew = 0, eh = 0;
+    double inv_area = 0, factor = 0;
+    int refs = 0; uint64_t last_use = 0;
+    // distinct corner columns / rows of the stumps of stage ranges (cached per range: plans ask again and again)
+    std::map<std::pair<int, int>, std::pair<std::vector<int>, std::vector<int>>> offsets;
+    const std::pair<std::vector<int>, std::vector<int>> &corner_offsets(int k0, int k1, bool with_eq);
+    ~ScaleTable() { dev.release(); }
+};
+void build_scale_table(const Cascade &c, double factor, ScaleTable &t);
+ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor);     // nullptr: allocation / copy failed (error set)
+void free_scale_tables(nvca_ctx *ctx);
 void build_stage_recs(const Cascade &c, std::vector<StageRec> &out);
 
 // one scan grid handed to the evaluator
@@ -26,7 +41,8 @@ struct DetectPlan {
     int cols = 0, rows = 0, spitch = 0;
     int nstumps = 0;
     std::vector<ScaleRec> scales;
-    std::vector<StumpRec> stumps;
+    std::vector<ScaleTable *> tabs;   // per scale (referenced: refs++ / refs-- in release_tables)
+    void release_tables();
     std::vector<StageRec> stages;
     std::vector<StripRec> strips;
     std::vector<int> pos;
@@ -35,7 +51,6 @@ struct DetectPlan {
     int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
     std::vector<TileRec> tiles;  // LDS lattice tiles (k_tile); empty: row strips (k_strip)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;
-    std::vector<TStumpRec> tstumps;
     std::vector<unsigned short> tcoords;
     int tile_lds = 0;            // dynamic LDS bytes of the largest tile
     std::vector<DeepRec> deeprecs;  // per scale (k_deep LDS patches); empty: not used
@@ -49,12 +64,12 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stumps, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tstumps, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off, d_blob;   // the table buffers are views into d_blob
+    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off, d_blob;   // the table buffers are views into d_blob
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
-    int build_custom(const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
+    int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
     nvca_rect hit_rect(unsigned key) const;
-    int build_scale_cascade(const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
+    int build_scale_cascade(nvca_ctx *ctx, const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                             int minw, int minh, int maxw, int maxh, std::string &err);
     int upload(nvca_ctx *ctx);
     ~DetectPlan();
