@@ -135,6 +135,7 @@ struct GeomPlan {
     std::vector<PyrLevel> lv;
     std::vector<std::unique_ptr<GeomPlan>> level_tabs;
     size_t gray_total = 0, plane_total = 0; int P = 0;
+    std::vector<int> fb_ladder;                               // FIND_BIGGEST: ladder position of each scale of the full-grid plan
     DevBuf d_pyr; int pyr_maxw = 0, pyr_maxh = 0; bool pyr_ok = false;   // device level table (one-launch pyramid kernels)
     ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); d_pyr.release(); }
 };
@@ -382,11 +383,12 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
 
 // after the stream has been synchronised: raw[b] / grouped[b] for the job's n frames
 static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job, std::vector<std::vector<nvca_rect>> &raw,
-                           std::vector<char> *grouped)
+                           std::vector<char> *grouped, std::vector<std::vector<int>> *scale_of = nullptr)
 {
     static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
     const int batch = job.n;
     raw.assign(batch, {});
+    if (scale_of) scale_of->assign(batch, {});
     if (grouped) grouped->assign(batch, 0);
     unsigned long long *hh = job.h_hits;
     if (job.dev_group) {
@@ -425,21 +427,24 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
     std::sort(hh + 1, hh + 1 + total);
     for (unsigned long long i = 0; i < total; i++) {
         const int slot = (int)(hh[1 + i] >> 32);
-        if (!job.dev_group || !(*grouped)[slot]) raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
+        if (!job.dev_group || !(*grouped)[slot]) {
+            raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
+            if (scale_of) (*scale_of)[slot].push_back((int)((unsigned)hh[1 + i] >> 26));
+        }
     }
     return NVCA_OK;
 }
 
 static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, int batch,
                        std::vector<std::vector<nvca_rect>> &raw, const int *group_thr = nullptr,
-                       std::vector<char> *grouped = nullptr)
+                       std::vector<char> *grouped = nullptr, std::vector<std::vector<int>> *scale_of = nullptr)
 {
     CascadeJob job; job.n = batch; job.total = batch;
     int rc = cascade_enqueue(ctx, dp, sum_slot, spitch, job, group_thr, grouped != nullptr);
     if (rc) return rc;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     drain_timer(ctx);
-    return cascade_collect(ctx, dp, job, raw, grouped);
+    return cascade_collect(ctx, dp, job, raw, grouped, scale_of);
 }
 
 static void group_all(std::vector<std::vector<nvca_rect>> &raw, int min_neighbors)
@@ -1063,8 +1068,7 @@ extern "C" {
 
 // cvHaarDetectObjectsForROC with CV_HAAR_FIND_BIGGEST_OBJECT (NOSE/kmsnosedetect.cpp:870-873, MOUTH/kmsmouthdetect.cpp:870-873,
 // EAR/kmseardetect.cpp:712-715): scale-cascade scan from the largest factor down; after the first grouped detection
-// the scan narrows to a region of interest and a minimum size.  Sequential across scales by definition, so the host
-// drives one launch set per scale.
+// the scan narrows to a region of interest and a minimum size.
 static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int cols, int rows, int stride,
                                int mem, double scaleFactor, int minNeighbors, int flags, int minw, int minh, int maxw,
                                int maxh, std::vector<nvca_rect> &out)
@@ -1077,50 +1081,113 @@ static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const vo
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
     if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, gray, stride, cols, rows, mem))) return rc;
     run_integral(ctx, g, nullptr, 1);
-    std::vector<nvca_rect> all;
-    nvca_rect scanROI{0, 0, 0, 0};
-    int n_factors = 0; double factor;
-    for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= scaleFactor)
-        ;
-    scaleFactor = 1. / scaleFactor; factor *= scaleFactor;
-    for (; n_factors-- > 0; factor *= scaleFactor) {
-        const double ystep = std::max(2., factor);
-        const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
-        int startX = 0, startY = 0;
-        int endX = cv_round((cols - winw) / ystep), endY = cv_round((rows - winh) / ystep);
-        if (winw < minw || winh < minh) break;
-        if (winw > maxw || winh > maxh) continue;
-        if (scanROI.w * scanROI.h > 0) {
-            startY = cv_round(scanROI.y / ystep); endY = cv_round((scanROI.y + scanROI.h - winh) / ystep);
-            startX = cv_round(scanROI.x / ystep); endX = cv_round((scanROI.x + scanROI.w - winw) / ystep);
-        }
-        if (endX > startX && endY > startY) {
+    // the ladder of factors, largest first, exactly as the serial loop walks it
+    struct Step { double factor, ystep; int winw, winh; };
+    std::vector<Step> ladder;
+    {
+        int n_factors = 0; double factor;
+        for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= scaleFactor)
+            ;
+        const double inv = 1. / scaleFactor; factor *= inv;
+        for (; n_factors-- > 0; factor *= inv) ladder.push_back(Step{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
+    }
+    // scan grid of one ladder step; false: nothing to scan there
+    auto make_spec = [&](const Step &st, int startX, int endX, int startY, int endY, ScaleSpec &sp) {
+        if (!(endX > startX && endY > startY)) return false;
+        sp = ScaleSpec();
+        sp.table_factor = st.factor; sp.plane_off = 0; sp.pitch = g.spitch; sp.plane_rows = rows + 1; sp.adaptive = 1;
+        sp.out_factor = 0; sp.out_w = st.winw; sp.out_h = st.winh;
+        for (int ix = startX; ix < endX; ix++) sp.xs.push_back(cv_round(ix * st.ystep));
+        for (int iy = startY; iy < endY; iy++) sp.ys.push_back(cv_round(iy * st.ystep));
+        // cvRunHaarClassifierCascadeSum returns -1 (no hit, step 1) outside the image: drop such grid points
+        while (!sp.xs.empty() && (sp.xs.back() + st.winw >= cols + 1)) sp.xs.pop_back();
+        while (!sp.ys.empty() && (sp.ys.back() + st.winh >= rows + 1)) sp.ys.pop_back();
+        const bool neg = (!sp.xs.empty() && sp.xs.front() < 0) || (!sp.ys.empty() && sp.ys.front() < 0);
+        return !sp.xs.empty() && !sp.ys.empty() && !neg;
+    };
+    // The serial loop changes its scan only once: after the first grouped detection it narrows to a region of interest and
+    // raises the minimum size.  So two launch sets do: (1) every step on its full grid (a cached plan per geometry),
+    // (2) once the region is known, the remaining steps on their narrowed grids.  The loop below replays the serial
+    // logic on those results, step by step.
+    std::vector<std::vector<nvca_rect>> hits(ladder.size());             // per ladder step, scan order
+    char key[256];
+    snprintf(key, sizeof(key), "FB|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, scaleFactor, minw, minh, maxw, maxh);
+    GeomPlan *p1 = find_plan(ctx, key);
+    if (!p1) {
+        std::unique_ptr<GeomPlan> np(new GeomPlan());
+        std::vector<ScaleSpec> specs;
+        for (size_t i = 0; i < ladder.size(); i++) {
+            const Step &st = ladder[i];
+            if (st.winw < minw || st.winh < minh) break;
+            if (st.winw > maxw || st.winh > maxh) continue;
             ScaleSpec sp;
-            sp.table_factor = factor; sp.plane_off = 0; sp.pitch = g.spitch; sp.plane_rows = rows + 1; sp.adaptive = 1;
-            sp.out_factor = 0; sp.out_w = winw; sp.out_h = winh;
-            for (int ix = startX; ix < endX; ix++) sp.xs.push_back(cv_round(ix * ystep));
-            for (int iy = startY; iy < endY; iy++) sp.ys.push_back(cv_round(iy * ystep));
-            // cvRunHaarClassifierCascadeSum returns -1 (no hit, step 1) outside the image: drop such grid points
-            while (!sp.xs.empty() && (sp.xs.back() + winw >= cols + 1)) sp.xs.pop_back();
-            while (!sp.ys.empty() && (sp.ys.back() + winh >= rows + 1)) sp.ys.pop_back();
-            bool neg = (!sp.xs.empty() && sp.xs.front() < 0) || (!sp.ys.empty() && sp.ys.front() < 0);
-            if (!sp.xs.empty() && !sp.ys.empty() && !neg) {
-                std::vector<ScaleSpec> one; one.push_back(std::move(sp));
-                DetectPlan dp; std::string err;
-                auto h0 = std::chrono::steady_clock::now();
-                if ((rc = dp.build_custom(ctx, c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
-                auto h1 = std::chrono::steady_clock::now();
-                if ((rc = dp.upload(ctx))) return rc;
-                auto h2 = std::chrono::steady_clock::now();
-                std::vector<std::vector<nvca_rect>> raw;
-                if ((rc = run_cascade(ctx, dp, g.sum_slot, g.spitch, 1, raw))) return rc;
-                auto h3 = std::chrono::steady_clock::now();
-                { static const bool hp = getenv("NVCA_HOST_PROFILE") != nullptr;
-                  if (hp) { auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-                            fprintf(stderr, "[nvca host] find-biggest scale %.3f: build %ld us, upload %ld us, run %ld us (%zu x %zu grid)\n", factor, us(h0, h1), us(h1, h2), us(h2, h3), dp.specs[0].xs.size(), dp.specs[0].ys.size()); } }
-                all.insert(all.end(), raw[0].begin(), raw[0].end());
+            if (make_spec(st, 0, cv_round((cols - st.winw) / st.ystep), 0, cv_round((rows - st.winh) / st.ystep), sp)) {
+                specs.push_back(std::move(sp)); np->fb_ladder.push_back((int)i);
+                if (specs.size() >= 63) break;               // (deeper ladders fall back to per-step evaluation below)
             }
         }
+        if (!specs.empty()) {
+            std::string err;
+            if ((rc = np->det.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
+            if ((rc = np->det.upload(ctx))) return rc;
+        }
+        p1 = store_plan(ctx, key, std::move(np));
+    }
+    std::vector<char> have(ladder.size(), 0);                            // steps whose scan result is in `hits`
+    auto run_set = [&](DetectPlan &dp, const std::vector<int> &ladder_of) {
+        std::vector<std::vector<nvca_rect>> raw;
+        std::vector<std::vector<int>> sc;
+        int r = run_cascade(ctx, dp, g.sum_slot, g.spitch, 1, raw, nullptr, nullptr, &sc);
+        if (r) return r;
+        for (size_t k = 0; k < raw[0].size(); k++) hits[ladder_of[sc[0][k]]].push_back(raw[0][k]);
+        for (int li : ladder_of) have[li] = 1;
+        return (int)NVCA_OK;
+    };
+    if (!p1->fb_ladder.empty() && (rc = run_set(p1->det, p1->fb_ladder))) return rc;
+    std::vector<nvca_rect> all;
+    nvca_rect scanROI{0, 0, 0, 0};
+    bool narrowed_done = false;
+    for (size_t i = 0; i < ladder.size(); i++) {
+        const Step &st = ladder[i];
+        if (st.winw < minw || st.winh < minh) break;
+        if (st.winw > maxw || st.winh > maxh) continue;
+        const bool narrowed = scanROI.w * scanROI.h > 0;
+        if (narrowed && !narrowed_done) {
+            // second launch set: this step and all later ones on the narrowed grids (nothing changes the scan any more)
+            narrowed_done = true;
+            std::vector<ScaleSpec> specs; std::vector<int> ladder_of;
+            for (size_t k = i; k < ladder.size() && specs.size() < 63; k++) {
+                const Step &sk = ladder[k];
+                hits[k].clear(); have[k] = 0;
+                if (sk.winw < minw || sk.winh < minh) break;
+                if (sk.winw > maxw || sk.winh > maxh) continue;
+                ScaleSpec sp;
+                if (make_spec(sk, cv_round(scanROI.x / sk.ystep), cv_round((scanROI.x + scanROI.w - sk.winw) / sk.ystep),
+                              cv_round(scanROI.y / sk.ystep), cv_round((scanROI.y + scanROI.h - sk.winh) / sk.ystep), sp)) {
+                    specs.push_back(std::move(sp)); ladder_of.push_back((int)k);
+                } else have[k] = 1;                          // nothing to scan at that step
+            }
+            if (!specs.empty()) {
+                DetectPlan dp; std::string err;
+                if ((rc = dp.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
+                if ((rc = dp.upload(ctx))) return rc;
+                if ((rc = run_set(dp, ladder_of))) return rc;
+            }
+        }
+        if (!have[i]) {                                      // not covered by a launch set (a ladder deeper than 63 steps): on its own
+            ScaleSpec sp;
+            const bool any = narrowed ? make_spec(st, cv_round(scanROI.x / st.ystep), cv_round((scanROI.x + scanROI.w - st.winw) / st.ystep),
+                                                  cv_round(scanROI.y / st.ystep), cv_round((scanROI.y + scanROI.h - st.winh) / st.ystep), sp)
+                                      : make_spec(st, 0, cv_round((cols - st.winw) / st.ystep), 0, cv_round((rows - st.winh) / st.ystep), sp);
+            if (any) {
+                std::vector<ScaleSpec> one; one.push_back(std::move(sp));
+                DetectPlan dp; std::string err;
+                if ((rc = dp.build_custom(ctx, c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
+                if ((rc = dp.upload(ctx))) return rc;
+                if ((rc = run_set(dp, std::vector<int>{(int)i}))) return rc;
+            }
+        }
+        all.insert(all.end(), hits[i].begin(), hits[i].end());
         if (!all.empty() && scanROI.w * scanROI.h == 0) {
             std::vector<nvca_rect> tmp(all);
             group_rectangles(tmp, std::max(minNeighbors, 1), 0.2);
