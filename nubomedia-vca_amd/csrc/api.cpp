@@ -136,8 +136,8 @@ struct GeomPlan {
     std::vector<std::unique_ptr<GeomPlan>> level_tabs;
     size_t gray_total = 0, plane_total = 0; int P = 0;
     std::vector<int> fb_ladder;                               // FIND_BIGGEST: ladder position of each scale of the full-grid plan
-    DevBuf d_pyr; int pyr_maxw = 0, pyr_maxh = 0; bool pyr_ok = false;   // device level table (one-launch pyramid kernels)
-    ~GeomPlan() { d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); d_pyr.release(); }
+    DevBuf d_pyr, d_level_tabs; int pyr_maxw = 0, pyr_maxh = 0; bool pyr_ok = false;   // device level table (one-launch pyramid kernels)
+    ~GeomPlan() { level_tabs.clear(); d_xofs.release(); d_yofs.release(); d_ialpha.release(); d_ibeta.release(); d_pyr.release(); d_level_tabs.release(); }
 };
 
 DetectPlan::~DetectPlan()
@@ -222,6 +222,27 @@ static int upload_tab(nvca_ctx *ctx, GeomPlan &gp)
     NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_yofs.p, t.yofs.data(), t.yofs.size() * 4, hipMemcpyHostToDevice));
     NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_ialpha.p, t.ialpha.data(), t.ialpha.size() * 2, hipMemcpyHostToDevice));
     NVCA_HIP_CHECK(ctx, hipMemcpy(gp.d_ibeta.p, t.ibeta.data(), t.ibeta.size() * 2, hipMemcpyHostToDevice));
+    return NVCA_OK;
+}
+
+// the resize tables of several levels in one allocation (owned by `blob`) and one copy; the levels' buffers become views
+static int upload_tabs(nvca_ctx *ctx, std::vector<std::unique_ptr<GeomPlan>> &levels, DevBuf &blob)
+{
+    auto al = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    size_t total = 0;
+    for (auto &gp : levels) { const ResizeTab &t = gp->tab; if (t.mode != 1) continue; total += al(t.xofs.size() * 4) + al(t.yofs.size() * 4) + al(t.ialpha.size() * 2) + al(t.ibeta.size() * 2); }
+    if (!total) return NVCA_OK;
+    std::vector<unsigned char> h(total);
+    if (blob.ensure(total)) { ctx->set_error("hipMalloc failed for resize tables"); return NVCA_ERR_NOMEM; }
+    size_t off = 0;
+    auto put = [&](DevBuf &d, const void *src, size_t n) { memcpy(h.data() + off, src, n); d.release(); d.p = (unsigned char *)blob.p + off; d.bytes = 0; off += al(n); };
+    for (auto &gp : levels) {
+        const ResizeTab &t = gp->tab;
+        if (t.mode != 1) continue;
+        put(gp->d_xofs, t.xofs.data(), t.xofs.size() * 4); put(gp->d_yofs, t.yofs.data(), t.yofs.size() * 4);
+        put(gp->d_ialpha, t.ialpha.data(), t.ialpha.size() * 2); put(gp->d_ibeta, t.ibeta.data(), t.ibeta.size() * 2);
+    }
+    NVCA_HIP_CHECK(ctx, hipMemcpy(blob.p, h.data(), total, hipMemcpyHostToDevice));
     return NVCA_OK;
 }
 
@@ -986,7 +1007,6 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         for (const PyrLevel &L : np->lv) {
             std::unique_ptr<GeomPlan> gp(new GeomPlan());
             build_resize_tab(cols, rows, L.szw, L.szh, gp->tab);
-            if ((rc = upload_tab(ctx, *gp))) return rc;
             np->level_tabs.push_back(std::move(gp));
             ScaleSpec sp;
             sp.table_factor = 1.; sp.plane_off = L.plane_off; sp.pitch = np->P; sp.plane_rows = L.szh + 1; sp.adaptive = 0;
@@ -996,6 +1016,7 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
             for (int y = 0; y < L.szh - c.oh; y += ystep) sp.ys.push_back(y);
             specs.push_back(std::move(sp));
         }
+        if ((rc = upload_tabs(ctx, np->level_tabs, np->d_level_tabs))) return rc;
         if (!np->lv.empty()) {
             std::string err;
             if ((rc = np->det.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
