@@ -17,7 +17,9 @@ parts = {"eye": capi.PartStream(ctx, 0, face_c, pc["righteye"], pc["lefteye"], d
          "mouth": capi.PartStream(ctx, 2, face_c, pc["mouth"], None, detect_event=1),
          "ear": capi.PartStream(ctx, 3, face_c, pc["leftear"], pc["rightear"], detect_event=1)}
 base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
-frames = [synth.make_bgr(W, H, 40 + i, "natural", [(x + 8 * i, y, s) for x, y, s in base]) for i in range(N)]
+JITTER = "--jitter" in sys.argv          # faces change size from frame to frame: the part detectors meet new ROI sizes all the time
+N = 48 if JITTER else N
+frames = [synth.make_bgr(W, H, 40 + i, "natural", [(x + 8 * (i % 16), y, s + ((7 * i) % 23 if JITTER else 0)) for x, y, s in base]) for i in range(N)]
 keep = [torch.from_numpy(f).cuda() for f in frames]
 torch.cuda.synchronize()
 fr = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
@@ -51,5 +53,5 @@ for i in range(K):
     tot[0] += nb; tot[1] += nf
 ctx.synchronize()
 dt = time.perf_counter() - t0
-print("roi chain 1080p: %.1f frames/s (%.3f ms/frame); faces/frame %.2f, parts/frame %.2f; per element ms: %s" %
+print(("roi chain 1080p, face sizes changing every frame: " if JITTER else "roi chain 1080p: ") + "%.1f frames/s (%.3f ms/frame); faces/frame %.2f, parts/frame %.2f; per element ms: %s" %
       (K / dt, dt / K * 1e3, tot[0] / K, tot[1] / K, {k: round(v / K * 1e3, 3) for k, v in acc.items()}))
