@@ -4,27 +4,25 @@
 // (OpenCV 2.4 haar.cpp) behind cascade->detectMultiScale at
 // FACE/kmsfacedetect.cpp:809-811.
 //
-// Three launches per batch of frames:
-//  K5a k_stage0      every window of every scale, one lane per window, 64 consecutive
-//                    x positions per wave: window variance + stage 0.  Writes the
-//                    stage-0 reject bits (one u64 per wave task) and the variance
-//                    normaliser.  OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
-//                    is resolved later in closed form from these bits: window j is
-//                    visited iff the run of stage-0 rejects immediately left of it in
-//                    its row has even length.
-//  K5b k_tile        per tile (<= 32 x 32 windows of one scale): the integral samples the
-//                    tile touches are staged, compacted, in LDS; visited survivors are
-//                    queued in LDS and run through the next stages one window per lane,
-//                    re-compacted after every stage; whoever survives stage
-//                    deep_stage-1 is appended to the deep list.  (k_strip: the same on
-//                    row strips with global gathers, NVCA_TILES=0.)
-//  K5c k_deep        one workgroup per surviving window, one stump per thread (the long
-//                    stages have 33..213 stumps): the serial 2000-stump tail of the
-//                    few face-like windows becomes one step per stage.
-// Stage/rect tables are wave-uniform in K5a/K5b (scalar loads) and coalesced
-// per-lane records in K5c; window sums are gathers from the integral planes.
-// No MFMA: integer rect sums, f32 products, f64 stage sums -- exactly the
-// reference's arithmetic (compiled with -ffp-contract=off).
+// Launches per batch of frames:
+//  K5  k_band        (batches with >= 1024 bands in flight) one workgroup per row of tiles of a
+//                    scale, walking it left to right: per tile (<= 32 x 32 windows) the integral
+//                    samples the windows touch are staged, compacted, in LDS; window variance and
+//                    stage 0 for every window; OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
+//                    in closed form -- window j is visited iff the run of stage-0 rejects
+//                    immediately left of it in its row has even length (the parity is carried from
+//                    tile to tile); visited survivors are queued in LDS and run through the next
+//                    stages, re-compacted after every stage; whoever survives stage deep_stage-1
+//                    is appended to the deep list.
+//  K5a k_stage0 +    (smaller batches) the same as a pre-pass over all windows with global reads
+//  K5b k_tile        (reject bits + variance normaliser per window) followed by one workgroup per
+//                    tile.  k_strip / k_list_*: older variants with global gathers (NVCA_TILES=0).
+//  K5c k_deep        one workgroup per surviving window, one stump per thread (the long stages have
+//                    33..213 stumps); after the first late stage the window's samples are staged in LDS.
+//  K6  k_group       cv::groupRectangles per frame.
+// Stump records are geometry-independent tables per (cascade, factor), wave-uniform in K5/K5a/K5b
+// (scalar loads) and per-lane in K5c.  No MFMA: integer rect sums, f32 products, f64 stage sums --
+// exactly the reference's arithmetic (compiled with -ffp-contract=off).
 #include "nvca_internal.h"
 
 namespace nvca {
