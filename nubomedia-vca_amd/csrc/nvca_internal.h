@@ -55,7 +55,7 @@ struct ScaleRec {           // one evaluated scale
     int    endX, endY;      // scan grid: ix in [0,endX), iy in [0,endY)
     int    eq[4];           // equRect corner offsets
     int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
-    int    stump_off;       // (unused)
+    int    pad_s;
     int    task_off;        // first stage-0 wave task (64 windows) of this scale
     int    wpr;             // wave tasks (64-bit reject words) per scan row
     int    adaptive;        // 1: OpenCV's adaptive x step applies (scale-cascade scan); 0: every grid point is visited
@@ -75,7 +75,7 @@ struct TileRec {
     int ncol, nrow;         // distinct sample columns / rows staged
     int span_x, span_y;     // map extents: the largest column / row offset from (x0, y0) ever looked up, + 1
     int col_off, row_off;   // first entry of the column / row coordinate lists (plane coordinates, u16) in `tcoords`
-    int stump_off;          // first TStumpRec of this scale
+    int pad_t;
     int pad0, pad1;
 };
 struct TStumpRec {          // a stump with separate corner columns / rows (window-relative pixels)
@@ -87,7 +87,7 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
 // workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
 // Per scale: the distinct corner columns / rows (window-relative pixels) of the late stages' stumps.  k_deep stages that
 // ncol x nrow patch of a surviving window in LDS after the first late stage (ncol == 0: scale not eligible, global gathers).
-struct DeepRec { int col_off, ncol, row_off, nrow, span_x, span_y, stump_off, pad; };
+struct DeepRec { int col_off, ncol, row_off, nrow, span_x, span_y, pad0, pad1; };
 static constexpr int kDeepMaxSide = 64;            // patch side (distinct columns / rows)
 static constexpr int kDeepMaxSpan = 1280;          // largest corner offset + 1 the patch maps cover
 struct BandRec { int scale, iy0, ny, first_tile, ntiles, pad0, pad1, pad2; };
