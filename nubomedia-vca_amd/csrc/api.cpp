@@ -102,20 +102,20 @@ static inline int cv_round(double v)
 // what a cascade job leaves behind for the host: candidate list, box table, thresholds.  Three sets: [0] the synchronous
 // entry points, [1] / [2] the two batches that may be in flight through nvca_face_batch_submit / _collect
 struct ResultBufs {
-    DevBuf hits, grp, gthr;
+    DevBuf hits, grp, gthr, staging, srcptrs;        // staging / srcptrs: host frames on their way in, frame pointer table
     PinnedBuf h_hits, h_grp, h_gthr, h_srcptrs;   // h_srcptrs: frame pointers on their way to the device array
     std::vector<int> gthr_last;       // thresholds currently resident in gthr
-    void release() { hits.release(); grp.release(); gthr.release(); h_hits.release(); h_grp.release(); h_gthr.release(); h_srcptrs.release(); gthr_last.clear(); }
+    void release() { hits.release(); grp.release(); gthr.release(); staging.release(); srcptrs.release(); h_hits.release(); h_grp.release(); h_gthr.release(); h_srcptrs.release(); gthr_last.clear(); }
 };
 struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, srcptrs, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
     ResultBufs res[3];
     int cur_res = 0;
     int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
-        sqsum.release(); srcptrs.release(); staging.release(); aux.release();
+        sqsum.release(); staging.release(); aux.release();
         failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
         for (ResultBufs &r : res) r.release();
     }
@@ -204,7 +204,7 @@ static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
     e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
     e |= ws.sum.ensure(g.sum_slot * batch * sizeof(int));
     e |= ws.sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
-    e |= ws.srcptrs.ensure((size_t)batch * sizeof(void *));
+    e |= ws.res[ws.cur_res].srcptrs.ensure((size_t)batch * sizeof(void *));
     e |= ws.res[ws.cur_res].h_srcptrs.ensure((size_t)batch * sizeof(void *));
     if (e) { ctx->set_error("device/pinned allocation failed for the workspace"); return NVCA_ERR_NOMEM; }
     return NVCA_OK;
@@ -786,18 +786,18 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
     Workspace &ws = *ctx->ws;
     if (!st) st = ctx->stream;
     if (!off_io) {           // stand-alone call: size the buffers here
-        if (ws.srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
+        if (ws.res[ws.cur_res].srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
             ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
         }
         const size_t need = staging_need(frames, idx, n);
-        if (need && ws.staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
+        if (need && ws.res[ws.cur_res].staging.ensure(need)) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
     }
     const void **hp = ws.res[ws.cur_res].h_srcptrs.as<const void *>() + r0;
     size_t off = off_io ? *off_io : 0;
     for (int i = 0; i < n; i++) {
         const nvca_frame &f = frames[idx ? idx[i] : i];
         if (f.mem == NVCA_MEM_HOST) {
-            uint8_t *d = ws.staging.as<uint8_t>() + off;
+            uint8_t *d = ws.res[ws.cur_res].staging.as<uint8_t>() + off;
             NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp,
                                                hipMemcpyHostToDevice, st));
             hp[i] = d;
@@ -805,7 +805,7 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
         } else
             hp[i] = f.data;
     }
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.srcptrs.as<const void *>() + r0, hp, (size_t)n * sizeof(void *), hipMemcpyHostToDevice, st));
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.res[ws.cur_res].srcptrs.as<const void *>() + r0, hp, (size_t)n * sizeof(void *), hipMemcpyHostToDevice, st));
     if (off_io) *off_io = off;
     return NVCA_OK;
 }
@@ -831,7 +831,7 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     nvca_frame f{src, w, h, stride, mem, 0};
     if ((rc = stage_frames(ctx, &f, nullptr, 1, channels))) return rc;
     { TimedLaunch t(ctx, NVCA_K_GRAY);
-      launch_gray(ctx->stream, ctx->ws->srcptrs.as<const uint8_t *>(), g, 0, nullptr, nullptr, nullptr, nullptr, w,
+      launch_gray(ctx->stream, ctx->ws->res[ctx->ws->cur_res].srcptrs.as<const uint8_t *>(), g, 0, nullptr, nullptr, nullptr, nullptr, w,
                   ctx->ws->gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
     return unstage_2d(ctx, dst, dst_stride, ctx->ws->gray.p, g.gpitch, w, h, mem);
 }
@@ -1432,6 +1432,14 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     // ---- pass 2: one launch set per distinct geometry; result slots are numbered over the whole batch
     std::vector<char> done(n, 0);
     int gbase = 0;
+    size_t stage_off = 0;                      // host frames of all groups share this batch's staging buffer
+    {
+        ResultBufs &rb = ws.res[ws.cur_res];
+        size_t need = 0; int na = 0;
+        for (int i = 0; i < n; i++) if (work[i].analysed) { na++; need += staging_need(frames + i, nullptr, 1); }
+        if (rb.srcptrs.ensure((size_t)std::max(na, 1) * sizeof(void *)) || rb.h_srcptrs.ensure((size_t)std::max(na, 1) * sizeof(void *)) ||
+            (need && rb.staging.ensure(need))) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
+    }
     for (int i = 0; i < n; i++) {
         if (!work[i].analysed || done[i]) continue;
         const nvca_face_stream *s0 = streams[i];
@@ -1462,16 +1470,11 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         const int chunk = (any_host && chunk_env > 0 && batch >= 2 * chunk_env) ? chunk_env : batch;
         const bool piped = chunk < batch;
         if ((rc = ensure_ws(ctx, gp->g, chunk))) return rc;
-        {
-            const size_t need = staging_need(frames, idx.data(), batch);
-            if (ws.srcptrs.ensure((size_t)(gbase + batch) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(gbase + batch) * sizeof(void *)) ||
-                (need && ws.staging.ensure(need))) { ctx->set_error("allocation failed (frame staging)"); return NVCA_ERR_NOMEM; }
-        }
+
         std::vector<int> &gthr = grp.gthr;
         gthr.resize(batch);
         for (int b = 0; b < batch; b++) { const int mn = streams[idx[b]]->p.min_neighbors; gthr[b] = mn != 0 ? std::max(mn, 1) : 0; }
         std::vector<CascadeJob> &jobs = grp.jobs;
-        size_t stage_off = 0;
         for (int s0 = 0; s0 < batch; s0 += chunk) {
             const int nc = std::min(chunk, batch - s0);
             if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->stream, &stage_off))) return rc;
@@ -1493,7 +1496,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
             unsigned long long *z_hits = nullptr, *z_deep = nullptr;
             if ((rc = cascade_counters(ctx, gp->det, job, &z_hits, &z_deep))) return rc;
             { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
-              launch_gray(ctx->stream, ws.srcptrs.as<const uint8_t *>() + gbase + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
+              launch_gray(ctx->stream, ws.res[ws.cur_res].srcptrs.as<const uint8_t *>() + gbase + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
                           gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
                           ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), nc, frames_aligned4(frames, idx.data() + s0, nc)); }
             { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
@@ -1508,8 +1511,6 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     }
     if (!tk.done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
     NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->stream));
-    // a later batch's host-frame copies (copy stream) must not overtake this batch's reads of the staging buffer
-    NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy_stream, tk.done, 0));
     tk.pending = true;
     return NVCA_OK;
 }

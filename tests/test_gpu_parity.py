@@ -414,6 +414,32 @@ def test_face_batch_mixed_geometries(ctx, casc, orc_cascade):
     assert seen > 8
 
 
+def test_face_batch_two_chunked_groups(ctx, casc, orc_cascade):
+    """two geometry groups in one call, both large enough for the chunked ingest: their host frames share one staging
+    buffer (the copy stream runs ahead of the kernels), pipelined as well"""
+    import orc
+    from nubovca import capi, synth
+    geo = [(480, 360, {"width_to_process": 480, "multi_scale_factor": 15}), (400, 300, {"width_to_process": 400, "multi_scale_factor": 15})]
+    kw = {"width_to_process": "width_to_process", "multi_scale_factor": "scale_factor_pct"}
+    N = 17
+    specs = [geo[i % 2] for i in range(2 * N)]
+    streams = [capi.FaceStream(ctx, casc, **p) for _, _, p in specs]
+    oracles = [orc.FaceStream(orc_cascade, **{kw[k]: v for k, v in p.items()}) for _, _, p in specs]
+    frames = [[synth.make_bgr(W, H, 9000 + 13 * i + t, "natural", [(W // 6 + 3 * i, H // 7 + t, H // 2)] if i % 3 else [])
+               for i, (W, H, _) in enumerate(specs)] for t in range(3)]
+    res0 = ctx.face_batch_process(streams, [capi.make_frame(f) for f in frames[0]])
+    t1 = ctx.face_batch_submit(streams, [capi.make_frame(f) for f in frames[1]])
+    t2 = ctx.face_batch_submit(streams, [capi.make_frame(f) for f in frames[2]])
+    got = [res0, ctx.face_batch_collect(t1), ctx.face_batch_collect(t2)]
+    seen = 0
+    for t in range(3):
+        for i in range(len(specs)):
+            eb, eid = oracles[i].process(frames[t][i])
+            assert np.array_equal(got[t][i][0], eb) and np.array_equal(got[t][i][1], eid), (t, i)
+            seen += len(eb)
+    assert seen > 20
+
+
 def test_face_batch_submit_collect(ctx, casc, orc_cascade):
     """two batches in flight (submit k+1 before collect k), the same streams in consecutive batches, host and device
     frames, mixed geometries: boxes and ids as if every frame went through the synchronous call"""
