@@ -244,7 +244,7 @@ def main():
             launches = max([ktimes.get(m, (0.0, 0))[1] for m in members] + [0])
             if launches:
                 per_launch_ms = ms / launches
-                bytes_per_launch = ab.get(gname, 0) * F
+                bytes_per_launch = ab.get(gname, 0) * F * args.steps / launches     # frames per launch set (host frames go through in chunks)
                 kern[gname] = {"ms_per_launch": per_launch_ms, "launches": launches,
                                "alg_bytes_per_launch": bytes_per_launch,
                                "achieved_GBs": bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0}
