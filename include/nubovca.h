@@ -195,8 +195,8 @@ int  nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *stre
                              int *n_out);
 /* The same in two halves, for a serving loop that keeps the GPU busy across batches: submit() gates the frames and queues
  * every launch, collect() waits for that batch and runs the temporal logic (Faces::track_faces, FACE/Faces.cpp:78-153).
- * Up to two batches may be in flight; they are collected in submission order.  Frame memory must stay valid until the
- * batch has been collected. */
+ * Up to two batches may be in flight; they are collected in submission order.  Frame memory and the streams of a batch
+ * must stay valid until the batch has been collected. */
 int  nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames, int *ticket);
 int  nvca_face_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out, int *ids, int cap, int *n_out);
 
