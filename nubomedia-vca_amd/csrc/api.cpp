@@ -325,10 +325,12 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     const size_t rec = 2 + 4 * kGroupOutCap;
     const size_t grp_stride = rec + 2;                                       // per result slot: a job's table is followed by the 64-bit raw count
     if (dev_group) {
+        const void *old_gthr = rb.gthr.p;
         if (rb.grp.ensure((size_t)total * grp_stride * sizeof(int)) || rb.h_grp.ensure((size_t)total * grp_stride * sizeof(int)) ||
             rb.gthr.ensure((size_t)total * sizeof(int)) || rb.h_gthr.ensure((size_t)total * sizeof(int))) {
             ctx->set_error("device allocation failed for the grouping workspace"); return NVCA_ERR_NOMEM;
         }
+        if (rb.gthr.p != old_gthr) rb.gthr_last.clear();          // a new buffer holds no thresholds yet
         job.d_grp = rb.grp.as<int>() + grp_stride * job.r0; job.h_grp = rb.h_grp.as<int>() + grp_stride * job.r0;
         if (rb.gthr_last.size() < (size_t)total) rb.gthr_last.resize(total, -1);
         if (memcmp(rb.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
@@ -1588,8 +1590,12 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
 {
     NVCA_LOCK_OR_FAIL(ctx);
     if (n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
+    // a stream's frames are consumed in order: the synchronous call may not overtake a submitted batch of the same stream
     for (int k = 1; k < 3; k++)
-        if (ctx->face_tickets[k] && ctx->face_tickets[k]->pending) { ctx->set_error("collect the submitted batches first"); return NVCA_ERR_ARG; }
+        if (ctx->face_tickets[k] && ctx->face_tickets[k]->pending)
+            for (int i = 0; i < n; i++)
+                for (nvca_face_stream *s : ctx->face_tickets[k]->streams)
+                    if (s == streams[i]) { ctx->set_error("a stream of this batch has a submitted batch in flight: collect it first"); return NVCA_ERR_ARG; }
     FaceTicket &tk = ticket_slot(ctx, 0);
     int rc = face_submit(ctx, n, streams, frames, 0, tk);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); face_release(tk); return rc; }
