@@ -71,13 +71,28 @@ def seq_detect(seed):
     return run
 
 
+def seq_varbatch(seed):
+    """batches of changing size and geometry: every buffer of the workspace grows at some point"""
+    rng = np.random.RandomState(seed)
+    sizes = [1, 3, 9, 2, 19, 5, 33, 4]
+    geos = [(320, 240), (400, 300), (320, 240), (480, 360)]
+    fr = [[synth.make_bgr(*geos[(k + j) % 4], seed + 50 * k + j, "natural", [(40 + 3 * j, 30, 120)] if j % 3 else []) for j in range(n)] for k, n in enumerate(sizes)]
+    def run():
+        out = []
+        for k, n in enumerate(sizes):
+            s = [capi.FaceStream(ctx, casc, width_to_process=geos[(k + j) % 4][0], multi_scale_factor=20, min_neighbors=2 + j % 2) for j in range(n)]
+            out.append(ctx.face_batch_process(s, [capi.make_frame(f) for f in fr[k]]))
+        return out
+    return run
+
+
 def same(a, b):
     if isinstance(a, (list, tuple)):
         return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
     return np.array_equal(np.asarray(a), np.asarray(b))
 
 
-jobs = [seq_face(1), seq_face(500), seq_async(900), seq_tracker(7), seq_parts(40), seq_detect(3), seq_detect(77)]
+jobs = [seq_face(1), seq_face(500), seq_async(900), seq_tracker(7), seq_parts(40), seq_detect(3), seq_detect(77), seq_varbatch(11)]
 expect = [j() for j in jobs]
 stop = time.time() + SECS
 errors, rounds = [], [0] * len(jobs)
