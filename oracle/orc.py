@@ -337,7 +337,10 @@ class FaceStream:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_face_stream_destroy(self.h)
+            try:
+                lib().orc_face_stream_destroy(self.h)
+            except Exception:       # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -371,7 +374,10 @@ class Tracker:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_tracker_destroy(self.h)
+            try:
+                lib().orc_tracker_destroy(self.h)
+            except Exception:       # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -421,5 +427,8 @@ class PartStream:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_part_stream_destroy(self.h)
+            try:
+                lib().orc_part_stream_destroy(self.h)
+            except Exception:       # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
