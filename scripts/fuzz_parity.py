@@ -18,9 +18,59 @@ cascs = [(ctx.load_cascade_xml(x), orc.parse_cascade_xml(x)) for x in (xml_full,
 KW = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4", "multi_scale_factor": "scale_factor_pct",
       "min_neighbors": "min_neighbors"}
 t_end = time.time() + SECS
-rounds = {"face": 0, "detect": 0}
+rounds = {"face": 0, "detect": 0, "tracker": 0, "parts": 0}
+part_xml = {n: synth.synthetic_part_cascade_xml(n) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+part_dev = {n: ctx.load_cascade_xml(x) for n, x in part_xml.items()}
+part_cpu = {n: orc.parse_cascade_xml(x) for n, x in part_xml.items()}
+KINDS = {0: ("righteye", "lefteye"), 1: ("nose", None), 2: ("mouth", None), 3: ("leftear", "rightear")}
 while time.time() < t_end:
-    if rng.rand() < 0.5:
+    u = rng.rand()
+    if u < 0.12:
+        # ---- tracker: blobs moving over a noisy background, random parameters and sizes
+        W, H = int(rng.choice([160, 200, 320, 322, 401])), int(rng.randint(90, 260))
+        tp = {"set_threshold": int(rng.randint(5, 60)), "set_min_area": int(rng.randint(5, 200)), "set_max_area": int(rng.randint(500, 40000)),
+              "set_distance": int(rng.randint(5, 80))}
+        gt = capi.Tracker(ctx, **tp)
+        ot = orc.Tracker(threshold=tp["set_threshold"], min_area=tp["set_min_area"], max_area=tp["set_max_area"], distance=tp["set_distance"])
+        bg = rng.randint(0, 256, size=(H, W, 4)).astype(np.uint8)
+        nb = int(rng.randint(1, 5))
+        blobs = [(rng.randint(0, W - 20), rng.randint(0, H - 20), rng.randint(6, 60), rng.randint(6, 60), rng.randint(-9, 10), rng.randint(-9, 10), rng.randint(0, 256)) for _ in range(nb)]
+        for t in range(int(rng.randint(3, 9))):
+            f = bg.copy()
+            if rng.rand() < 0.3:
+                f[:, :, :3] = np.clip(f[:, :, :3].astype(int) + rng.randint(-3, 4), 0, 255).astype(np.uint8)
+            for (x, y, w_, h_, vx, vy, c) in blobs:
+                x0, y0 = int(np.clip(x + vx * t, 0, W - 2)), int(np.clip(y + vy * t, 0, H - 2))
+                f[y0:min(H, y0 + h_), x0:min(W, x0 + w_), :3] = c
+            ts = 1000.0 + 33.3 * t
+            a, b = gt.process(f, ts, cap=1 << 14), ot.process(f, ts, cap=1 << 16)
+            if not np.array_equal(a, b):
+                print("MISMATCH tracker", W, H, tp, "tick", t, len(a), len(b)); sys.exit(1)
+        gt.close()
+        rounds["tracker"] += 1
+    elif u < 0.2:
+        # ---- part detectors (own face pass or detect-event mode)
+        kind = int(rng.randint(0, 4)); na, nbn = KINDS[kind]
+        W, H = int(rng.choice([320, 400, 480, 640])), int(rng.choice([240, 300, 360, 480]))
+        pr = {"process_x_every_4_frames": int(rng.randint(1, 5)), "multi_scale_factor": int(rng.choice([10, 25, 40]))}
+        if kind != 3 and rng.rand() < 0.5: pr["detect_event"] = 1
+        if rng.rand() < 0.3: pr["width_to_process"] = int(rng.choice([160, 320, W]))
+        names = {"width_to_process": "width_to_process", "process_x_every_4_frames": "process_x_every_4", "multi_scale_factor": "scale_factor_pct", "detect_event": "detect_event"}
+        gp = capi.PartStream(ctx, kind, cascs[0][0], part_dev[na], part_dev[nbn] if nbn else None, **pr)
+        op = orc.PartStream(kind, cascs[0][1], part_cpu[na], part_cpu[nbn] if nbn else None, **{names[k]: v for k, v in pr.items()})
+        sfc = int(H * rng.uniform(0.35, 0.6))
+        for t in range(int(rng.randint(2, 6))):
+            faces = [(int(rng.randint(0, max(1, W - sfc))), int(rng.randint(0, max(1, H - sfc))), sfc)] if rng.rand() < 0.8 else []
+            f = synth.make_bgr(W, H, int(rng.randint(1 << 30)), "natural", faces)
+            if pr.get("detect_event"):
+                boxes = [(x, y, s_, s_) for (x, y, s_) in faces]
+                gp.push_faces(boxes); op.push_faces(boxes)
+            (a1, b1), (a2, b2) = gp.process(f), op.process(f)
+            if not (np.array_equal(a1, a2) and np.array_equal(b1, b2)):
+                print("MISMATCH parts", kind, W, H, pr, "tick", t, a1, a2, b1, b2); sys.exit(1)
+        gp.close()
+        rounds["parts"] += 1
+    elif u < 0.6:
         # ---- face streams
         gc, oc = cascs[0]
         W, H = int(rng.randint(80, 360)), int(rng.randint(64, 260))
