@@ -1,6 +1,7 @@
 """Randomised parity run: the HIP path against the CPU oracle on random configurations (frame sizes, properties,
 host / device frames, synchronous / per-stream / submit-collect calls, the three detectMultiScale variants with random
-size limits) for a given number of seconds.  TEST TOOL (it loads oracle/).  Usage: fuzz_parity.py [seconds] [seed]"""
+size limits) for a given number of seconds.  Test tool (lives under tests/ because it loads oracle/).
+Usage: python tests/fuzz_parity.py [seconds] [seed]; tests/test_gpu_fuzz.py runs a short burst of it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "nubomedia-vca_amd"), os.path.join(ROOT, "oracle")):
