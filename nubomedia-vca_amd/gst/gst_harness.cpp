@@ -3,14 +3,15 @@
 // and prints what an unmodified downstream would observe: every CUSTOM_DOWNSTREAM "message" event
 // leaving the element (one line per frame: "event <pts> x,y,w,h;...") and every string signal
 // ("signal <payload>").  Usage:
-//   gst_harness <element> <format BGR|BGRA> <width> <height> <frames.raw> [prop=value ...]
+//   gst_harness <element> <format BGR|BGRA> <width> <height> <frames.raw>[,<more.raw>...] [prop=value ...]
+// With several files the pipeline has one such branch per file (lines of branch k > 0 are tagged "event#k" / "signal#k").
 #include <gst/gst.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
 
-static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer)
+static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer user)
 {
     GstEvent *ev = GST_PAD_PROBE_INFO_EVENT(info);
     if (GST_EVENT_TYPE(ev) != GST_EVENT_CUSTOM_DOWNSTREAM) return GST_PAD_PROBE_OK;
@@ -33,17 +34,23 @@ static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer)
         }
         gst_structure_free(sub);
     }
-    printf("event %llu %s\n", (unsigned long long)pts, line.c_str());
+    const int k = GPOINTER_TO_INT(user);
+    char tag[24] = "event";
+    if (k) snprintf(tag, sizeof(tag), "event#%d", k);
+    printf("%s %llu %s\n", tag, (unsigned long long)pts, line.c_str());
     fflush(stdout);
     return GST_PAD_PROBE_OK;
 }
-static void on_signal(GstElement *, const gchar *payload, gpointer) { printf("signal %s\n", payload); fflush(stdout); }
-
-int main(int argc, char **argv)
+static void on_signal(GstElement *, const gchar *payload, gpointer user)
 {
-    if (argc < 6) { fprintf(stderr, "usage: %s element format width height file [prop=value...]\n", argv[0]); return 2; }
-    gst_init(&argc, &argv);
-    GstElement *pipe = gst_pipeline_new("p");
+    const int k = GPOINTER_TO_INT(user);
+    if (k) printf("signal#%d %s\n", k, payload); else printf("signal %s\n", payload);
+    fflush(stdout);
+}
+
+// one branch: filesrc ! rawvideoparse ! <element or bin> ! fakesink, observed on the element named "el"
+static int add_branch(GstElement *pipe, int k, int argc, char **argv, const char *file)
+{
     GstElement *src = gst_element_factory_make("filesrc", NULL), *parse = gst_element_factory_make("rawvideoparse", NULL);
     // argv[1]: a factory name, or a bin description ("a ! b name=el ...") whose element named "el" is observed
     GstElement *sink = gst_element_factory_make("fakesink", NULL);
@@ -54,29 +61,47 @@ int main(int argc, char **argv)
         if (!chain) { fprintf(stderr, "bad description: %s\n", err ? err->message : "?"); return 3; }
         el = gst_bin_get_by_name(GST_BIN(chain), "el");
     } else {
-        el = gst_element_factory_make(argv[1], "el");
+        el = gst_element_factory_make(argv[1], NULL);
         chain = el;
     }
     if (!src || !parse || !el || !sink) { fprintf(stderr, "missing element (%s?)\n", argv[1]); return 3; }
     const bool bgra = !strcmp(argv[2], "BGRA");
-    g_object_set(src, "location", argv[5], NULL);
+    g_object_set(src, "location", file, NULL);
     gst_util_set_object_arg(G_OBJECT(parse), "format", bgra ? "bgra" : "bgr");
     g_object_set(parse, "width", atoi(argv[3]), "height", atoi(argv[4]), NULL);
     gst_util_set_object_arg(G_OBJECT(parse), "framerate", "30/1");
     for (int i = 6; i < argc; i++) {
-        char *eq = strchr(argv[i], '=');
-        if (!eq) continue;
-        *eq = 0;
-        gst_util_set_object_arg(G_OBJECT(el), argv[i], eq + 1);
+        std::string kv(argv[i]);
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) continue;
+        gst_util_set_object_arg(G_OBJECT(el), kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str());
     }
     gst_bin_add_many(GST_BIN(pipe), src, parse, chain, sink, NULL);
     if (!gst_element_link_many(src, parse, chain, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }
     GstPad *sp = gst_element_get_static_pad(el, "src");
-    gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_EVENT_DOWNSTREAM, on_event, NULL, NULL);
+    gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_EVENT_DOWNSTREAM, on_event, GINT_TO_POINTER(k), NULL);
     gst_object_unref(sp);
     const char *sigs[] = {"face-event", "tracker-event", "eye-event", "nose-event", "mouth-event", "ear-event"};
     for (const char *sig : sigs)
-        if (g_signal_lookup(sig, G_OBJECT_TYPE(el))) g_signal_connect(el, sig, G_CALLBACK(on_signal), NULL);
+        if (g_signal_lookup(sig, G_OBJECT_TYPE(el))) g_signal_connect(el, sig, G_CALLBACK(on_signal), GINT_TO_POINTER(k));
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s element format width height file[,file...] [prop=value...]\n", argv[0]); return 2; }
+    gst_init(&argc, &argv);
+    GstElement *pipe = gst_pipeline_new("p");
+    // several files => several branches in the one pipeline, each with its own streaming thread (one per "session")
+    std::string files(argv[5]);
+    int k = 0;
+    for (size_t pos = 0; pos <= files.size();) {
+        size_t c = files.find(',', pos);
+        if (c == std::string::npos) c = files.size();
+        const std::string file = files.substr(pos, c - pos);
+        if (!file.empty()) { const int rc = add_branch(pipe, k++, argc, argv, file.c_str()); if (rc) return rc; }
+        pos = c + 1;
+    }
     gst_element_set_state(pipe, GST_STATE_PLAYING);
     GstBus *bus = gst_element_get_bus(pipe);
     GstMessage *msg = gst_bus_timed_pop_filtered(bus, 120 * GST_SECOND, (GstMessageType)(GST_MESSAGE_EOS | GST_MESSAGE_ERROR));

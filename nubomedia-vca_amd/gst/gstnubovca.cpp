@@ -22,6 +22,10 @@
 #include <string.h>
 #include <string>
 #include <mutex>
+#include <condition_variable>
+#include <map>
+#include <vector>
+#include <algorithm>
 #include "nubovca.h"
 
 GST_DEBUG_CATEGORY_STATIC(nubovca_debug);
@@ -42,6 +46,116 @@ static nvca_ctx *shared_ctx()
     }
     return g_ctx;
 }
+// Elements that name the same cascade file share one handle: their plans and scale tables are then shared in the
+// context, and their frames can ride in one batch (streams batch only when cascade, geometry and parameters agree).
+struct SharedCascade { nvca_cascade *h; int refs; };
+static std::map<std::string, SharedCascade> g_cascades;
+static nvca_cascade *acquire_cascade(nvca_ctx *ctx, const std::string &path)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    auto it = g_cascades.find(path);
+    if (it != g_cascades.end()) { it->second.refs++; return it->second.h; }
+    nvca_cascade *h = nullptr;
+    if (nvca_cascade_load_xml(ctx, path.c_str(), &h) != NVCA_OK) return nullptr;
+    g_cascades[path] = SharedCascade{h, 1};
+    return h;
+}
+static void release_cascade(nvca_cascade *h)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    for (auto it = g_cascades.begin(); it != g_cascades.end(); ++it)
+        if (it->second.h == h) {
+            if (--it->second.refs == 0) { nvca_cascade_free(h); g_cascades.erase(it); }
+            return;
+        }
+}
+
+// Frames of different elements of one kind that arrive while the GPU is busy are combined into one batched call.  The
+// first streaming thread to arrive leads: it takes whatever has queued up (its own frame included), runs the batched
+// entry point on the lot and wakes the owners; threads that arrive meanwhile queue up for the next round, so the batch
+// grows with the load and an idle pipeline still sees single-frame latency.  Results are those of per-frame calls:
+// streams are independent and a batch keeps the order of each stream's frames.
+template <class Req> struct Combiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Req *> q;
+    bool leader = false;
+    int max_batch = 0;                                      /* largest batch seen (NVCA_GST_STATS) */
+    template <class Run> int process(Req *req, Run run)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        req->done = false;
+        q.push_back(req);
+        while (!req->done) {
+            if (leader) { cv.wait(lk); continue; }
+            leader = true;
+            std::vector<Req *> round;
+            round.swap(q);
+            lk.unlock();
+            run(round);
+            lk.lock();
+            if ((int)round.size() > max_batch) max_batch = (int)round.size();
+            for (Req *r : round) r->done = true;
+            leader = false;
+            cv.notify_all();
+        }
+        return req->rc;
+    }
+};
+
+static const int kFaceCap = 256, kTrkCap = 4096;
+struct FaceReq { nvca_face_stream *stream; nvca_frame frame; nvca_rect *out; int n, rc; bool done; };
+struct TrkReq { nvca_tracker *trk; nvca_frame frame; double ts; nvca_rect *out; int n, rc; bool done; };
+static Combiner<FaceReq> g_face_q;
+static Combiner<TrkReq> g_trk_q;
+
+static void face_run_round(nvca_ctx *ctx, std::vector<FaceReq *> &round)
+{
+    const int n = (int)round.size();
+    bool batched = false;
+    if (n > 1) {
+        std::vector<nvca_face_stream *> streams(n);
+        std::vector<nvca_frame> frames(n);
+        std::vector<nvca_rect> out((size_t)n * kFaceCap);
+        std::vector<int> n_out(n, 0);
+        for (int i = 0; i < n; i++) { streams[i] = round[i]->stream; frames[i] = round[i]->frame; }
+        const int rc = nvca_face_batch_process(ctx, n, streams.data(), frames.data(), out.data(), NULL, kFaceCap, n_out.data());
+        batched = rc != NVCA_ERR_ARG;
+        for (int i = 0; batched && i < n; i++) {
+            FaceReq *r = round[i];
+            r->rc = rc; r->n = rc == NVCA_OK ? n_out[i] : 0;
+            memcpy(r->out, out.data() + (size_t)i * kFaceCap, sizeof(nvca_rect) * (size_t)std::min(n_out[i], kFaceCap));
+        }
+    }
+    // a single frame, or a batch refused with NVCA_ERR_ARG (every frame is validated before any stream is touched): one
+    // bad frame must not fail its neighbours, so each gets its own call and its own status.  Any other failure came
+    // after the streams' frame gates advanced and is reported to every owner as it is.
+    if (!batched)
+        for (FaceReq *r : round) r->rc = nvca_face_stream_process(r->stream, &r->frame, r->out, NULL, kFaceCap, &r->n);
+}
+static void trk_run_round(nvca_ctx *ctx, std::vector<TrkReq *> &round)
+{
+    const int n = (int)round.size();
+    bool batched = false;
+    if (n > 1) {
+        std::vector<nvca_tracker *> trks(n);
+        std::vector<nvca_frame> frames(n);
+        std::vector<double> ts(n);
+        std::vector<nvca_rect> out((size_t)n * kTrkCap);
+        std::vector<int> n_out(n, 0);
+        for (int i = 0; i < n; i++) { trks[i] = round[i]->trk; frames[i] = round[i]->frame; ts[i] = round[i]->ts; }
+        const int rc = nvca_tracker_batch_process(ctx, n, trks.data(), frames.data(), ts.data(), out.data(), kTrkCap, n_out.data());
+        batched = rc != NVCA_ERR_ARG;
+        for (int i = 0; batched && i < n; i++) {
+            TrkReq *r = round[i];
+            r->rc = rc; r->n = rc == NVCA_OK ? n_out[i] : 0;
+            memcpy(r->out, out.data() + (size_t)i * kTrkCap, sizeof(nvca_rect) * (size_t)std::min(n_out[i], kTrkCap));
+        }
+    }
+    if (!batched)
+        for (TrkReq *r : round) r->rc = nvca_tracker_process(r->trk, &r->frame, r->ts, r->out, kTrkCap, &r->n);
+}
+
 static std::string cascade_path(const char *file)
 {
     const char *dir = getenv("NVCA_CASCADE_DIR");
@@ -150,9 +264,9 @@ static void face_lazy_init(NvcaFace *f)
     if (!ctx) return;
     if (!f->cascade) {
         const std::string path = cascade_path("haarcascade_frontalface_alt.xml");
-        if (nvca_cascade_load_xml(ctx, path.c_str(), &f->cascade) != NVCA_OK) {
+        f->cascade = acquire_cascade(ctx, path);
+        if (!f->cascade) {
             GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));   /* :167-176: logged, not fatal */
-            f->cascade = nullptr;
             return;
         }
     }
@@ -178,7 +292,10 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
         nf.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
         nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
         nvca_rect boxes[256]; int n = 0;
-        const int rc = nvca_face_stream_process(f->stream, &nf, boxes, NULL, 256, &n);
+        FaceReq req{f->stream, nf, boxes, 0, NVCA_OK, false};
+        nvca_ctx *ctx = shared_ctx();
+        const int rc = g_face_q.process(&req, [ctx](std::vector<FaceReq *> &round) { face_run_round(ctx, round); });
+        n = req.n;
         if (rc != NVCA_OK) GST_ERROR("nvca_face_stream_process: %d", rc);
         else {
             if (n > 256) n = 256;
@@ -215,8 +332,12 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
 static void nvca_face_finalize(GObject *o)
 {
     NvcaFace *f = (NvcaFace *)o;
+    if (getenv("NVCA_GST_STATS")) {
+        std::lock_guard<std::mutex> lk(g_face_q.m);
+        fprintf(stderr, "nubovca: largest combined face batch %d\n", g_face_q.max_batch);
+    }
     if (f->stream) nvca_face_stream_destroy(f->stream);
-    if (f->cascade) nvca_cascade_free(f->cascade);
+    if (f->cascade) release_cascade(f->cascade);
     if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
     g_queue_free_full(f->events_queue, (GDestroyNotify)gst_structure_free);
     g_rec_mutex_clear(&f->mutex);
@@ -329,8 +450,11 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
         nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
         const double timestamp = 1000.0 * clock() / CLOCKS_PER_SEC;          /* TRK/gstnubotracker.cpp:349 */
         int n = 0;
-        nvca_rect *bx = (nvca_rect *)g_malloc(sizeof(nvca_rect) * 4096);
-        const int rc = nvca_tracker_process(t->trk, &nf, timestamp, bx, 4096, &n);
+        nvca_rect *bx = (nvca_rect *)g_malloc(sizeof(nvca_rect) * kTrkCap);
+        TrkReq req{t->trk, nf, timestamp, bx, 0, NVCA_OK, false};
+        nvca_ctx *ctx = shared_ctx();
+        const int rc = g_trk_q.process(&req, [ctx](std::vector<TrkReq *> &round) { trk_run_round(ctx, round); });
+        n = req.n;
         if (rc != NVCA_OK) GST_ERROR("nvca_tracker_process: %d", rc);
         else if (n > 0) {
             if (n > 4096) n = 4096;
@@ -354,6 +478,10 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
 static void nvca_trk_finalize(GObject *o)
 {
     NvcaTrk *t = (NvcaTrk *)o;
+    if (getenv("NVCA_GST_STATS")) {
+        std::lock_guard<std::mutex> lk(g_trk_q.m);
+        fprintf(stderr, "nubovca: largest combined tracker batch %d\n", g_trk_q.max_batch);
+    }
     if (t->trk) nvca_tracker_destroy(t->trk);
     g_rec_mutex_clear(&t->mutex);
     G_OBJECT_CLASS(nvca_trk_parent_class)->finalize(o);
@@ -469,9 +597,9 @@ static void part_lazy_init(NvcaPart *f)
     for (auto &n : need) {
         if (!n.file || *n.c) continue;
         const std::string path = cascade_path(n.file);
-        if (nvca_cascade_load_xml(ctx, path.c_str(), n.c) != NVCA_OK) {
+        *n.c = acquire_cascade(ctx, path);
+        if (!*n.c) {
             GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));
-            *n.c = nullptr;
             return;
         }
     }
@@ -580,9 +708,9 @@ static void nvca_part_finalize(GObject *o)
 {
     NvcaPart *f = (NvcaPart *)o;
     if (f->stream) nvca_part_stream_destroy(f->stream);
-    if (f->cf) nvca_cascade_free(f->cf);
-    if (f->ca) nvca_cascade_free(f->ca);
-    if (f->cb) nvca_cascade_free(f->cb);
+    if (f->cf) release_cascade(f->cf);
+    if (f->ca) release_cascade(f->ca);
+    if (f->cb) release_cascade(f->cb);
     if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
     g_rec_mutex_clear(&f->mutex);
     G_OBJECT_CLASS(f->desc->parent_class)->finalize(o);

@@ -48,13 +48,19 @@ def test_tracker_element_surface(shim):
     assert "Range: 0 - 255 Default: 20" in out and "Range: 0 - 300000 Default: 30000" in out
 
 
-def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None):
+def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None, extra_env=None):
+    """frames: one list of frames, or a list of such lists (one pipeline branch per list)"""
     with tempfile.TemporaryDirectory() as td:
-        raw = os.path.join(td, "frames.raw")
-        with open(raw, "wb") as f:
-            for fr in frames:
-                f.write(np.ascontiguousarray(fr).tobytes())
+        branches = frames if isinstance(frames[0], (list, tuple)) else [frames]
+        raws = []
+        for k, seq in enumerate(branches):
+            raws.append(os.path.join(td, "frames%d.raw" % k))
+            with open(raws[-1], "wb") as f:
+                for fr in seq:
+                    f.write(np.ascontiguousarray(fr).tobytes())
+        raw = ",".join(raws)
         env = build_gst.env()
+        env.update(extra_env or {})
         if cascade_xml is not None:
             with open(os.path.join(td, "haarcascade_frontalface_alt.xml"), "w") as f:
                 f.write(cascade_xml)
@@ -103,6 +109,41 @@ def test_face_pipeline_events_match_oracle(shim, synth_xml, orc_cascade):
 
 
 @pytest.mark.gpu
+def test_face_branches_share_batches_and_keep_per_stream_results(shim, synth_xml, orc_cascade):
+    """several face elements in one process: their frames are combined into batched calls (shared cascade handle),
+    and every branch still emits exactly what the oracle emits for its own frame sequence"""
+    import orc
+    from nubovca import synth
+    W, H, NB, NF = 640, 480, 4, 12
+    branches = []
+    for b in range(NB):
+        seq = []
+        for i in range(NF):
+            faces = [] if (i + b) % 5 == 3 else [(30 + 40 * b + 5 * i, H // 8 + 10 * b, H // 2 - 20 * b)]
+            seq.append(synth.make_bgr(W, H, 900 + 37 * b + i, "natural", faces))
+        branches.append(seq)
+    r = _run_harness("nubofacedetector", "BGR", W, H, branches, cascade_xml=synth_xml, extra_env={"NVCA_GST_STATS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    n_boxes = 0
+    for b, seq in enumerate(branches):
+        tag = "event " if b == 0 else "event#%d " % b
+        events = [l for l in lines if l.startswith(tag)]
+        assert len(events) == NF, (b, len(events))
+        ofs = orc.FaceStream(orc_cascade)
+        for fr, line in zip(seq, events):
+            boxes, _ = ofs.process(fr)
+            exp = "".join("face/face:%d,%d,%d,%d;" % tuple(bx) for bx in boxes)
+            parts = line.split(" ", 2)
+            assert (parts[2] if len(parts) > 2 else "") == exp, (b, line, exp)
+            n_boxes += len(boxes)
+    assert n_boxes > 0
+    stats = [l for l in r.stderr.splitlines() if "largest combined face batch" in l]
+    assert stats, r.stderr[-500:]
+    print(stats[-1])
+
+
+@pytest.mark.gpu
 def test_tracker_pipeline_runs(shim):
     W, H = 320, 240
     frames = []
@@ -114,6 +155,28 @@ def test_tracker_pipeline_runs(shim):
     assert r.returncode == 0, r.stderr[-2000:]
     sig = [l for l in r.stdout.splitlines() if l.startswith("signal ")]
     assert len(sig) >= 3 and all("width:" in s for s in sig)
+
+
+@pytest.mark.gpu
+def test_tracker_branches_are_combined(shim):
+    W, H, NB = 320, 240, 3
+    branches = []
+    for b in range(NB):
+        seq = []
+        for i in range(10):
+            f = np.full((H, W, 4), 40, np.uint8)
+            f[40 + 20 * b:100 + 20 * b, 30 + 10 * i:90 + 10 * i, :3] = 220
+            seq.append(f)
+        branches.append(seq)
+    r = _run_harness("nubotracker", "BGRA", W, H, branches, props=["activate-events=1", "events-ms=0"],
+                     extra_env={"NVCA_GST_STATS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    for b in range(NB):
+        tag = "signal " if b == 0 else "signal#%d " % b
+        sig = [l for l in lines if l.startswith(tag)]
+        assert len(sig) >= 3 and all("width:" in x for x in sig), (b, sig)
+    assert any("largest combined tracker batch" in l for l in r.stderr.splitlines())
 
 
 @pytest.mark.parametrize("factory,view,signal,meta", [
