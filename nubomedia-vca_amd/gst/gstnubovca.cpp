@@ -83,6 +83,8 @@ template <class Req> struct Combiner {
     int max_batch = 0;                                      /* largest batch seen (NVCA_GST_STATS) */
     template <class Run> int process(Req *req, Run run)
     {
+        static const bool off = getenv("NVCA_GST_NO_COMBINE") != NULL;     /* A/B switch: every frame on its own */
+        if (off) { std::vector<Req *> one(1, req); run(one); return req->rc; }
         std::unique_lock<std::mutex> lk(m);
         req->done = false;
         q.push_back(req);
