@@ -420,6 +420,69 @@ __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *
     return v >= t ? a1 : a0;
 }
 
+// A wave-uniform record held whole in scalar registers.  Left to itself the compiler fetches a record piecemeal, each
+// piece right before its use (corners; weights; threshold; votes): four dependent scalar-memory round trips per stump on
+// the critical path of a latency-bound loop.  One 16-dword and one 8-dword load bring the record in at once.
+typedef int int16v __attribute__((ext_vector_type(16)));
+typedef int int8v __attribute__((ext_vector_type(8)));
+struct SRec { int16v a; int8v b; };
+__device__ __forceinline__ SRec load_srec(const TStumpRec *p)
+{
+    SRec r;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b) : "s"(p) : "memory");
+    return r;
+}
+template <bool PAIR>
+__device__ __forceinline__ double tile_vote_s(const int *T, const unsigned short *cmap, const unsigned short *rmap,
+                                              int xw, int yw, double vnf, const SRec &f)
+{
+    // dwords: x0[3] 0-2 | x1[3] 3-5 | y0[3] 6-8 | y1[3] 9-11 | w[3] 12-14 | nrect 15 || thr 0-1 | a0 2-3 | a1 4-5 | share 6
+    auto at = [&](int rw, int cb) { return *(const int *)((const char *)T + ((rw << 2) + cb)); };
+    // dword b[6]: which pairs a later rectangle shares with rectangle 0 (wave-uniform: scalar branches)
+    const int share = f.b[6];
+    const int ca = cmap[xw + f.a[0]], cb = cmap[xw + f.a[3]];
+    const int ra = rmap[yw + f.a[6]], rb = rmap[yw + f.a[9]];
+    auto rs = [&](int x0, int x1, int y0, int y1, int sh) {
+        int c0 = ca, c1 = cb, r0 = ra, r1 = rb;
+        if (!(sh & 2)) { c0 = cmap[xw + x0]; c1 = cmap[xw + x1]; }
+        if (!(sh & 1)) { r0 = rmap[yw + y0]; r1 = rmap[yw + y1]; }
+        return at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
+    };
+    const int s0 = at(ra, ca) - at(ra, cb) - at(rb, ca) + at(rb, cb);
+    const int s1 = rs(f.a[1], f.a[4], f.a[7], f.a[10], share);
+    const double t = __hiloint2double(f.b[1], f.b[0]) * vnf;
+    const float w0 = __int_as_float(f.a[12]), w1 = __int_as_float(f.a[13]);
+    double v;
+    if (PAIR) {
+        const float fs = (float)s0 * w0 + (float)s1 * w1;
+        v = (double)fs;
+    } else {
+        v = (double)((float)s0 * w0);
+        v += (double)((float)s1 * w1);
+        if (f.a[15] == 3) {
+            const int s2 = rs(f.a[2], f.a[5], f.a[8], f.a[11], share >> 2);
+            v += (double)((float)s2 * __int_as_float(f.a[14]));
+        }
+    }
+    const double a0 = __hiloint2double(f.b[3], f.b[2]), a1 = __hiloint2double(f.b[5], f.b[4]);
+    return v >= t ? a1 : a0;
+}
+// one stage's sum over stumps j0, j0 + step, ... < count for one window, records wave-uniform
+template <bool PAIR>
+__device__ __forceinline__ double tile_stage_sum(const int *T, const unsigned short *cmap, const unsigned short *rmap, int xw, int yw,
+                                                 double vnf, const TStumpRec *recs, int j0, int count, int step)
+{
+    // the table pointer is wave-uniform but comes out of a vector load: hand the asm a scalar copy
+    const unsigned long long u = (unsigned long long)recs;
+    const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+    const TStumpRec *base = (const TStumpRec *)ub;
+    double sum = 0.0;
+    for (int j = j0; j < count; j += step) sum += tile_vote_s<PAIR>(T, cmap, rmap, xw, yw, vnf, load_srec(base + j));
+    return sum;
+}
+
 // LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
 struct TileLds {
     double *psum; unsigned short *q0, *winx, *winy; int *qn; double *vnf_s; unsigned *rej; int *carry;
@@ -492,6 +555,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
 {
     const int tid = threadIdx.x;
     CTStumpRec *recs = (CTStumpRec *)sc.trecs;
+    const TStumpRec *urecs = sc.trecs;
     const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
     const double *__restrict__ vnfp = a.vnf + vbase;
     auto vnf_of = [&](int w) {
@@ -529,9 +593,8 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 const double vnf = vnf_of(w);
                 if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
                     const int pu = __builtin_amdgcn_readfirstlane(p);
-                    for (int j = pu; j < st.count; j += P)
-                        part += pair ? tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
+                    part = pair ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, pu, st.count, P)
+                                : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, pu, st.count, P);
                 } else {
                     for (int j = p; j < st.count; j += P)
                         part += pair ? tile_vote<true, false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
@@ -556,9 +619,8 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 w = qi[i];
                 const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
                 const double vnf = vnf_of(w);
-                double stage_sum = 0.0;
-                if (pair) for (int j = 0; j < st.count; j++) stage_sum += tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
-                else for (int j = 0; j < st.count; j++) stage_sum += tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
+                const double stage_sum = pair ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1)
+                                              : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1);
                 pass = !(stage_sum < (double)st.thr);
             }
             queue_push(pass, w, qo, &L.qn[cout]);
@@ -637,7 +699,6 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         __syncthreads();             // previous tile completely done with LDS
         const TileRec t = a.tiles[b.first_tile + ti];
         const TileLds L = carve_tile(lds, t);
-        CTStumpRec *recs = (CTStumpRec *)sc.trecs;
         tile_fill(a, t, sc, slot, L);
         __syncthreads();
         // variance + stage 0 for every window of the tile; a wave covers two window rows
@@ -659,9 +720,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
                 vnf = vnf * sc.inv_area - mean * mean;
                 vnf = vnf >= 0. ? sqrt(vnf) : 1.;
                 L.vnf_s[w] = vnf;
-                double stage_sum = 0.0;
-                if (pair0) for (int j = 0; j < st0.count; j++) stage_sum += tile_vote<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st0.first + j]);
-                else for (int j = 0; j < st0.count; j++) stage_sum += tile_vote<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st0.first + j]);
+                const double stage_sum = pair0 ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1)
+                                               : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1);
                 pass0 = !(stage_sum < (double)st0.thr);
             }
             const unsigned long long fb = __ballot(active && !pass0);

@@ -82,7 +82,10 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
     int x0[3], x1[3], y0[3], y1[3];
     float w[3]; int nrect;
     double thr, a0, a1;
+    int share;              // bit 0 / 1: rectangle 1 has rectangle 0's rows / columns; bit 2 / 3: rectangle 2 likewise
+    int pad;                // 96 bytes: the tile kernels fetch a record with two wide scalar loads (16 + 8 dwords)
 };
+static_assert(sizeof(TStumpRec) == 96, "TStumpRec layout is read dword by dword in kernels_cascade.hip");
 // A band is one row of tiles (<= 32 window rows of one scale, the full scan width): k_band walks it left to right in one
 // workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
 // Per scale: the distinct corner columns / rows (window-relative pixels) of the late stages' stumps.  k_deep stages that

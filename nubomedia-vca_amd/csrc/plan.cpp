@@ -107,6 +107,12 @@ void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
         r.thr = (double)n.threshold;
         r.a0 = (double)c.alpha[hc.first_alpha]; r.a1 = (double)c.alpha[hc.first_alpha + 1];
         r.nrect = n.nrect;
+        // an x2 / x3 feature's rectangles span the same rows, a y2 / y3 feature's the same columns (same y and height, or
+        // same x and width, go through the same rounding): the tile kernels look the shared pair up once
+        for (int q = 1; q < n.nrect; q++) {
+            if (r.y0[q] == r.y0[0] && r.y1[q] == r.y1[0]) r.share |= 1 << (2 * (q - 1));
+            if (r.x0[q] == r.x0[0] && r.x1[q] == r.x1[0]) r.share |= 2 << (2 * (q - 1));
+        }
     }
 }
 
