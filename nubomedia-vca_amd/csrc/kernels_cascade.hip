@@ -682,7 +682,15 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // longest bands first across the whole batch (a band is a serial walk; the short ones level the tail)
-    const int bi = blockIdx.x / a.batch, slot = blockIdx.x - bi * a.batch;
+    int bi = blockIdx.x / a.batch, slot = blockIdx.x - bi * a.batch;
+    if (a.band_map) {
+        // EXPERIMENT: workgroups go round-robin over the 8 XCDs; keep a frame on one XCD and run the frames of an XCD one
+        // after the other, so that the bands of a frame (all scales) share that XCD's L2
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int g = a.band_map;                                  // frames of an XCD walked together (1, 2, ...)
+        const int fi = k / (a.band_blocks_per_frame * g), r = k - fi * a.band_blocks_per_frame * g;
+        bi = r / g; slot = xcd + 8 * (fi * g + (r - bi * g));
+    }
     const BandRec b = a.bands[a.band_order[bi]];
     const ScaleRec &sc = a.scales[b.scale];
     const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;

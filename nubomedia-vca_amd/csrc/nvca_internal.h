@@ -283,7 +283,7 @@ struct CascadeArgs {
     const int *order; int blocks_per_frame;   // k_strip dispatch slot -> strip
     const TileRec *tiles; const int *tile_order; int tile_blocks_per_frame;   // k_tile
     const unsigned short *tcoords; int tile_lds;
-    const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch;   // k_band
+    const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch; int band_map;  // k_band
     const DeepRec *deeprecs;                  // [nscales] or null (k_deep: LDS patches)
     // global survivor lists (k_list_*): per-scale segments; counts per stage
     unsigned *list_cnt;            // [nstages][64]
