@@ -41,6 +41,18 @@ static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer user
     fflush(stdout);
     return GST_PAD_PROBE_OK;
 }
+// NVCA_HARNESS_DUMP=<file>: the frames leaving branch 0's element are appended to it (what a viewer would see)
+static GstPadProbeReturn on_buffer(GstPad *, GstPadProbeInfo *info, gpointer user)
+{
+    GstBuffer *buf = GST_PAD_PROBE_INFO_BUFFER(info);
+    GstMapInfo map;
+    if (buf && gst_buffer_map(buf, &map, GST_MAP_READ)) {
+        fwrite(map.data, 1, map.size, (FILE *)user);
+        fflush((FILE *)user);
+        gst_buffer_unmap(buf, &map);
+    }
+    return GST_PAD_PROBE_OK;
+}
 static void on_signal(GstElement *, const gchar *payload, gpointer user)
 {
     const int k = GPOINTER_TO_INT(user);
@@ -80,6 +92,10 @@ static int add_branch(GstElement *pipe, int k, int argc, char **argv, const char
     if (!gst_element_link_many(src, parse, chain, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }
     GstPad *sp = gst_element_get_static_pad(el, "src");
     gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_EVENT_DOWNSTREAM, on_event, GINT_TO_POINTER(k), NULL);
+    if (k == 0 && getenv("NVCA_HARNESS_DUMP")) {
+        FILE *dump = fopen(getenv("NVCA_HARNESS_DUMP"), "wb");
+        if (dump) gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, on_buffer, dump, NULL);
+    }
     gst_object_unref(sp);
     const char *sigs[] = {"face-event", "tracker-event", "eye-event", "nose-event", "mouth-event", "ear-event"};
     for (const char *sig : sigs)

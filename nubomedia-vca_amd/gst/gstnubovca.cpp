@@ -26,6 +26,7 @@
 #include <map>
 #include <vector>
 #include <algorithm>
+#include <math.h>
 #include "nubovca.h"
 
 GST_DEBUG_CATEGORY_STATIC(nubovca_debug);
@@ -167,6 +168,58 @@ static double now_ms()
 {
     struct timeval t; gettimeofday(&t, NULL);
     return t.tv_sec * 1000.0 + t.tv_usec / 1000.0;
+}
+
+// ---------------------------------------------------------------- view-* drawing (host side, on the mapped frame)
+// The reference draws on the frame in place when a view property is on: cvRectangle(..., thickness 3, line type 8)
+// around every box and cv::circle(..., thickness 4) around the eyes (FACE/BaseFace.cpp:70-82, NOSE :898-905,
+// MOUTH :896-903, EAR :750-758, EYE :1069-1099, TRK :389).  Frames are host memory here, so this stays on the host
+// ("stays on host"); it is written from the documented geometry of OpenCV's thick primitives -- a 3-pixel
+// band centred on each edge with radius-1 round joins, a 4-pixel ring -- and is NOT pixel-verified against OpenCV,
+// which is not available offline.  Boxes, events and signals do not depend on it.
+struct Canvas { guint8 *data; int w, h, stride, bpp; };
+static inline void put_px(const Canvas &c, int x, int y, const guint8 *col)
+{
+    if ((unsigned)x >= (unsigned)c.w || (unsigned)y >= (unsigned)c.h) return;
+    guint8 *p = c.data + (size_t)y * c.stride + (size_t)x * c.bpp;
+    for (int k = 0; k < c.bpp; k++) p[k] = col[k];
+}
+static void fill_span(const Canvas &c, int x0, int x1, int y0, int y1, const guint8 *col)
+{
+    x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, c.w - 1); y1 = std::min(y1, c.h - 1);
+    for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) put_px(c, x, y, col);
+}
+// corners (x0, y0) and (x1, y1) inclusive, as cvRectangle takes them
+static void draw_rect3(const Canvas &c, int x0, int y0, int x1, int y1, const guint8 *col)
+{
+    if (x0 > x1) std::swap(x0, x1);
+    if (y0 > y1) std::swap(y0, y1);
+    fill_span(c, x0, x1, y0 - 1, y0 + 1, col); fill_span(c, x0, x1, y1 - 1, y1 + 1, col);
+    fill_span(c, x0 - 1, x0 + 1, y0, y1, col); fill_span(c, x1 - 1, x1 + 1, y0, y1, col);
+    const int cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
+    for (int k = 0; k < 4; k++) {                           // radius-1 round join: the 4-neighbourhood of the vertex
+        put_px(c, cx[k] - 1, cy[k], col); put_px(c, cx[k] + 1, cy[k], col);
+        put_px(c, cx[k], cy[k] - 1, col); put_px(c, cx[k], cy[k] + 1, col);
+    }
+}
+static void draw_ring4(const Canvas &c, int cx, int cy, int radius, const guint8 *col)
+{
+    if (radius < 0) return;
+    const int ro = radius + 2, ri = std::max(radius - 2, 0);
+    for (int y = -ro; y <= ro; y++)
+        for (int x = -ro; x <= ro; x++) {
+            const int d2 = x * x + y * y;
+            if (d2 <= ro * ro && d2 >= ri * ri) put_px(c, cx + x, cy + y, col);
+        }
+}
+#define BGR_OF_RGB(r, g, b) {b, g, r, 0}
+static Canvas canvas_of(GstVideoFrame *frame)
+{
+    Canvas c;
+    c.data = (guint8 *)GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+    c.w = GST_VIDEO_FRAME_WIDTH(frame); c.h = GST_VIDEO_FRAME_HEIGHT(frame);
+    c.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0); c.bpp = GST_VIDEO_FRAME_COMP_PSTRIDE(frame, 0);
+    return c;
 }
 
 // =====================================================================================
@@ -318,6 +371,15 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
                              ",width:" + std::to_string((guint)boxes[i].w) + ",height:" + std::to_string((guint)boxes[i].h) + ";";
             }
             gst_pad_push_event(GST_BASE_TRANSFORM(f)->srcpad, gst_event_new_custom(GST_EVENT_CUSTOM_DOWNSTREAM, message));
+            if (f->view_faces > 0 && !f->image_to_overlay) {
+                // Faces::draw: (x, y) .. (x + w - 1, y + h - 1) of the working-image box, times the integer scale, in
+                // colors[1] = CV_RGB(0,128,255)  (FACE/BaseFace.cpp:70-82, FACE/kmsfacedetect.cpp:144-151,832-850)
+                static const guint8 col[4] = BGR_OF_RGB(0, 128, 255);
+                const Canvas cv = canvas_of(frame);
+                const int scale = nf.width / f->p.width_to_process;
+                for (int i = 0; i < n; i++)
+                    draw_rect3(cv, boxes[i].x, boxes[i].y, boxes[i].x + boxes[i].w - scale, boxes[i].y + boxes[i].h - scale, col);
+            }
             if (n > 0) {
                 const double t = now_ms();
                 if (1 == f->server_events && t - f->time_events_ms > f->events_ms) {
@@ -460,6 +522,11 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
         if (rc != NVCA_OK) GST_ERROR("nvca_tracker_process: %d", rc);
         else if (n > 0) {
             if (n > 4096) n = 4096;
+            if (t->visual_mode > 0) {                        /* TRK/gstnubotracker.cpp:389: tl() .. br(), Scalar(0,0,255) */
+                static const guint8 col[4] = {0, 0, 255, 0};
+                const Canvas cv = canvas_of(frame);
+                for (int i = 0; i < n; i++) draw_rect3(cv, bx[i].x, bx[i].y, bx[i].x + bx[i].w, bx[i].y + bx[i].h, col);
+            }
             std::string s;
             if (1 == t->server_events)
                 for (int i = 0; i < n; i++)
@@ -690,6 +757,35 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
             } else {                                     // EAR: right list then left list; the event is never pushed (:196-290)
                 for (int k = 0; k < nb; k++) str += box_str(b[k]);
                 for (int k = 0; k < na; k++) str += box_str(a[k]);
+            }
+            if (1 == f->view && !f->image_to_overlay) {
+                const Canvas cv = canvas_of(frame);
+                if (kind == NVCA_PART_EYE) {                 // one circle per side, first box only (EYE :1069-1099)
+                    static const guint8 col[4] = {255, 0, 0, 0};              /* Scalar(255, 0, 0) */
+                    int radius = -1;
+                    if (na > 0) {
+                        radius = (int)lrint((a[0].w + a[0].h) * 0.25);
+                        draw_ring4(cv, a[0].x + a[0].w / 2, a[0].y + a[0].h / 2, radius, col);
+                    }
+                    if (nb > 0) {
+                        if (radius < 0) radius = (int)lrint((b[0].w + b[0].h) * 0.25);
+                        draw_ring4(cv, b[0].x + b[0].w / 2, b[0].y + b[0].h / 2, radius, col);
+                    }
+                } else {
+                    // palettes and corner arithmetic as written in NOSE :808-815,902-905 (x + w, y + h - 1),
+                    // MOUTH :814-821,900-903 (x + w - 1, y + h - 1), EAR :736-743,754-758 (x + w, y + h - 1)
+                    static const guint8 nose_col[8][4] = {BGR_OF_RGB(255, 0, 255), BGR_OF_RGB(255, 0, 0), BGR_OF_RGB(255, 255, 0), BGR_OF_RGB(255, 128, 0),
+                                                          BGR_OF_RGB(0, 255, 0), BGR_OF_RGB(0, 255, 255), BGR_OF_RGB(0, 128, 255), BGR_OF_RGB(0, 0, 255)};
+                    static const guint8 mouth_col[8][4] = {BGR_OF_RGB(255, 255, 0), BGR_OF_RGB(255, 128, 0), BGR_OF_RGB(255, 0, 0), BGR_OF_RGB(255, 0, 255),
+                                                           BGR_OF_RGB(0, 128, 255), BGR_OF_RGB(0, 0, 255), BGR_OF_RGB(0, 255, 255), BGR_OF_RGB(0, 255, 0)};
+                    static const guint8 ear_col[8][4] = {BGR_OF_RGB(0, 0, 255), BGR_OF_RGB(0, 128, 255), BGR_OF_RGB(0, 255, 255), BGR_OF_RGB(0, 255, 0),
+                                                         BGR_OF_RGB(255, 128, 0), BGR_OF_RGB(255, 255, 0), BGR_OF_RGB(255, 0, 0), BGR_OF_RGB(255, 0, 255)};
+                    const guint8 (*pal)[4] = kind == NVCA_PART_NOSE ? nose_col : kind == NVCA_PART_MOUTH ? mouth_col : ear_col;
+                    const int dx = kind == NVCA_PART_MOUTH ? -1 : 0;
+                    int j = 0;
+                    if (kind == NVCA_PART_EAR) for (int k = 0; k < nb; k++, j++) draw_rect3(cv, b[k].x, b[k].y, b[k].x + b[k].w + dx, b[k].y + b[k].h - 1, pal[j % 8]);
+                    for (int k = 0; k < na; k++, j++) draw_rect3(cv, a[k].x, a[k].y, a[k].x + a[k].w + dx, a[k].y + a[k].h - 1, pal[j % 8]);
+                }
             }
             if (kind == NVCA_PART_EAR) gst_structure_free(message);
             else gst_pad_push_event(GST_BASE_TRANSFORM(f)->srcpad, gst_event_new_custom(GST_EVENT_CUSTOM_DOWNSTREAM, message));

@@ -48,7 +48,7 @@ def test_tracker_element_surface(shim):
     assert "Range: 0 - 255 Default: 20" in out and "Range: 0 - 300000 Default: 30000" in out
 
 
-def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None, extra_env=None):
+def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None, extra_env=None, dump_frames=False):
     """frames: one list of frames, or a list of such lists (one pipeline branch per list)"""
     with tempfile.TemporaryDirectory() as td:
         branches = frames if isinstance(frames[0], (list, tuple)) else [frames]
@@ -68,8 +68,15 @@ def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_c
                 with open(os.path.join(td, name), "w") as f:
                     f.write(xml)
             env["NVCA_CASCADE_DIR"] = td
+        dump = os.path.join(td, "out.raw")
+        if dump_frames:
+            env["NVCA_HARNESS_DUMP"] = dump
         r = subprocess.run([build_gst.HARNESS, element, fmt, str(W), str(H), raw] + list(props), env=env,
                            capture_output=True, text=True, timeout=300)
+        if dump_frames:
+            bpp = 4 if fmt == "BGRA" else 3
+            data = np.fromfile(dump, np.uint8) if os.path.exists(dump) else np.zeros(0, np.uint8)
+            r.frames_out = data.reshape(-1, H, W, bpp) if data.size and data.size % (H * W * bpp) == 0 else None
         return r
 
 
@@ -106,6 +113,41 @@ def test_face_pipeline_events_match_oracle(shim, synth_xml, orc_cascade):
         n_boxes += len(boxes)
     assert n_boxes > 0
     assert any(l.startswith("signal x:") for l in r.stdout.splitlines())
+
+
+@pytest.mark.gpu
+def test_view_faces_draws_the_boxes_in_place(shim, synth_xml, orc_cascade):
+    """view-faces=1: a 3-pixel outline from (x, y) to (x + w - scale, y + h - scale) in CV_RGB(0,128,255)
+    (FACE/BaseFace.cpp:70-82); with view-faces=0 the frame leaves untouched"""
+    import orc
+    from nubovca import synth
+    W, H = 640, 480
+    frames = [synth.make_bgr(W, H, 300 + i, "natural", [(40 + 6 * i, H // 6, H // 2)]) for i in range(3)]
+    off = _run_harness("nubofacedetector", "BGR", W, H, frames, cascade_xml=synth_xml, dump_frames=True)
+    assert off.returncode == 0 and off.frames_out is not None and len(off.frames_out) == len(frames)
+    for fr, out in zip(frames, off.frames_out):
+        assert np.array_equal(fr, out)
+    on = _run_harness("nubofacedetector", "BGR", W, H, frames, props=["view-faces=1"], cascade_xml=synth_xml, dump_frames=True)
+    assert on.returncode == 0 and on.frames_out is not None and len(on.frames_out) == len(frames)
+    ofs = orc.FaceStream(orc_cascade)
+    scale = W // 160
+    drawn = 0
+    for fr, out in zip(frames, on.frames_out):
+        boxes, _ = ofs.process(fr)
+        changed = np.any(out != fr, axis=2)
+        expect = np.zeros((H, W), bool)
+        for (x, y, w, h) in boxes:
+            x1, y1 = x + w - scale, y + h - scale
+            for (xa, xb, ya, yb) in ((x, x1, y - 1, y + 1), (x, x1, y1 - 1, y1 + 1), (x - 1, x + 1, y, y1), (x1 - 1, x1 + 1, y, y1)):
+                expect[max(ya, 0):yb + 1, max(xa, 0):xb + 1] = True
+            for (cx, cy) in ((x, y), (x1, y), (x1, y1), (x, y1)):
+                for (dx, dy) in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    if 0 <= cx + dx < W and 0 <= cy + dy < H:
+                        expect[cy + dy, cx + dx] = True
+            drawn += 1
+        assert not np.any(changed & ~expect)                       # nothing outside the outlines was touched
+        assert np.all(out[expect] == np.array([255, 128, 0], np.uint8))
+    assert drawn > 0
 
 
 @pytest.mark.gpu
