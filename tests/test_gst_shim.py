@@ -115,6 +115,49 @@ def test_face_pipeline_events_match_oracle(shim, synth_xml, orc_cascade):
     assert any(l.startswith("signal x:") for l in r.stdout.splitlines())
 
 
+def _server_parse(payload):
+    """What Kurento's server object makes of a signal string (NuboFaceDetectorImpl.cpp:55-129, same in the other
+    modules): split on ';', then ',', then ':' into one flat token list; walk it in key/value pairs; a record is
+    emitted when its "height" arrives (fields that were not seen stay 0)."""
+    flat = []
+    for face in payload.split(";"):
+        for field in face.split(","):
+            flat.extend(field.split(":"))
+    out, cur = [], dict(x=0, y=0, width=0, height=0)
+    for i in range(0, len(flat), 2):
+        key = flat[i]
+        if key in cur and i + 1 < len(flat):
+            cur[key] = int(flat[i + 1])
+            if key == "height":
+                out.append((cur["x"], cur["y"], cur["width"], cur["height"]))
+                cur = dict(x=0, y=0, width=0, height=0)
+    return out
+
+
+def test_server_double_parser():
+    assert _server_parse("x:1,y:2,width:3,height:4;x:5,y:6,width:7,height:8;") == [(1, 2, 3, 4), (5, 6, 7, 8)]
+    assert _server_parse("") == [] and _server_parse("x:9,y:9;") == []
+
+
+@pytest.mark.gpu
+def test_face_signal_as_the_server_reads_it(shim, synth_xml, orc_cascade):
+    """the string signal, parsed the way the Kurento module's server object parses it, carries the oracle's boxes"""
+    import orc
+    from nubovca import synth
+    W, H = 640, 480
+    frames = [synth.make_bgr(W, H, 700 + i, "natural", [(60 + 8 * i, H // 6, H // 2), (380, 40 + 4 * i, H // 3)]) for i in range(6)]
+    r = _run_harness("nubofacedetector", "BGR", W, H, frames, props=["activate-events=1", "events-ms=0"], cascade_xml=synth_xml)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [_server_parse(l[len("signal "):]) for l in r.stdout.splitlines() if l.startswith("signal ")]
+    ofs = orc.FaceStream(orc_cascade)
+    exp = []
+    for fr in frames:
+        boxes, _ = ofs.process(fr)
+        if len(boxes):                                   # the element signals only when there is a box (FACE :228-241)
+            exp.append([tuple(int(v) for v in b) for b in boxes])
+    assert len(exp) > 0 and got == exp
+
+
 @pytest.mark.gpu
 def test_view_faces_draws_the_boxes_in_place(shim, synth_xml, orc_cascade):
     """view-faces=1: a 3-pixel outline from (x, y) to (x + w - scale, y + h - scale) in CV_RGB(0,128,255)
