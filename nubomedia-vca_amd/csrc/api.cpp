@@ -123,8 +123,35 @@ struct Workspace {
 
 // one cached geometry: source frame -> working image -> scan tables
 struct PyrLevel { double f; int szw, szh, winw, winh; size_t gray_off; int gpitch; int plane_off; };
+// Source rows a shrinking bilinear resize reads, when they form equal runs at a fixed period (integer ratios: a 1080p
+// frame shrunk by 12 reads rows 12k + 5 and 12k + 6 only).  Host frames then cross PCIe as one strided 2-D copy of those
+// rows -- into their natural places of the staged frame, so the kernels are unchanged -- instead of whole.
+struct RowCopy {
+    bool on = false;
+    int first = 0, period = 0, run = 0, count = 0;
+};
+static RowCopy make_rowcopy(const ResizeTab &t)
+{
+    RowCopy rc;
+    if (t.mode != 1 || t.dh <= 0) return rc;
+    std::vector<int> rows;
+    auto clampr = [&](int r) { return r >= 0 ? (r < t.sh ? r : t.sh - 1) : 0; };
+    for (int dy = 0; dy < t.dh; dy++) { rows.push_back(clampr(t.yofs[dy])); rows.push_back(clampr(t.yofs[dy] + 1)); }
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    if (rows.size() * 2 > (size_t)t.sh) return rc;              // no saving worth a strided copy
+    std::vector<std::pair<int, int>> runs;                          // maximal runs of consecutive rows
+    for (int r : rows) { if (!runs.empty() && runs.back().first + runs.back().second == r) runs.back().second++; else runs.push_back({r, 1}); }
+    const int period = runs.size() > 1 ? runs[1].first - runs[0].first : t.sh;
+    for (size_t i = 0; i < runs.size(); i++)
+        if (runs[i].second != runs[0].second || runs[i].first != runs[0].first + (int)i * period) return rc;
+    rc.on = true; rc.first = runs[0].first; rc.period = period; rc.run = runs[0].second; rc.count = (int)runs.size();
+    return rc;
+}
+
 struct GeomPlan {
     ResizeTab tab;
+    RowCopy rowcopy;
     DevBuf d_xofs, d_yofs, d_ialpha, d_ibeta;
     DetectPlan det;
     PreGeom g;
@@ -546,6 +573,7 @@ static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, 
     std::unique_ptr<GeomPlan> gp(new GeomPlan());
     make_geom(gp->g, W, H, stride, cn, cols, rows);
     build_resize_tab(W, H, cols, rows, gp->tab);
+    gp->rowcopy = make_rowcopy(gp->tab);
     int rc = upload_tab(ctx, *gp);
     if (rc) return rc;
     std::string err;
@@ -784,8 +812,10 @@ static size_t staging_need(const nvca_frame *frames, const int *idx, int n)
 // frame pointers of n frames -> device pointer array entries [r0, r0 + n); host frames are copied into the staging
 // buffer first (from byte offset *off on, advanced).  `st`: the stream the copies are queued on.
 static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx, int n, int bpp, int r0 = 0,
-                        hipStream_t st = nullptr, size_t *off_io = nullptr)
+                        hipStream_t st = nullptr, size_t *off_io = nullptr, const RowCopy *rows = nullptr)
 {
+    static const bool sparse_off = getenv("NVCA_SPARSE_INGEST") && atoi(getenv("NVCA_SPARSE_INGEST")) == 0;
+    if (sparse_off || (rows && !rows->on)) rows = nullptr;
     Workspace &ws = *ctx->ws;
     if (!st) st = ctx->stream;
     if (!off_io) {           // stand-alone call: size the buffers here
@@ -801,6 +831,21 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
         const nvca_frame &f = frames[idx ? idx[i] : i];
         if (f.mem == NVCA_MEM_HOST) {
             uint8_t *d = ws.res[ws.cur_res].staging.as<uint8_t>() + off;
+            if (rows) {
+                // only the rows the resize reads; a run that ends on the frame's last row is copied without the row padding
+                // (the caller's buffer need not extend past the last pixel)
+                const size_t pitch = (size_t)rows->period * f.stride, start = (size_t)rows->first * f.stride;
+                const bool tail = rows->first + (rows->count - 1) * rows->period + rows->run == f.height;
+                const int full = tail ? rows->count - 1 : rows->count;
+                if (full > 0)
+                    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(d + start, pitch, (const uint8_t *)f.data + start, pitch, (size_t)rows->run * f.stride,
+                                                         (size_t)full, hipMemcpyHostToDevice, st));
+                if (tail) {
+                    const size_t o = start + (size_t)full * pitch;
+                    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d + o, (const uint8_t *)f.data + o, (size_t)(rows->run - 1) * f.stride + (size_t)f.width * bpp,
+                                                       hipMemcpyHostToDevice, st));
+                }
+            } else
             NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp,
                                                hipMemcpyHostToDevice, st));
             hp[i] = d;
@@ -1480,7 +1525,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         std::vector<CascadeJob> &jobs = grp.jobs;
         for (int s0 = 0; s0 < batch; s0 += chunk) {
             const int nc = std::min(chunk, batch - s0);
-            if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->stream, &stage_off))) return rc;
+            if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->stream, &stage_off, &gp->rowcopy))) return rc;
             if (piped) {
                 while (ctx->chunk_events.size() <= jobs.size()) {
                     hipEvent_t ev; NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));

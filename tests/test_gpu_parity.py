@@ -350,6 +350,42 @@ def test_face_stream_sequence(ctx, casc, orc_cascade, W, H, props):
     fs.close()
 
 
+@pytest.mark.parametrize("W,H,w2p", [
+    (1920, 1080, 160),       # ratio 12: rows 12k+5, 12k+6 cross PCIe as one strided copy
+    (1920, 1080, 320),       # ratio 6
+    (1280, 720, 160),        # ratio 8
+    (1000, 562, 160),        # 1000/166: irregular row pattern -> whole frames
+    (644, 484, 160),         # ratio 4 + a remainder (scale 4, 161 x 121): the run pattern reaches the last row
+])
+def test_face_host_frames_shrinking_ingest(ctx, casc, orc_cascade, W, H, w2p):
+    """host frames in the reference's shrink-first mode: only the source rows the bilinear resize reads are copied to the
+    device (into their natural places of the staged frame); every frame of the sequence differs, so a row that was
+    needed but not copied would show up as stale data"""
+    import orc
+    from nubovca import capi, synth
+    fs = capi.FaceStream(ctx, casc, width_to_process=w2p)
+    ofs = orc.FaceStream(orc_cascade, width_to_process=w2p)
+    seen = 0
+    for i in range(6):
+        f = synth.make_bgr(W, H, 4000 + 17 * i, "natural", [(W // 8 + 20 * i, H // 6, H // 2)])
+        boxes, ids = fs.process(f)
+        eb, eid = ofs.process(f)
+        assert np.array_equal(boxes, eb), (i, boxes, eb)
+        assert np.array_equal(ids, eid)
+        seen += len(eb)
+    assert seen > 0
+    # the same through the batched entry point (chunked ingest on the copy stream)
+    frames = [synth.make_bgr(W, H, 4200 + i, "natural", [(W // 8 + 10 * i, H // 6, H // 2)]) for i in range(16)]
+    streams = [capi.FaceStream(ctx, casc, width_to_process=w2p) for _ in frames]
+    res = ctx.face_batch_process(streams, [capi.make_frame(f) for f in frames], cap=64)
+    for f, (b, _) in zip(frames, res):
+        eb, _ = orc.FaceStream(orc_cascade, width_to_process=w2p).process(f)
+        assert np.array_equal(b, eb)
+    for st in streams:
+        st.close()
+    fs.close()
+
+
 def test_face_batch_equals_sequential(ctx, casc, orc_cascade):
     """3 streams x 6 frames interleaved in ONE batched call == each stream run alone on the oracle."""
     import orc
