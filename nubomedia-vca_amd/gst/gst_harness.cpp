@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 static GstPadProbeReturn on_event(GstPad *, GstPadProbeInfo *info, gpointer user)
 {
@@ -60,10 +62,28 @@ static void on_signal(GstElement *, const gchar *payload, gpointer user)
     fflush(stdout);
 }
 
+struct FrameData { std::vector<unsigned char> bytes; };
+static GstPadProbeReturn on_fill(GstPad *, GstPadProbeInfo *info, gpointer user)
+{
+    FrameData *fd = (FrameData *)user;
+    GstBuffer *buf = gst_buffer_make_writable(GST_PAD_PROBE_INFO_BUFFER(info));
+    GST_PAD_PROBE_INFO_DATA(info) = buf;
+    GstMapInfo map;
+    if (gst_buffer_map(buf, &map, GST_MAP_WRITE)) {
+        memcpy(map.data, fd->bytes.data(), std::min((size_t)map.size, fd->bytes.size()));
+        gst_buffer_unmap(buf, &map);
+    }
+    return GST_PAD_PROBE_OK;
+}
+
 // one branch: filesrc ! rawvideoparse ! <element or bin> ! fakesink, observed on the element named "el"
 static int add_branch(GstElement *pipe, int k, int argc, char **argv, const char *file)
 {
-    GstElement *src = gst_element_factory_make("filesrc", NULL), *parse = gst_element_factory_make("rawvideoparse", NULL);
+    // NVCA_HARNESS_LOOP=<n>: the file holds one frame, which is pushed n times (throughput runs without gigabyte files):
+    // videotestsrc provides the buffers, a probe copies the frame into each (the cost filesrc's read would have)
+    const char *loop = getenv("NVCA_HARNESS_LOOP");
+    GstElement *src = gst_element_factory_make(loop ? "videotestsrc" : "filesrc", NULL);
+    GstElement *parse = gst_element_factory_make(loop ? "capsfilter" : "rawvideoparse", NULL);
     // argv[1]: a factory name, or a bin description ("a ! b name=el ...") whose element named "el" is observed
     GstElement *sink = gst_element_factory_make("fakesink", NULL);
     GstElement *el = NULL, *chain = NULL;
@@ -78,10 +98,25 @@ static int add_branch(GstElement *pipe, int k, int argc, char **argv, const char
     }
     if (!src || !parse || !el || !sink) { fprintf(stderr, "missing element (%s?)\n", argv[1]); return 3; }
     const bool bgra = !strcmp(argv[2], "BGRA");
-    g_object_set(src, "location", file, NULL);
-    gst_util_set_object_arg(G_OBJECT(parse), "format", bgra ? "bgra" : "bgr");
-    g_object_set(parse, "width", atoi(argv[3]), "height", atoi(argv[4]), NULL);
-    gst_util_set_object_arg(G_OBJECT(parse), "framerate", "30/1");
+    if (loop) {
+        FrameData *fd = new FrameData();
+        FILE *fp = fopen(file, "rb");
+        if (fp) { fseek(fp, 0, SEEK_END); fd->bytes.resize((size_t)ftell(fp)); fseek(fp, 0, SEEK_SET); if (fread(fd->bytes.data(), 1, fd->bytes.size(), fp) != fd->bytes.size()) fd->bytes.clear(); fclose(fp); }
+        gst_util_set_object_arg(G_OBJECT(src), "pattern", "black");
+        g_object_set(src, "num-buffers", atoi(loop), NULL);
+        GstCaps *caps = gst_caps_new_simple("video/x-raw", "format", G_TYPE_STRING, bgra ? "BGRA" : "BGR", "width", G_TYPE_INT, atoi(argv[3]),
+                                            "height", G_TYPE_INT, atoi(argv[4]), "framerate", GST_TYPE_FRACTION, 30, 1, NULL);
+        g_object_set(parse, "caps", caps, NULL);
+        gst_caps_unref(caps);
+        GstPad *vp = gst_element_get_static_pad(src, "src");
+        gst_pad_add_probe(vp, GST_PAD_PROBE_TYPE_BUFFER, on_fill, fd, NULL);
+        gst_object_unref(vp);
+    } else {
+        g_object_set(src, "location", file, NULL);
+        gst_util_set_object_arg(G_OBJECT(parse), "format", bgra ? "bgra" : "bgr");
+        g_object_set(parse, "width", atoi(argv[3]), "height", atoi(argv[4]), NULL);
+        gst_util_set_object_arg(G_OBJECT(parse), "framerate", "30/1");
+    }
     for (int i = 6; i < argc; i++) {
         std::string kv(argv[i]);
         const size_t eq = kv.find('=');

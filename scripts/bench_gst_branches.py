@@ -1,6 +1,6 @@
 """Aggregate frame rate of B nubofacedetector elements in ONE process (one pipeline branch each, own streaming thread),
 through the GStreamer shim, with and without the shim's frame combiner.  Start-up (gst_init, plugin load, context and
-plan creation) is removed by differencing two run lengths.  Usage: python scripts/bench_gst_branches.py [B] [W H]"""
+plan creation) is removed by differencing two run lengths.  Usage: python scripts/bench_gst_branches.py [B] [W H] [frames per branch]"""
 import os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,14 +15,13 @@ build_gst.build(required=True)
 xml = synth.synthetic_cascade_xml()
 with tempfile.TemporaryDirectory() as td:
     open(os.path.join(td, "haarcascade_frontalface_alt.xml"), "w").write(xml)
-    base = [synth.make_bgr(W, H, 500 + i, "natural", [(40 + 5 * i, H // 6, H // 2)]) for i in range(10)]
+    frame = synth.make_bgr(W, H, 500, "natural", [(40, H // 6, H // 2)])
+    raw = os.path.join(td, "frame.raw")
+    with open(raw, "wb") as f:
+        f.write(frame.tobytes())
+
     def run(nframes, extra):
-        raw = os.path.join(td, "f%d.raw" % nframes)
-        if not os.path.exists(raw):
-            with open(raw, "wb") as f:
-                for i in range(nframes):
-                    f.write(base[i % len(base)].tobytes())
-        env = build_gst.env(); env["NVCA_CASCADE_DIR"] = td; env["NVCA_GST_STATS"] = "1"; env.update(extra)
+        env = build_gst.env(); env["NVCA_CASCADE_DIR"] = td; env["NVCA_GST_STATS"] = "1"; env["NVCA_HARNESS_LOOP"] = str(nframes); env.update(extra)
         t0 = time.time()
         r = subprocess.run([build_gst.HARNESS, "nubofacedetector", "BGR", str(W), str(H), ",".join([raw] * B), "process-x-every-4-frames=4"],
                            env=env, capture_output=True, text=True, timeout=600)
@@ -30,10 +29,12 @@ with tempfile.TemporaryDirectory() as td:
         assert r.returncode == 0, r.stderr[-1000:]
         stat = [l for l in r.stderr.splitlines() if "largest combined" in l]
         return dt, (stat[-1].split()[-1] if stat else "?")
-    n1 = 40
-    n2 = n1 + max(200, int(2.4e9 / (W * H * 3 * 8)))          # the long run adds a few seconds of work
-    run(n1, {}); run(n2, {})                                  # page the files and the libraries in
+
+    # every branch pushes the same one-frame file n times (multifilesrc loop); start-up is removed by differencing
+    n1 = 50
+    n2 = n1 + (int(sys.argv[4]) if len(sys.argv) > 4 else 1000)
+    run(n1, {})                                               # page the libraries in
     for label, extra in (("combined", {}), ("per-frame", {"NVCA_GST_NO_COMBINE": "1"})):
-        t1 = min(run(n1, extra)[0] for _ in range(2))
-        t2, mb = min(run(n2, extra) for _ in range(2))
-        print("%-9s %d branches %dx%d: %.0f frames/s aggregate (largest round %s)" % (label, B, W, H, (n2 - n1) * B / (t2 - t1), mb), flush=True)
+        t1, _ = run(n1, extra)
+        t2, mb = run(n2, extra)
+        print("%-9s %d branches %dx%d: %.0f frames/s aggregate over %.1f s (largest round %s)" % (label, B, W, H, (n2 - n1) * B / (t2 - t1), t2 - t1, mb), flush=True)
