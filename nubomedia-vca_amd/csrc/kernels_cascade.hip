@@ -523,14 +523,15 @@ __device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = (int)cl[c < t.ncol ? c : t.ncol - 1]; }   // clamped: loads stay unconditional
     constexpr int NW = kTileThreads / 64;
+    const int nk = (t.ncol + 63) >> 6;      // 64-column groups that hold a staged column (wave-uniform: the others are skipped)
     for (int r = wave; r < t.nrow; r += 2 * NW) {
         const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + NW < t.nrow ? ra + NW : ra;
         const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
         int va[4], vb[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
+        for (int k = 0; k < 4; k++) if (k < nk) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (lane + 64 * k < t.ncol) { L.T[ra * L.pitchT + lane + 64 * k] = va[k]; L.T[rb * L.pitchT + lane + 64 * k] = vb[k]; }
+        for (int k = 0; k < 4; k++) if (k < nk && lane + 64 * k < t.ncol) { L.T[ra * L.pitchT + lane + 64 * k] = va[k]; L.T[rb * L.pitchT + lane + 64 * k] = vb[k]; }
     }
 }
 
