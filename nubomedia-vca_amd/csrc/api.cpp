@@ -1001,12 +1001,12 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     run_integral(ctx, g, nullptr, 1);
     rc = unstage_2d(ctx, sum, (size_t)(w + 1) * 4, ws.sum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
     if (rc) return rc;
-    if (sqsum) {                                       // device layout: low-word plane, then high-word plane
+    if (sqsum) {                                       // device layout: u32 low-word plane, then u8 high-byte plane
         const size_t n = (size_t)(w + 1) * (h + 1);
-        std::vector<unsigned> lo(n), hi(n);
+        std::vector<unsigned> lo(n); std::vector<uint8_t> hi(n);
         rc = unstage_2d(ctx, lo.data(), (size_t)(w + 1) * 4, ws.sqsum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
         if (rc) return rc;
-        rc = unstage_2d(ctx, hi.data(), (size_t)(w + 1) * 4, ws.sqsum.as<unsigned>() + g.sum_slot, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+        rc = unstage_2d(ctx, hi.data(), (size_t)(w + 1), ws.sqsum.as<unsigned>() + g.sum_slot, (size_t)g.spitch, (size_t)(w + 1), h + 1, NVCA_MEM_HOST);
         if (rc) return rc;
         for (size_t i = 0; i < n; i++) sqsum[i] = (double)(((unsigned long long)hi[i] << 32) | lo[i]);
     }

@@ -33,6 +33,19 @@ typedef const __attribute__((address_space(4))) TStumpRec CTStumpRec;
 
 __device__ __forceinline__ int ldsum(const int *__restrict__ sum, unsigned idx) { return sum[idx]; }
 
+// Squared-pixel sum of the variance window from the squared integral, as the f64 OpenCV computes (every operand and every
+// partial result is an integer below 2^53, so the f64 chain is exact and equals the integer result).  The plane pair is a
+// u32 low-word plane and a u8 high-byte plane (the values stay below 2^40 whenever the i32 sum plane is valid); when the
+// window's sum is known to be below 2^32 the low words alone give it, modulo 2^32.
+__device__ __forceinline__ double window_sqsum(const unsigned *__restrict__ sql, const uint8_t *__restrict__ sqh, bool lo_only,
+                                               unsigned e0, unsigned e1, unsigned e2, unsigned e3)
+{
+    if (lo_only) return (double)(unsigned)(sql[e0] - sql[e1] - sql[e2] + sql[e3]);
+    const unsigned long long q0 = ((unsigned long long)sqh[e0] << 32) | sql[e0], q1 = ((unsigned long long)sqh[e1] << 32) | sql[e1];
+    const unsigned long long q2 = ((unsigned long long)sqh[e2] << 32) | sql[e2], q3 = ((unsigned long long)sqh[e3] << 32) | sql[e3];
+    return (double)q0 - (double)q1 - (double)q2 + (double)q3;
+}
+
 // feature value of one stump on one window (v) against its threshold: returns the vote.  Records hold corner columns /
 // rows relative to the window (geometry-independent tables); the plane offset is row * pitch + column.
 template <bool PAIR, class Rec, bool UNI = false>
@@ -107,9 +120,9 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
     const int ix = k * 64 + lane;
     const bool active = ix < sc.endX;
     const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-    // squared integral: two u32 planes (low / high word) per slot, see k_integral
+    // squared integral: a u32 low-word plane and a u8 high-byte plane per slot, see k_integral
     const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
-    const unsigned *__restrict__ sqh = sql + a.sum_slot;
+    const uint8_t *__restrict__ sqh = (const uint8_t *)((const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + a.sum_slot) + sc.plane_off;
     bool pass0 = false;
     double vnf = 1.;
     if (active) {
@@ -117,9 +130,7 @@ __global__ __launch_bounds__(256) void k_stage0(CascadeArgs a)
         const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
         const int ws = sum[e0] - sum[e1] - sum[e2] + sum[e3];
         const double mean = (double)ws * sc.inv_area;
-        const unsigned long long q0 = ((unsigned long long)sqh[e0] << 32) | sql[e0], q1 = ((unsigned long long)sqh[e1] << 32) | sql[e1];
-        const unsigned long long q2 = ((unsigned long long)sqh[e2] << 32) | sql[e2], q3 = ((unsigned long long)sqh[e3] << 32) | sql[e3];
-        vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
+        vnf = window_sqsum(sql, sqh, sc.sq32 != 0, e0, e1, e2, e3);
         vnf = vnf * sc.inv_area - mean * mean;
         vnf = vnf >= 0. ? sqrt(vnf) : 1.;
         pass0 = run_stage(sum, off, sc.pitch, vnf, (CTStumpRec *)sc.trecs, a.stages[0], a.pair_policy);
@@ -695,7 +706,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     const BandRec b = a.bands[a.band_order[bi]];
     const ScaleRec &sc = a.scales[b.scale];
     const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
-    const unsigned *__restrict__ sqh = sql + a.sum_slot;
+    const uint8_t *__restrict__ sqh = (const uint8_t *)((const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + a.sum_slot) + sc.plane_off;
+    const bool sq_lo_only = sc.sq32 != 0;
     const int ex0 = sc.eq[0] % sc.pitch, ey0 = sc.eq[0] / sc.pitch, ex1 = sc.eq[3] % sc.pitch, ey1 = sc.eq[3] / sc.pitch;
     const StageRec st0 = a.stages[0];
     const bool pair0 = a.pair_policy && (st0.flags & 1);
@@ -723,9 +735,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
                 const double mean = (double)ws * sc.inv_area;
                 const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
                 const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
-                const unsigned long long q0 = ((unsigned long long)sqh[e0] << 32) | sql[e0], q1 = ((unsigned long long)sqh[e1] << 32) | sql[e1];
-                const unsigned long long q2 = ((unsigned long long)sqh[e2] << 32) | sql[e2], q3 = ((unsigned long long)sqh[e3] << 32) | sql[e3];
-                double vnf = (double)q0 - (double)q1 - (double)q2 + (double)q3;
+                double vnf = window_sqsum(sql, sqh, sq_lo_only, e0, e1, e2, e3);
                 vnf = vnf * sc.inv_area - mean * mean;
                 vnf = vnf >= 0. ? sqrt(vnf) : 1.;
                 L.vnf_s[w] = vnf;

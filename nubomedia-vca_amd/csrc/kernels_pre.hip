@@ -4,7 +4,7 @@
 // detectMultiScale).  All integer; HBM-bound streaming work.
 //
 // Data layout (per batch slot): gray u8 [h][gpitch]; sum i32 [(h+1)][spitch];
-// sqsum u64 [(h+1)][spitch] (exact integers -> bit-identical to OpenCV's f64);
+// sqsum [(h+1)][spitch] as a u32 low-word plane + a u8 high-byte plane (exact integers below 2^40 -> bit-identical to OpenCV's f64);
 // band partials u32 [nbands][bpitch] for column sums of pixel and pixel^2.
 #include "nvca_internal.h"
 
@@ -478,7 +478,8 @@ __global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restr
     const int bpitch = (int)(g.band_slot / g.nbands);
     const uint8_t *gbase = gray + (size_t)slot * g.gray_slot;
     int *sbase = sum + (size_t)slot * g.sum_slot;
-    unsigned *lbase = sq32 + (size_t)slot * 2 * g.sum_slot, *hbase = lbase + g.sum_slot;
+    unsigned *lbase = sq32 + (size_t)slot * 2 * g.sum_slot;
+    uint8_t *hbase = (uint8_t *)(lbase + g.sum_slot);        // high bytes (bits 32..39), one per element
     const unsigned *bs = bandsum + (size_t)slot * g.band_slot + (size_t)band * bpitch;
     const unsigned *bq = bandsq + (size_t)slot * g.band_slot + (size_t)band * bpitch;
     const int nchunks = (g.w + 1 + 2047) / 2048;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restr
         if (band == 0 && in_pitch) {                        // integral row 0 (all zero)
             *(int4 *)(sbase + X0) = make_int4(0, 0, 0, 0);
             *(uint4 *)(lbase + X0) = make_uint4(0, 0, 0, 0);
-            *(uint4 *)(hbase + X0) = make_uint4(0, 0, 0, 0);
+            *(unsigned *)(hbase + X0) = 0u;
         }
         // ---- rows of the band (the next row's pixels are in flight while this one is scanned)
         unsigned px_next = 0;
@@ -551,8 +552,8 @@ __global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restr
                 const size_t o = (size_t)(y + 1) * g.spitch + X0;
                 *(int4 *)(sbase + o) = make_int4((int)acc_s[0], (int)acc_s[1], (int)acc_s[2], (int)acc_s[3]);
                 *(uint4 *)(lbase + o) = make_uint4((unsigned)acc_q[0], (unsigned)acc_q[1], (unsigned)acc_q[2], (unsigned)acc_q[3]);
-                *(uint4 *)(hbase + o) = make_uint4((unsigned)(acc_q[0] >> 32), (unsigned)(acc_q[1] >> 32), (unsigned)(acc_q[2] >> 32),
-                                                   (unsigned)(acc_q[3] >> 32));
+                *(unsigned *)(hbase + o) = (unsigned)(acc_q[0] >> 32) | ((unsigned)(acc_q[1] >> 32) << 8) | ((unsigned)(acc_q[2] >> 32) << 16) |
+                                           ((unsigned)(acc_q[3] >> 32) << 24);
             }
         }
         __syncthreads();
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = L.szw, h = L.szh;
     const uint8_t *g = aux + (size_t)img * aux_slot + L.gray_off;
     int *s = sum + (size_t)img * sum_slot + L.plane_off;
-    unsigned *lo = sq32 + (size_t)img * 2 * sum_slot + L.plane_off, *hi = lo + sum_slot;
+    unsigned *lo = sq32 + (size_t)img * 2 * sum_slot + L.plane_off;
+    uint8_t *hi = (uint8_t *)(sq32 + (size_t)img * 2 * sum_slot + sum_slot) + L.plane_off;   // high-byte plane
     if (tid <= w) { s[tid] = 0; lo[tid] = 0; hi[tid] = 0; }            // integral row 0
     // running sums of this thread's column; the squared one stays below 2^32 (rows x 255^2), so its row prefix can be
     // scanned as two 32-bit halves (low 16 bits / the rest) on the VALU and recombined in 64 bits
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
         par ^= 1;
         const unsigned long long iq = ((unsigned long long)ih << 16) + il;
         const size_t row = (size_t)(y + 1) * P;
-        if (tid < w) { s[row + tid + 1] = (int)is; lo[row + tid + 1] = (unsigned)iq; hi[row + tid + 1] = (unsigned)(iq >> 32); }
+        if (tid < w) { s[row + tid + 1] = (int)is; lo[row + tid + 1] = (unsigned)iq; hi[row + tid + 1] = (uint8_t)(iq >> 32); }
         if (tid == 0) { s[row] = 0; lo[row] = 0; hi[row] = 0; }
     }
 }

@@ -55,7 +55,8 @@ struct ScaleRec {           // one evaluated scale
     int    endX, endY;      // scan grid: ix in [0,endX), iy in [0,endY)
     int    eq[4];           // equRect corner offsets
     int    xpos_off, ypos_off;           // into the position tables (indexed by ix / iy)
-    int    pad_s;
+    int    sq32;            // 1: the squared-pixel sum of the variance window is below 2^32 at this scale (ew * eh * 255^2):
+                            //    the low-word plane alone gives it exactly (modulo-2^32 corner arithmetic)
     int    task_off;        // first stage-0 wave task (64 windows) of this scale
     int    wpr;             // wave tasks (64-bit reject words) per scan row
     int    adaptive;        // 1: OpenCV's adaptive x step applies (scale-cascade scan); 0: every grid point is visited

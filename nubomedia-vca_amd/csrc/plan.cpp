@@ -213,6 +213,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
         if (!tabp) { err = "allocation failed (stump tables)"; return NVCA_ERR_NOMEM; }
         tabp->refs++; tabs.push_back(tabp);
         sr.winw = tabp->winw; sr.winh = tabp->winh; sr.inv_area = tabp->inv_area; sr.factor = tabp->factor;
+        sr.sq32 = (unsigned long long)tabp->ew * (unsigned long long)tabp->eh * 65025ull < (1ull << 32) ? 1 : 0;
         sr.eq[0] = tabp->ey * pitch + tabp->ex;               sr.eq[1] = tabp->ey * pitch + tabp->ex + tabp->ew;
         sr.eq[2] = (tabp->ey + tabp->eh) * pitch + tabp->ex;  sr.eq[3] = (tabp->ey + tabp->eh) * pitch + tabp->ex + tabp->ew;
         sr.trecs = tabp->dev.as<TStumpRec>();
