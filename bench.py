@@ -212,7 +212,11 @@ def main():
     for _ in range(args.warmup):
         res = step()
     n_boxes = float(np.mean([len(b) for b, _ in res])) if args.warmup else 0.0
-    ctx.enable_kernel_timing(os.environ.get("NVCA_BENCH_NOTIMING") is None)
+    # per-kernel HIP events ride on every 4th step of the timed region (they keep consecutive launches from overlapping:
+    # ~6 us per launch); NVCA_BENCH_TIMING_STRIDE=1 puts them on every step, NVCA_BENCH_NOTIMING=1 on none
+    stride = 0 if os.environ.get("NVCA_BENCH_NOTIMING") is not None else max(1, int(os.environ.get("NVCA_BENCH_TIMING_STRIDE", "4")))
+    ctx.enable_kernel_timing(stride)
+    sampled_steps = (args.steps + stride - 1) // stride if stride else 0     # steps whose launches carried events
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -244,7 +248,7 @@ def main():
             launches = max([ktimes.get(m, (0.0, 0))[1] for m in members] + [0])
             if launches:
                 per_launch_ms = ms / launches
-                bytes_per_launch = ab.get(gname, 0) * F * args.steps / launches     # frames per launch set (host frames go through in chunks)
+                bytes_per_launch = ab.get(gname, 0) * F * sampled_steps / launches  # frames per launch set (host frames go through in chunks)
                 kern[gname] = {"ms_per_launch": per_launch_ms, "launches": launches,
                                "alg_bytes_per_launch": bytes_per_launch,
                                "achieved_GBs": bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0}
@@ -284,6 +288,7 @@ def main():
                         "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
                         "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
                         "kernels": kern, "lds": lds,
+                        "timed_steps": sampled_steps,      # steps of the timed region whose launches carried HIP events (every `stride`-th)
                         "detail_ms_per_launch": {k: v[0] / v[1] for k, v in ktimes.items() if v[1]}}
         out = {
             "metric": "1080p frames/sec/node (NuboFaceDetector); achieved HBM GB/s vs peak",

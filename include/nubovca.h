@@ -85,7 +85,11 @@ int  nvca_host_register(nvca_ctx *ctx, void *ptr, size_t bytes);
 int  nvca_host_unregister(nvca_ctx *ctx, void *ptr);
 
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,
- * every kernel launch is bracketed by events; nvca_ctx_kernel_timing drains them. */
+ * kernel launches are bracketed by events; nvca_ctx_kernel_timing drains them.
+ * on == 0: off; on == 1: every launch; on == N > 1: the launches of every N-th
+ * batch of the face-detector / tracker entry points only (the first one included) --
+ * event-carrying launches do not overlap their neighbours, which costs a few
+ * microseconds per launch. */
 #define NVCA_K_GRAY      0  /* resize + BGR2GRAY + histogram            */
 #define NVCA_K_LUT       1  /* equalizeHist LUT                         */
 #define NVCA_K_COLSUM    2  /* integral: band column sums               */

@@ -45,7 +45,7 @@ void PinnedBuf::release() { if (p) { (void)hipHostFree(p); p = nullptr; bytes = 
 static thread_local TimedLaunch *g_scope = nullptr;
 TimedLaunch::TimedLaunch(nvca_ctx *c, int kind) : ctx(c), k(kind)
 {
-    if (!ctx->timer.on) return;
+    if (!ctx->timer.on || !ctx->timer.sample) return;
     active = true; prev = g_scope; g_scope = this;
 }
 TimedLaunch::~TimedLaunch()
@@ -685,6 +685,7 @@ int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
     (void)hipStreamSynchronize(ctx->stream);
     drain_timer(ctx);
     ctx->timer.on = on != 0;
+    ctx->timer.stride = on > 1 ? on : 1; ctx->timer.seq[0] = ctx->timer.seq[1] = 0; ctx->timer.sample = true;
     for (int k = 0; k < NVCA_K_COUNT; k++) { ctx->timer.total_ms[k] = 0; ctx->timer.launches[k] = 0; }
     return NVCA_OK;
 }
@@ -1453,6 +1454,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
 {
     if (n < 0 || (n > 0 && (!streams || !frames))) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
+    ctx->timer.tick(0);
     Workspace &ws = *ctx->ws;
     struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);   // every other entry point works on set 0
     tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();

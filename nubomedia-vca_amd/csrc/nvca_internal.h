@@ -159,6 +159,10 @@ struct Workspace;    // api.cpp
 
 struct KernelTimer {
     bool on = false;
+    int stride = 1;                 // events ride on every stride-th batch of an entry point (they serialise consecutive launches)
+    uint64_t seq[2] = {0, 0};       // batches seen: [0] face detector, [1] tracker
+    bool sample = true;             // the batch being queued carries events
+    void tick(int which) { sample = stride <= 1 || (seq[which]++ % (uint64_t)stride) == 0; }
     struct Ev { hipEvent_t a, b; int k; bool first; };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;

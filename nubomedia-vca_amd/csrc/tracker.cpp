@@ -64,6 +64,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!trackers || !frames || !ts || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
+    ctx->timer.tick(1);
     for (int i = 0; i < n; i++) {
         n_out[i] = 0;
         const nvca_frame &f = frames[i];
