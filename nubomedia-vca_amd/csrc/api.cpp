@@ -328,6 +328,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
 {
     Workspace &ws = *ctx->ws;
     ResultBufs &rb = ws.res[ws.cur_res];
+    static const bool grp_zero_copy = !(getenv("NVCA_GROUP_ZEROCOPY") && atoi(getenv("NVCA_GROUP_ZEROCOPY")) == 0);
     const int batch = job.n, total = std::max(job.total, job.r0 + job.n);
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;                 // u64 words per result slot
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
@@ -420,10 +421,14 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
         }
         { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
-        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, job.d_grp, kGroupOutCap, batch); }
+        // the box tables are small (a few KB per frame): the grouping kernel stores them straight into the page-locked host
+        // buffer (plain stores, visible to the host once the stream has drained) -- no copy operation behind the last kernel
+        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
-    if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
+    if (dev_group && grp_zero_copy) {
+        // nothing to copy: k_group wrote the host buffer
+    } else if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, (rec * batch + 2) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     } else {              // one D2H covers the count and (almost always) every candidate
         job.first = std::min<size_t>(cap, 2048);

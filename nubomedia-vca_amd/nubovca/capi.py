@@ -318,6 +318,11 @@ class Context:
         return res
 
 
+    def prepare_face_batch(self, streams, frames, cap=64):
+        """argument and result arrays of a batch that is handed in again and again (a serving loop over the same buffers):
+        the ctypes marshalling is done once, process() is then just the C call"""
+        return PreparedFaceBatch(self, streams, frames, cap)
+
     def face_batch_submit(self, streams, frames):
         """first half of face_batch_process: queues the batch and returns a ticket (at most two in flight)"""
         n = len(frames)
@@ -336,6 +341,29 @@ class Context:
         boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)
         idv = np.frombuffer(ids, dtype=np.int32).reshape(n, cap)
         return [(boxes[i, :min(cnt[i], cap)].copy(), idv[i, :min(cnt[i], cap)].copy()) for i in range(n)]
+
+
+class PreparedFaceBatch:
+    def __init__(self, ctx, streams, frames, cap):
+        self.ctx, self.n, self.cap = ctx, len(frames), cap
+        self.keep = (list(streams), list(frames))
+        self.sh = (C.c_void_p * self.n)(*[s.h for s in streams])
+        self.fr = (Frame * self.n)(*frames)
+        self.out = (Rect * (self.n * cap))()
+        self.ids = (C.c_int * (self.n * cap))()
+        self.cnt = (C.c_int * self.n)()
+        self.boxes = np.frombuffer(self.out, dtype=np.int32).reshape(self.n, cap, 4)
+        self.idv = np.frombuffer(self.ids, dtype=np.int32).reshape(self.n, cap)
+        self.counts = np.frombuffer(self.cnt, dtype=np.int32)
+
+    def process(self):
+        """nvca_face_batch_process on the prepared arrays; results stay in self.boxes / self.idv / self.counts"""
+        self.ctx.check(self.ctx.L.nvca_face_batch_process(self.ctx.h, self.n, self.sh, self.fr, self.out, self.ids, self.cap, self.cnt))
+        return self
+
+    def results(self):
+        """[(boxes[k,4], ids[k])] per frame, as face_batch_process returns them"""
+        return [(self.boxes[i, :min(self.counts[i], self.cap)].copy(), self.idv[i, :min(self.counts[i], self.cap)].copy()) for i in range(self.n)]
 
 
 class Cascade:
