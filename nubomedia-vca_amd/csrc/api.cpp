@@ -388,11 +388,10 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { static const int bm = getenv("NVCA_BAND_MAP") ? atoi(getenv("NVCA_BAND_MAP")) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
-        // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the GPU several times
-        // over; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
+        // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
         const char *band_e = getenv("NVCA_BAND");
         const int band_env = band_e ? atoi(band_e) : -1;
-        const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 1024);
+        const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 640);     // measured crossover at 1080p: 8 frames (544 bands) equal, 16 frames +20 %
         if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
         const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
         const bool lists = !use_band && dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
