@@ -198,12 +198,11 @@ def main():
             inflight[0] = nxt
         else:
             res = prepared[tick[0] % TICKS].process()
-            if world > 1:
-                res = res.results()
         if trackers is not None:
             capi.tracker_batch_process(ctx, trackers, bgra_frames[tick[0] % TICKS], [33.3 * tick[0]] * F, cap=256)
         if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL;
-            gather.submit(sharding.pack_boxes(res, MAX_BOXES))      # asynchronous: it overlaps the next tick's kernels
+            tab = sharding.pack_box_arrays(res.boxes, res.counts) if hasattr(res, "counts") else sharding.pack_boxes(res, MAX_BOXES)
+            gather.submit(tab)                                      # asynchronous: it overlaps the next tick's kernels
         return res
 
     def fence():

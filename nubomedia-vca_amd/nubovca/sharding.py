@@ -22,6 +22,18 @@ def pack_boxes(results, max_boxes):
     return tab
 
 
+def pack_box_arrays(boxes, counts, out=None):
+    """the same table from the batched call's raw result arrays (boxes int32 [n, cap, 4], counts int32 [n]) without
+    per-stream python work; entries past a stream's count are zeroed like pack_boxes leaves them"""
+    n, cap = boxes.shape[0], boxes.shape[1]
+    tab = out if out is not None else np.empty((n, 1 + 4 * cap), np.int32)
+    k = np.minimum(counts, cap)
+    tab[:, 0] = k
+    live = (np.arange(cap, dtype=np.int32)[None, :] < k[:, None])
+    np.multiply(boxes, live[:, :, None], out=tab[:, 1:].reshape(n, cap, 4))
+    return tab
+
+
 def unpack_boxes(tab):
     return [np.asarray(row[1:1 + 4 * int(row[0])], np.int32).reshape(-1, 4) for row in np.asarray(tab)]
 
@@ -46,6 +58,7 @@ class TableGather:
 
     def __init__(self, device=None):
         self.device, self.pending, self.done = device, None, None
+        self.outs, self.flip = [None, None], 0
 
     def submit(self, local_tab):
         self._complete()
@@ -56,7 +69,11 @@ class TableGather:
         if world == 1:
             self.done = (t, (1,) + tuple(t.shape))
             return
-        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        shape = (world * t.shape[0],) + tuple(t.shape[1:])
+        self.flip ^= 1                     # two output tensors alternate: the previous one may still be read by last()
+        out = self.outs[self.flip]
+        if out is None or tuple(out.shape) != shape or out.dtype != t.dtype or out.device != t.device:
+            out = self.outs[self.flip] = torch.empty(shape, dtype=t.dtype, device=t.device)
         work = dist.all_gather_into_tensor(out, t, async_op=True)
         self.pending = (work, out, t, (world,) + tuple(t.shape))
 

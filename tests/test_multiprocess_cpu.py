@@ -90,3 +90,15 @@ def test_pack_unpack_roundtrip():
     for (b, _), r in zip(res, back):
         assert np.array_equal(r, b[:16])
     assert sharding.streams_of_rank(10, 4, 1) == [1, 5, 9]
+
+
+def test_pack_box_arrays_equals_pack_boxes():
+    """the vectorised packing of the batched call's raw result arrays builds the same table as the per-stream one"""
+    import numpy as np
+    from nubovca import sharding
+    rng = np.random.default_rng(3)
+    cap, n = 8, 6
+    boxes = rng.integers(0, 2000, (n, cap, 4)).astype(np.int32)
+    counts = np.array([0, 3, 8, 12, 1, 7], np.int32)                 # 12 > cap: clipped like the C call reports it
+    res = [(boxes[i, :min(counts[i], cap)].copy(), None) for i in range(n)]
+    assert np.array_equal(sharding.pack_boxes(res, cap), sharding.pack_box_arrays(boxes, counts))
