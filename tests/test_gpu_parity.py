@@ -649,3 +649,28 @@ def test_detect_4k(ctx, casc, orc_cascade):
     raw = ctx.detect_raw(casc, g, 1.2, 0, (192, 108))
     eraw = orc.detect_raw(orc_cascade, g, 1.2, 0, (192, 108))
     assert len(eraw) > 0 and np.array_equal(raw, eraw)
+
+
+def test_kernel_timing_every_batch_and_sampled(ctx, casc, orc_cascade):
+    """nvca_ctx_enable_kernel_timing: 1 brackets every launch, N > 1 the launches of every N-th face batch (the first one
+    included); results are the same either way"""
+    import orc
+    from nubovca import capi, synth
+    W, H = 640, 480
+    frames = [synth.make_bgr(W, H, 5100 + i, "natural", [(60 + 9 * i, H // 6, H // 2)]) for i in range(6)]
+    exp = []
+    ofs = orc.FaceStream(orc_cascade)
+    for f in frames:
+        exp.append(ofs.process(f)[0])
+    for mode, want in ((1, 6), (3, 2)):
+        fs = capi.FaceStream(ctx, casc)
+        ctx.enable_kernel_timing(mode)
+        for f, e in zip(frames, exp):
+            b, _ = fs.process(f)
+            assert np.array_equal(b, e)
+        kt = ctx.kernel_timing()
+        ctx.enable_kernel_timing(0)
+        fs.close()
+        assert kt["gray_resize_hist"][1] == want, (mode, kt)
+        assert kt["gray_resize_hist"][0] > 0.0
+    assert all(v[1] == 0 for v in ctx.kernel_timing().values())      # off: nothing accumulates
