@@ -115,49 +115,6 @@ def test_face_pipeline_events_match_oracle(shim, synth_xml, orc_cascade):
     assert any(l.startswith("signal x:") for l in r.stdout.splitlines())
 
 
-def _server_parse(payload):
-    """What Kurento's server object makes of a signal string (NuboFaceDetectorImpl.cpp:55-129, same in the other
-    modules): split on ';', then ',', then ':' into one flat token list; walk it in key/value pairs; a record is
-    emitted when its "height" arrives (fields that were not seen stay 0)."""
-    flat = []
-    for face in payload.split(";"):
-        for field in face.split(","):
-            flat.extend(field.split(":"))
-    out, cur = [], dict(x=0, y=0, width=0, height=0)
-    for i in range(0, len(flat), 2):
-        key = flat[i]
-        if key in cur and i + 1 < len(flat):
-            cur[key] = int(flat[i + 1])
-            if key == "height":
-                out.append((cur["x"], cur["y"], cur["width"], cur["height"]))
-                cur = dict(x=0, y=0, width=0, height=0)
-    return out
-
-
-def test_server_double_parser():
-    assert _server_parse("x:1,y:2,width:3,height:4;x:5,y:6,width:7,height:8;") == [(1, 2, 3, 4), (5, 6, 7, 8)]
-    assert _server_parse("") == [] and _server_parse("x:9,y:9;") == []
-
-
-@pytest.mark.gpu
-def test_face_signal_as_the_server_reads_it(shim, synth_xml, orc_cascade):
-    """the string signal, parsed the way the Kurento module's server object parses it, carries the oracle's boxes"""
-    import orc
-    from nubovca import synth
-    W, H = 640, 480
-    frames = [synth.make_bgr(W, H, 700 + i, "natural", [(60 + 8 * i, H // 6, H // 2), (380, 40 + 4 * i, H // 3)]) for i in range(6)]
-    r = _run_harness("nubofacedetector", "BGR", W, H, frames, props=["activate-events=1", "events-ms=0"], cascade_xml=synth_xml)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = [_server_parse(l[len("signal "):]) for l in r.stdout.splitlines() if l.startswith("signal ")]
-    ofs = orc.FaceStream(orc_cascade)
-    exp = []
-    for fr in frames:
-        boxes, _ = ofs.process(fr)
-        if len(boxes):                                   # the element signals only when there is a box (FACE :228-241)
-            exp.append([tuple(int(v) for v in b) for b in boxes])
-    assert len(exp) > 0 and got == exp
-
-
 @pytest.mark.gpu
 def test_view_faces_draws_the_boxes_in_place(shim, synth_xml, orc_cascade):
     """view-faces=1: a 3-pixel outline from (x, y) to (x + w - scale, y + h - scale) in CV_RGB(0,128,255)
@@ -191,6 +148,43 @@ def test_view_faces_draws_the_boxes_in_place(shim, synth_xml, orc_cascade):
         assert not np.any(changed & ~expect)                       # nothing outside the outlines was touched
         assert np.all(out[expect] == np.array([255, 128, 0], np.uint8))
     assert drawn > 0
+
+
+@pytest.mark.gpu
+def test_view_mouths_and_tracker_visual_mode_draw(shim, synth_xml, orc_cascade):
+    """view-mouths=1 outlines every mouth in its palette colour (MOUTH :814-821,896-903); set_visual_mode=1 outlines the
+    tracker's boxes in Scalar(0,0,255) (TRK :389); pixels away from any outline stay untouched"""
+    import orc
+    frames = _scene(4)
+    files = _part_files()
+    r = _run_harness("nubomouthdetector", "BGR", 640, 480, frames, props=["view-mouths=1"], cascade_xml=synth_xml,
+                     extra_cascades=files, dump_frames=True)
+    assert r.returncode == 0 and r.frames_out is not None and len(r.frames_out) == len(frames), r.stderr[-1500:]
+    o = orc.PartStream(2, orc_cascade, orc.parse_cascade_xml(files["haarcascade_mcs_mouth.xml"]))
+    palette = [(0, 255, 255), (0, 128, 255), (0, 0, 255), (255, 0, 255), (255, 128, 0), (255, 0, 0), (255, 255, 0), (0, 255, 0)]   # BGR of CV_RGB(...)
+    drawn = 0
+    for fr, out in zip(frames, r.frames_out):
+        a, _ = o.process(fr)
+        changed = np.any(out != fr, axis=2)
+        near = np.zeros(changed.shape, bool)
+        for j, (x, y, w, h) in enumerate(a):
+            x1, y1 = x + w - 1, y + h - 1
+            near[max(y - 2, 0):y1 + 3, max(x - 2, 0):x1 + 3] = True
+            assert tuple(out[y, (x + x1) // 2]) == palette[j % 8]          # middle of the top edge
+            assert tuple(out[(y + y1) // 2, x]) == palette[j % 8]          # middle of the left edge
+            drawn += 1
+        assert not np.any(changed & ~near)
+    assert drawn > 0
+    W, H = 320, 240
+    seq = []
+    for i in range(6):
+        f = np.full((H, W, 4), 40, np.uint8)
+        f[60:120, 30 + 10 * i:90 + 10 * i, :3] = 220
+        seq.append(f)
+    t = _run_harness("nubotracker", "BGRA", W, H, seq, props=["set_visual_mode=1"], dump_frames=True)
+    assert t.returncode == 0 and t.frames_out is not None and len(t.frames_out) == len(seq), t.stderr[-1500:]
+    red = np.all(t.frames_out[-1] == np.array([0, 0, 255, 0], np.uint8), axis=2)
+    assert red.any() and np.array_equal(t.frames_out[0], seq[0])           # first frame: no motion history yet
 
 
 @pytest.mark.gpu
