@@ -47,7 +47,8 @@ def cpu_baseline(xml, frames_np, params, budget_s=12.0, max_frames=48):
     cores on a bounded sample of the same workload: one stream per thread (the reference runs one element per streaming
     thread; streams are the independent units), all available cores; the single-thread rate is reported alongside."""
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    if os.path.join(ROOT, "oracle") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     oc = orc.parse_cascade_xml(xml)
     kw = dict(width_to_process=params["width_to_process"], scale_factor_pct=params["multi_scale_factor"])
@@ -82,6 +83,100 @@ def cpu_baseline(xml, frames_np, params, budget_s=12.0, max_frames=48):
                       "available offline)" % (nall, cores, dtall, n1, dt1)}
 
 
+def oracle_expected(xml, frames_np, params, rows, multi_stream):
+    """What the oracle says the LAST step's boxes must be.  The harness feeds the same frames again and again: every
+    distinct frame's detections are computed once (threads: the call is stateless and releases the GIL), then the temporal
+    logic (gating, Faces::track_faces, hysteresis) is replayed over the whole sequence of steps, frame by frame, exactly
+    as the timed loop fed them.  rows: the frame-set index of every batch handed in so far, in order."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    oc = orc.parse_cascade_xml(xml)
+    kw = dict(width_to_process=params["width_to_process"], scale_factor_pct=params["multi_scale_factor"])
+    F = len(frames_np[0])
+    probe = orc.FaceStream(oc, **kw)
+    keys = [(r, s) for r in sorted(set(rows)) for s in range(F)]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    with ThreadPoolExecutor(max(1, min(cores, 32))) as ex:
+        dets = list(ex.map(lambda k: probe.frame_detect(frames_np[k[0]][k[1]]), keys))
+    memo = dict(zip(keys, dets))
+    streams = [orc.FaceStream(oc, **kw) for _ in range(F if multi_stream else 1)]
+    last = None
+    for r in rows:
+        last = [streams[s if multi_stream else 0].process_memo((r, s), frames_np[r][s], memo) for s in range(F)]
+    return last
+
+
+def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
+    """Figures a pipeline sees that the headline (device-resident, F frames per call) does not show; each a few untimed-
+    warm-up + timed calls, never `value`: one frame per call (latency mode), host frames incl. the PCIe copy (pageable and
+    page-locked), and the content sweep of SURVEY.md 8d (uniform noise; gradient + K pasted templates)."""
+    from nubovca import capi, synth
+
+    def rate(frames, reps, host=False, pinned=False, per_call=None):
+        per_call = per_call or len(frames)
+        st = capi.FaceStream(ctx, casc, **props)
+        if host:
+            fr = [capi.make_frame(f) for f in frames]
+            if pinned:
+                for f in frames:
+                    ctx.host_register(f)
+        else:
+            keep = [torch.from_numpy(f).to(dev) for f in frames]
+            torch.cuda.synchronize()
+            fr = [capi.make_frame(t.data_ptr(), W, H, W * 3, capi.MEM_DEVICE) for t in keep]
+        batches = [ctx.prepare_face_batch([st] * per_call, fr[i:i + per_call], cap=MAX_BOXES) for i in range(0, len(fr), per_call)]
+        try:
+            for b in batches[:max(1, len(batches) // 4)]:
+                b.process()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for b in batches:
+                    b.process()
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            if host and pinned:
+                for f in frames:
+                    ctx.host_unregister(f)
+            st.close()
+        return reps * len(frames) / dt, dt / (reps * len(batches)) * 1e3
+
+    tab = {}
+    fps1, ms1 = rate(frames_np[:8], 4, per_call=1)
+    tab["single_frame"] = {"ms_per_frame": ms1, "frames_per_s": fps1, "note": "one frame per nvca_face_batch_process call (no batching latency)"}
+    fps_p, _ = rate(frames_np, 3, host=True)
+    fps_l, _ = rate(frames_np, 3, host=True, pinned=True)
+    tab["host_frames"] = {"pageable_frames_per_s": fps_p, "pinned_frames_per_s": fps_l, "frames_per_call": F,
+                          "note": "frames start in host memory: the rate includes the PCIe copy (6.2 MB per 1080p frame)"}
+    sx, sy = W / 1920.0, H / 1080.0
+    spots = [(60 + 230 * (k % 8), 40 + 500 * (k // 8), 200 if k < 8 else 160) for k in range(16)]
+    content = {}
+    for name, kind, K in (("noise", "noise", 0), ("gradient+0", "gradient", 0), ("gradient+1", "gradient", 1),
+                          ("gradient+4", "gradient", 4), ("gradient+16", "gradient", 16)):
+        distinct = [synth.make_bgr(W, H, 777 + i, kind, [(int((x + 8 * i) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in spots[:K]])
+                    for i in range(8)]
+        fr = [distinct[i % 8] for i in range(F)]
+        fps, ms = rate(fr, 3)
+        content[name] = {"frames_per_s": fps, "ms_per_step": ms}
+    tab["content"] = content
+    tab["content_note"] = "device-resident, %d frames per call (8 distinct frames cycled), same cascade and parameters as the headline" % F
+    return tab
+
+
+def boxes_equal(got, exp):
+    if len(got) != len(exp):
+        return False
+    for (gb, gi), (eb, ei) in zip(got, exp):
+        if not (np.array_equal(np.asarray(gb).reshape(-1, 4), eb) and np.array_equal(np.asarray(gi).reshape(-1), ei)):
+            return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +189,8 @@ def main():
     ap.add_argument("--scale-factor-pct", type=int, default=10)
     ap.add_argument("--content", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--faces", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline, boxes_match, the OpenCV probe)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary table (single-frame latency, host-frame rates, content sweep)")
     ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
     ap.add_argument("--pipeline", action="store_true", help="nvca_face_batch_submit / _collect with two batches in flight instead of one synchronous "
                     "nvca_face_batch_process per step (faster without per-kernel timing, NVCA_BENCH_NOTIMING=1; the per-kernel events cost more than it gains)")
@@ -186,12 +282,14 @@ def main():
     # serving loop: two batches in flight -- the next batch is queued before the previous one is unpacked, so the host
     # work between batches overlaps the GPU.  K steps = K submits + K collects; one batch stays in flight across steps.
     pipelined = args.pipeline
+    rows = [0] if pipelined else []          # frame-set index of every batch handed in, in order (the oracle replays them)
     inflight = [ctx.face_batch_submit(streams, frames_t[0])] if pipelined else [None]
     # the synchronous loop hands the same frame buffers in again and again: marshal the ctypes arguments once per buffer set
     prepared = None if pipelined else [ctx.prepare_face_batch(streams, fr, cap=MAX_BOXES) for fr in frames_t]
 
     def step():
         tick[0] += 1
+        rows.append(tick[0] % TICKS)
         if pipelined:
             nxt = ctx.face_batch_submit(streams, frames_t[tick[0] % TICKS])
             res = ctx.face_batch_collect(inflight[0], cap=MAX_BOXES)
@@ -314,7 +412,28 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
+            # parity at the timed size, through the timed entry point: the boxes and ids of the LAST timed step against the
+            # oracle replaying the same sequence of batches (FACE/kmsfacedetect.cpp:805-826)
+            try:
+                exp = oracle_expected(xml, frames_np, props, rows, multi_stream)
+                out["boxes_match"] = bool(boxes_equal(as_list(res), exp))
+                out["boxes_checked"] = {"frames": len(exp), "boxes": int(sum(len(b) for b, _ in exp)), "batches_replayed": len(rows),
+                                        "against": "oracle (CPU restatement) on the same frames, same sequence of batches"}
+            except Exception as e:          # the check must never cost the line
+                out["boxes_match"] = None
+                out["boxes_checked"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["cpu_baseline"] = cpu_baseline(xml, frames_np[0], props)
+            try:                             # the real library, if this box happens to have it (never installed): SURVEY.md 8d(2)
+                import cv2_probe
+                out["cpu_baseline"]["opencv"] = cv2_probe.probe(xml, frames_np[0][:8], width_to_process=0 if w2p == W else w2p,
+                                                                 scale_factor=1 + args.scale_factor_pct / 100.0, budget_s=10.0)
+            except Exception as e:
+                out["cpu_baseline"]["opencv"] = {"available": False, "note": "probe not run: %s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_secondary and args.workload == "face1080p" and not args.host_frames:
+            try:
+                out["secondary"] = secondary_table(ctx, casc, props, frames_np[0], W, H, F, dev, args)
+            except Exception as e:
+                out["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -112,8 +112,7 @@ const char *nvca_kernel_name(int k);
 /* ---- cascade: replaces cv::CascadeClassifier::load ---------------------
  * FACE/kmsfacedetect.cpp:162-177 (HAAR_CONF_FILE :40), EYE/kmseyedetect.cpp:27-29,
  * NOSE/kmsnosedetect.cpp:31-32, MOUTH/kmsmouthdetect.cpp:37-38, EAR/kmseardetect.cpp:29-31.
- * Old-format ("opencv-haar-classifier") XML only, stump or tree weak classifiers,
- * upright features. */
+ * Old-format ("opencv-haar-classifier") XML only. */
 int  nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out);
 int  nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out);
 void nvca_cascade_free(nvca_cascade *c);

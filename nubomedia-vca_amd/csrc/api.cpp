@@ -25,8 +25,8 @@ int DevBuf::ensure(size_t n)
     if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; bytes = 0; }
     size_t want = n + n / 4;                                  // head-room: batches grow
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) { p = nullptr; e = hipMalloc(&p, n); want = n; }
-    if (e != hipSuccess) { p = nullptr; bytes = 0; return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; e = hipMalloc(&p, n); want = n; }    // the refused head-room attempt must not surface later as a launch error
+    if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; bytes = 0; return (int)e; }
     bytes = want;
     return 0;
 }
@@ -36,7 +36,7 @@ int PinnedBuf::ensure(size_t n)
     if (n <= bytes) return 0;
     if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; bytes = 0; }
     hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
-    if (e != hipSuccess) { p = nullptr; return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return (int)e; }
     bytes = n;
     return 0;
 }
@@ -386,13 +386,18 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.list_from = 0;
         a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
-        { static const int bm = getenv("NVCA_BAND_MAP") ? atoi(getenv("NVCA_BAND_MAP")) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
+        { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
         const char *band_e = getenv("NVCA_BAND");
         const int band_env = band_e ? atoi(band_e) : -1;
         const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 640);     // measured crossover at 1080p: 8 frames (544 bands) equal, 16 frames +20 %
-        if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_cascade_sc(ctx->stream, a, batch, 0); }
+        auto launch = [&](int which) {
+            const int e = launch_cascade_sc(ctx->stream, a, batch, which, ctx->lds_grant);
+            if (e) ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e));
+            return e;
+        };
+        if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); if (launch(0)) return NVCA_ERR_HIP; }
         const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
         const bool lists = !use_band && dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
         if (lists) {
@@ -412,14 +417,14 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.list_cnt.p, 0, sizeof(unsigned) * 64 * (dp.stages.size() + 1), ctx->stream));
             a.list_cnt = ws.list_cnt.as<unsigned>(); a.list_ent = ws.list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
             a.list_cap = (unsigned)cap_l; a.list_from = dp.list_from;
-            TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 4);
+            TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(4)) return NVCA_ERR_HIP;
         } else if (use_band) {
-            TimedLaunch t(ctx, NVCA_K_BAND); launch_cascade_sc(ctx->stream, a, batch, 5);
+            TimedLaunch t(ctx, NVCA_K_BAND); if (launch(5)) return NVCA_ERR_HIP;
         } else {
-            { TimedLaunch t(ctx, NVCA_K_TILE); launch_cascade_sc(ctx->stream, a, batch, 3); }
-            { TimedLaunch t(ctx, NVCA_K_STRIP); launch_cascade_sc(ctx->stream, a, batch, 1); }
+            { TimedLaunch t(ctx, NVCA_K_TILE); if (launch(3)) return NVCA_ERR_HIP; }
+            { TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(1)) return NVCA_ERR_HIP; }
         }
-        { TimedLaunch t(ctx, NVCA_K_DEEP); launch_cascade_sc(ctx->stream, a, batch, 2); }
+        { TimedLaunch t(ctx, NVCA_K_DEEP); if (launch(2)) return NVCA_ERR_HIP; }
         // the box tables are small (a few KB per frame): the grouping kernel stores them straight into the page-locked host
         // buffer (plain stores, visible to the host once the stream has drained) -- no copy operation behind the last kernel
         if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
@@ -602,6 +607,7 @@ nvca_ctx::~nvca_ctx()
     plans.clear();
     nvca::free_scale_tables(this);
     if (ws) ws->release_all();
+    trk.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1470,6 +1476,20 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         if (!s || s->ctx != ctx || check_img(ctx, f.data, f.width, f.height, f.stride, 3, f.mem)) return NVCA_ERR_ARG;
         if (s->p.width_to_process <= 0) { ctx->set_error("width-to-process must be > 0"); return NVCA_ERR_ARG; }
     }
+    // The gates advance per-stream counters; plans and buffers are resolved after them and may still fail (too many scales,
+    // allocation).  A failed submit must leave every stream as it found it -- callers (the GStreamer shim) re-submit the
+    // frames one by one -- so the counters are restored on any error return.
+    struct GateSnap { nvca_face_stream *s; int num_frame, num_iter, to_process, pending; };
+    struct GateRollback {
+        std::vector<GateSnap> v; bool armed = true;
+        ~GateRollback() { if (armed) for (const GateSnap &g : v) { g.s->num_frame = g.num_frame; g.s->num_iter = g.num_iter; g.s->num_frames_to_process = g.to_process; g.s->pending_events = g.pending; } }
+    } gates;
+    for (int i = 0; i < n; i++) {
+        nvca_face_stream *s = streams[i];
+        bool seen = false;
+        for (const GateSnap &g : gates.v) if (g.s == s) { seen = true; break; }
+        if (!seen) gates.v.push_back(GateSnap{s, s->num_frame, s->num_iter, s->num_frames_to_process, s->pending_events});
+    }
     for (int i = 0; i < n; i++) {
         nvca_face_stream *s = streams[i];
         const nvca_frame &f = frames[i];
@@ -1566,6 +1586,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     if (!tk.done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
     NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->stream));
     tk.pending = true;
+    gates.armed = false;
     return NVCA_OK;
 }
 

@@ -5,7 +5,7 @@
 // FACE/kmsfacedetect.cpp:809-811.
 //
 // Launches per batch of frames:
-//  K5  k_band        (batches with >= 1024 bands in flight) one workgroup per row of tiles of a
+//  K5  k_band        (batches with >= 640 bands in flight, api.cpp) one workgroup per row of tiles of a
 //                    scale, walking it left to right: per tile (<= 32 x 32 windows) the integral
 //                    samples the windows touch are staged, compacted, in LDS; window variance and
 //                    stage 0 for every window; OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
@@ -1029,9 +1029,20 @@ void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, in
     NVCA_LAUNCH(k_group, dim3(batch), dim3(256), 0, st, a, group_thr, out, out_cap);
 }
 
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which)
+// dynamic LDS above 64 KiB has to be granted per function and device; the record of what has been granted lives in the
+// calling context (entry points hold that context's lock), so two contexts never share a word here
+static int grant_lds(const void *fn, int bytes, int *granted)
 {
-    if (batch <= 0 || a.ntasks <= 0) return;
+    if (bytes <= *granted) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    *granted = bytes;
+    return 0;
+}
+
+int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant)
+{
+    if (batch <= 0 || a.ntasks <= 0) return 0;
     if (which == 0) {
         const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
         NVCA_LAUNCH(k_stage0, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
@@ -1048,22 +1059,12 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
             NVCA_LAUNCH(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
         if (a.tile_blocks_per_frame > 0) {
-            static int lds_allowed[64] = {0};    // dynamic LDS above 64 KiB has to be granted once per device (entry points hold the context lock)
-            int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
-            if (a.tile_lds > lds_allowed[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
-                lds_allowed[dev] = a.tile_lds;
-            }
+            if (int e = grant_lds(reinterpret_cast<const void *>(k_tile), a.tile_lds, &lds_grant[0])) return e;
             NVCA_LAUNCH(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 5) {
         if (a.band_blocks_per_frame > 0) {
-            static int lds_allowed_b[64] = {0};
-            int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
-            if (a.tile_lds > lds_allowed_b[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_band), hipFuncAttributeMaxDynamicSharedMemorySize, a.tile_lds);
-                lds_allowed_b[dev] = a.tile_lds;
-            }
+            if (int e = grant_lds(reinterpret_cast<const void *>(k_band), a.tile_lds, &lds_grant[1])) return e;
             NVCA_LAUNCH(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 1) {
@@ -1072,6 +1073,7 @@ void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int whic
     } else if (a.deep_stage < a.nstages) {
         NVCA_LAUNCH(k_deep, dim3(8192), dim3(256), 0, st, a);    // grid-stride over the list, one window per workgroup at a time
     }
+    return 0;
 }
 
 } // namespace nvca

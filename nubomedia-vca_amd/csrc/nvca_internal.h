@@ -150,6 +150,12 @@ struct PinnedBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// tracker workspace (tracker.cpp): slot table, labels, per-root accumulators, component list, frame staging
+struct TrkWorkspace {
+    DevBuf slots, labels, acc, out, staging; PinnedBuf h_slots, h_out;
+    void release_all() { slots.release(); labels.release(); acc.release(); out.release(); staging.release(); h_slots.release(); h_out.release(); }
+};
+
 struct DetectPlan;   // plan.cpp
 struct ScaleTable;   // plan.cpp: one cascade at one scale factor (geometry-independent stump records), cached in the context
 struct FaceTicket;   // api.cpp
@@ -191,6 +197,8 @@ struct nvca_ctx {
     std::map<std::string, std::unique_ptr<nvca::GeomPlan>> plans;
     std::map<std::pair<uint64_t, uint64_t>, nvca::ScaleTable *> scale_tables;   // (cascade uid, factor bits)
     std::unique_ptr<nvca::Workspace> ws;
+    nvca::TrkWorkspace trk;           // tracker buffers live and die with the context
+    int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
     std::recursive_mutex mu;          // serialises entry points: elements on different streaming threads share one context
     void set_error(const std::string &s) { err = s; }
@@ -307,7 +315,9 @@ struct CascadeArgs {
     unsigned hit_cap;
 };
 // which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage, 5 = k_band
-void launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which);
+// lds_grant: the calling context's record of the dynamic LDS already granted to k_tile ([0]) / k_band ([1]); returns a
+// hipError_t (as int) when the grant is refused, 0 otherwise
+int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant);
 // detectMultiScale(CV_HAAR_SCALE_IMAGE) on two images of one geometry with shared launches (api.cpp; used by parts.cpp)
 int detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
                             int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs /* [2] */);

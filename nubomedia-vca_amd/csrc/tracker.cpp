@@ -18,14 +18,6 @@ struct nvca_tracker {
 };
 
 namespace {
-struct TrkWorkspace { DevBuf slots, labels, acc, out, staging; PinnedBuf h_slots, h_out; };
-TrkWorkspace &trk_ws(nvca_ctx *ctx)
-{
-    static std::map<nvca_ctx *, std::unique_ptr<TrkWorkspace>> all;      // freed with the process
-    auto &p = all[ctx];
-    if (!p) p.reset(new TrkWorkspace());
-    return *p;
-}
 constexpr int kCompCap = 1 << 18;
 }
 
@@ -72,7 +64,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             (f.mem != NVCA_MEM_HOST && f.mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
         for (int j = 0; j < i; j++) if (trackers[j] == trackers[i]) { ctx->set_error("a tracker may appear once per batch"); return NVCA_ERR_ARG; }
     }
-    TrkWorkspace &ws = trk_ws(ctx);
+    TrkWorkspace &ws = ctx->trk;
     static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
     auto tp0 = std::chrono::steady_clock::now(), tp1 = tp0, tp2 = tp0;
     int total_comps = 0;

@@ -132,6 +132,13 @@ void orc_face_stream_destroy(orc_face_stream *s);
  * (may be NULL) receives the Faces ids. */
 int orc_face_stream_process(orc_face_stream *s, const uint8_t *bgr, int w, int h,
                             int stride, orc_rect *out, int *ids, int cap);
+/* The same in three pieces, so that a harness which feeds the same frames again and again (bench.py) can compute each
+ * distinct frame's detections once and replay the temporal logic: process == gate -> (analysed ? frame_detect) -> finish. */
+int orc_face_stream_gate(orc_face_stream *s);
+int orc_face_frame_detect(const orc_cascade *c, const orc_face_params *p, const uint8_t *bgr, int w, int h, int stride,
+                          orc_rect *cur, int cap);
+int orc_face_stream_finish(orc_face_stream *s, int analysed, const orc_rect *cur, int n_cur, int w, int h,
+                           orc_rect *out, int *ids, int cap);
 /* Faces::track_faces on explicit lists (for unit tests).  State in/out:
  * faces[n_faces] with ids; cur[n_cur] current detections. Returns new count. */
 int orc_track_faces(orc_rect *faces, int *ids, int n_faces, int *next_id,

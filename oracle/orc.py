@@ -98,6 +98,11 @@ def lib():
         L.orc_face_stream_destroy.argtypes = [C.c_void_p]
         L.orc_face_stream_process.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(Rect),
                                               C.POINTER(C.c_int), C.c_int]
+        L.orc_face_stream_gate.argtypes = [C.c_void_p]
+        L.orc_face_frame_detect.argtypes = [C.POINTER(CCascade), C.POINTER(FaceParams), u8p, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(Rect), C.c_int]
+        L.orc_face_stream_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(Rect), C.POINTER(C.c_int), C.c_int]
         L.orc_track_faces.argtypes = [C.POINTER(Rect), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(Rect), C.c_int, C.c_int, C.c_int]
         L.orc_tracker_params_default.argtypes = [C.POINTER(TrackerParams)]
@@ -325,7 +330,31 @@ class FaceStream:
         for k, v in kw.items():
             setattr(p, k, v)
         self.casc = casc
+        self.p = p
         self.h = lib().orc_face_stream_create(C.byref(casc.c), C.byref(p))
+
+    def frame_detect(self, bgr, cap=256):
+        """the stateless part of an analysed frame (resize, gray, equalizeHist, detectMultiScale): working-image boxes"""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        H, W, _ = bgr.shape
+        buf = (Rect * cap)()
+        n = lib().orc_face_frame_detect(C.byref(self.casc.c), C.byref(self.p), _u8(bgr), W, H, bgr.strides[0], buf, cap)
+        return rects_to_np(buf, n)
+
+    def process_memo(self, key, bgr, memo, cap=256):
+        """process(bgr), with the frame's detections taken from / left in memo[key]: for harnesses that feed the same
+        frames again and again (the temporal logic still runs frame by frame)"""
+        H, W = bgr.shape[:2]
+        analysed = lib().orc_face_stream_gate(self.h)
+        det = np.zeros((0, 4), np.int32)
+        if analysed:
+            if key not in memo:
+                memo[key] = self.frame_detect(bgr)
+            det = memo[key]
+        buf = (Rect * cap)()
+        ids = (C.c_int * cap)()
+        n = lib().orc_face_stream_finish(self.h, analysed, np_to_rects(det), len(det), W, H, buf, ids, cap)
+        return rects_to_np(buf, n), np.array(ids[:n], dtype=np.int32)
 
     def process(self, bgr, cap=256):
         bgr = np.ascontiguousarray(bgr, dtype=np.uint8)

@@ -114,35 +114,57 @@ void orc_face_stream_destroy(orc_face_stream *s) { free(s); }
 #define GOP 4
 #define MAX_NUM_FPS_WITH_NO_DETECTION 1
 
-int orc_face_stream_process(orc_face_stream *s, const uint8_t *bgr, int W, int H,
-                            int stride, orc_rect *out, int *ids, int cap)
+/* working-image geometry of one frame: conf_images FACE/kmsfacedetect.cpp:304 (INTEGER division, kept in a float) and
+ * process_frame :770-783 */
+static void face_geometry(const orc_face_params *p, int W, int H, int *cols, int *rows, int *norm_scale)
 {
-    /* conf_images FACE/kmsfacedetect.cpp:304 -- INTEGER division, kept in a float */
-    float fscale = s->p.full_res ? 1.f : (float)(s->p.width_to_process ? W / s->p.width_to_process : 0);
+    float fscale = p->full_res ? 1.f : (float)(p->width_to_process ? W / p->width_to_process : 0);
     double scale = fscale;
-    int norm_scale = s->p.full_res ? 1 : (s->p.width_to_process ? W / s->p.width_to_process : 0);
-    /* process_frame :770-783 */
-    int rows = H, cols = W;
-    if (cv_round(H / scale) > 0) rows = cv_round(H / scale); else scale = 1;
-    if (cv_round(W / scale) > 0) cols = cv_round(W / scale); else scale = 1;
+    *norm_scale = p->full_res ? 1 : (p->width_to_process ? W / p->width_to_process : 0);
+    *rows = H; *cols = W;
+    if (cv_round(H / scale) > 0) *rows = cv_round(H / scale); else scale = 1;
+    if (cv_round(W / scale) > 0) *cols = cv_round(W / scale); else scale = 1;
+}
 
-    /* detect_event == 0: __receive_event returns true (:722-726) */
+/* frame gating of kms_face_detect_process_frame (:794-803) with detect_event == 0 (__receive_event returns true,
+ * :722-726): 1 if this frame is analysed.  Advances the frame counters. */
+int orc_face_stream_gate(orc_face_stream *s)
+{
     s->num_frame++; s->num_iter++;
     int px = s->p.process_x_every_4;
     if ((2 == px && (1 == s->num_frame % 2)) || ((2 != px) && (s->num_frame <= px))) {
         s->num_frames_to_process--;
-        uint8_t *aux = (uint8_t *)malloc((size_t)rows * cols * 3);
-        uint8_t *gray = (uint8_t *)malloc((size_t)rows * cols);
-        orc_resize_linear(bgr, W, H, stride, 3, aux, cols, rows, cols * 3);   /* :805 */
-        orc_bgr2gray(aux, cols, rows, cols * 3, 3, gray, cols);                /* :806 */
-        orc_equalize_hist(gray, cols, rows, cols, gray, cols);                 /* :807 */
-        orc_rect cur[ORC_MAX_FACES];
-        int n = orc_detect_multiscale(s->c, gray, cols, rows, cols,
-                                      1 + s->p.scale_factor_pct * 1.0 / 100, s->p.min_neighbors, 0,
-                                      cols / 20, rows / 20, 0, 0, s->p.policy, cur, ORC_MAX_FACES, NULL);
-        free(aux); free(gray);
-        if (n > 0) {
-            s->n_faces = orc_track_faces(s->faces, s->ids, s->n_faces, &s->next_id, cur, n,
+        return 1;
+    }
+    return 0;
+}
+
+/* the stateless part of an analysed frame: resize -> gray -> equalizeHist -> detectMultiScale (:805-811) */
+int orc_face_frame_detect(const orc_cascade *c, const orc_face_params *p, const uint8_t *bgr, int W, int H, int stride,
+                          orc_rect *cur, int cap)
+{
+    int rows, cols, norm_scale;
+    face_geometry(p, W, H, &cols, &rows, &norm_scale);
+    uint8_t *aux = (uint8_t *)malloc((size_t)rows * cols * 3);
+    uint8_t *gray = (uint8_t *)malloc((size_t)rows * cols);
+    orc_resize_linear(bgr, W, H, stride, 3, aux, cols, rows, cols * 3);   /* :805 */
+    orc_bgr2gray(aux, cols, rows, cols * 3, 3, gray, cols);                /* :806 */
+    orc_equalize_hist(gray, cols, rows, cols, gray, cols);                 /* :807 */
+    int n = orc_detect_multiscale(c, gray, cols, rows, cols, 1 + p->scale_factor_pct * 1.0 / 100, p->min_neighbors, 0,
+                                  cols / 20, rows / 20, 0, 0, p->policy, cur, cap, NULL);
+    free(aux); free(gray);
+    return n;
+}
+
+/* the temporal part (:813-830) and the emission (kms_face_send_event :190,208-211); cur is read only if analysed */
+int orc_face_stream_finish(orc_face_stream *s, int analysed, const orc_rect *cur, int n_cur, int W, int H,
+                           orc_rect *out, int *ids, int cap)
+{
+    int rows, cols, norm_scale;
+    face_geometry(&s->p, W, H, &cols, &rows, &norm_scale);
+    if (analysed) {
+        if (n_cur > 0) {
+            s->n_faces = orc_track_faces(s->faces, s->ids, s->n_faces, &s->next_id, cur, n_cur,
                                          s->p.track_threshold, ORC_MAX_FACES);
         } else {
             if (s->frames_with_no_detection < MAX_NUM_FPS_WITH_NO_DETECTION)
@@ -152,7 +174,7 @@ int orc_face_stream_process(orc_face_stream *s, const uint8_t *bgr, int W, int H
     }
     if (GOP == s->num_frame) s->num_frame = 0;
 
-    /* kms_face_send_event :190,208-211: (guint) r->x * norm_scale */
+    /* (guint) r->x * norm_scale */
     int n = s->n_faces < cap ? s->n_faces : cap;
     for (int i = 0; i < n; i++) {
         out[i].x = (int)((unsigned)s->faces[i].x * (unsigned)norm_scale);
@@ -162,6 +184,16 @@ int orc_face_stream_process(orc_face_stream *s, const uint8_t *bgr, int W, int H
         if (ids) ids[i] = s->ids[i];
     }
     return n;
+}
+
+int orc_face_stream_process(orc_face_stream *s, const uint8_t *bgr, int W, int H,
+                            int stride, orc_rect *out, int *ids, int cap)
+{
+    orc_rect cur[ORC_MAX_FACES];
+    int n = 0;
+    const int analysed = orc_face_stream_gate(s);
+    if (analysed) n = orc_face_frame_detect(s->c, &s->p, bgr, W, H, stride, cur, ORC_MAX_FACES);
+    return orc_face_stream_finish(s, analysed, cur, n, W, H, out, ids, cap);
 }
 
 /* ============================ NuboTracker =============================== */
