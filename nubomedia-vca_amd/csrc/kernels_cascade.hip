@@ -30,6 +30,18 @@ namespace nvca {
 // Wave-uniform table records are read through the constant address space: the compiler then issues scalar loads
 // (s_load) for them even though the kernels also store to global memory.  The tables are never written by a kernel.
 typedef const __attribute__((address_space(4))) TStumpRec CTStumpRec;
+// a small plain record at a wave-uniform address, read dword by dword through the constant address space (s_load)
+template <class T> __device__ __forceinline__ T load_const(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword records only");
+    typedef const __attribute__((address_space(4))) int CInt;
+    CInt *q = (CInt *)p;
+    T r;
+    int *d = (int *)&r;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = q[i];
+    return r;
+}
 
 __device__ __forceinline__ int ldsum(const int *__restrict__ sum, unsigned idx) { return sum[idx]; }
 
@@ -516,34 +528,53 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
     return L;
 }
 
-// window origins, coordinate maps and the compacted sample rows x columns of one tile -> LDS (no barrier inside)
-__device__ __forceinline__ void tile_fill(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L)
+// Staging a tile = two rounds of global reads.  Round 1 (tile_coords): every coordinate a thread needs -- its entries of
+// the tile's column / row lists for the maps, the window origins, the wave's sample-row offsets and the lane's sample
+// columns.  Round 2 (tile_commit): the maps are scattered into LDS and the sample rows x columns are copied global -> LDS by
+// LDS-DMA (global_load_lds_dword: the source address is per lane -- a gather of the tile's lattice columns -- the
+// destination is 64 consecutive words of the row, no registers in between).  A wave takes rows wave, wave + 16, ...; every
+// transfer of the tile is in flight before the first one is waited for (register staging kept two rows per wave in
+// flight: the copy was a chain of dependent round trips).  The caller waits: s_waitcnt vmcnt(0) + barrier before T is read.
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+struct TileCoords { int mapc, mapr, wx, wy; unsigned rowb, xcb[4]; };
+__device__ __forceinline__ TileCoords tile_coords(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned short *__restrict__ cl = a.tcoords + t.col_off, *__restrict__ rl = a.tcoords + t.row_off;
-    const int *__restrict__ xpos = a.pos + sc.xpos_off + t.ix0;
-    const int *__restrict__ ypos = a.pos + sc.ypos_off + t.iy0;
-    if (tid < 3) L.qn[tid] = 0;          // the three rotating queue counters (qn[3]: list base scratch)
-    if (tid < t.nx) L.winx[tid] = (unsigned short)(xpos[tid] - t.x0);
-    if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(ypos[tid - 64] - t.y0);
-    for (int c = tid; c < t.ncol; c += kTileThreads) L.cmap[cl[c] - t.x0] = (unsigned short)(c * 4);
-    for (int r = tid; r < t.nrow; r += kTileThreads) L.rmap[rl[r] - t.y0] = (unsigned short)(r * L.pitchT);
-    // a wave per sample row (two rows in flight), lanes across the compacted columns
-    const int *__restrict__ src = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-    int xc[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int c = lane + 64 * k; xc[k] = (int)cl[c < t.ncol ? c : t.ncol - 1]; }   // clamped: loads stay unconditional
     constexpr int NW = kTileThreads / 64;
-    const int nk = (t.ncol + 63) >> 6;      // 64-column groups that hold a staged column (wave-uniform: the others are skipped)
-    for (int r = wave; r < t.nrow; r += 2 * NW) {
-        const int ra = __builtin_amdgcn_readfirstlane(r), rb = ra + NW < t.nrow ? ra + NW : ra;
-        const int *__restrict__ pa = src + (size_t)rl[ra] * sc.pitch, *__restrict__ pb = src + (size_t)rl[rb] * sc.pitch;
-        int va[4], vb[4];
+    const unsigned short *__restrict__ cl = a.tcoords + t.col_off, *__restrict__ rl = a.tcoords + t.row_off;
+    TileCoords c;
+    c.mapc = tid < t.ncol ? (int)cl[tid] : -1;               // ncol, nrow <= 256 < kTileThreads: one list entry per thread
+    c.mapr = tid < t.nrow ? (int)rl[tid] : -1;
+    c.wx = tid < t.nx ? a.pos[sc.xpos_off + t.ix0 + tid] : 0;
+    c.wy = (tid >= 64 && tid < 64 + t.ny) ? a.pos[sc.ypos_off + t.iy0 + tid - 64] : 0;
+    const int nmine = t.nrow > wave ? (t.nrow - wave + NW - 1) / NW : 0;
+    c.rowb = lane < nmine ? (unsigned)rl[wave + NW * lane] * (unsigned)sc.pitch * 4u : 0u;     // lane j: the wave's j-th sample row
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k < nk) { va[k] = pa[xc[k]]; vb[k] = pb[xc[k]]; }
+    for (int k = 0; k < 4; k++) { const int q = lane + 64 * k; c.xcb[k] = 4u * (unsigned)cl[q < t.ncol ? q : t.ncol - 1]; }
+    return c;
+}
+__device__ __forceinline__ void tile_commit(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, const TileCoords &c)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = kTileThreads / 64;
+    const char *__restrict__ src = (const char *)(a.sum + (size_t)slot * a.sum_slot + sc.plane_off);
+    const int nmine = t.nrow > wave ? (t.nrow - wave + NW - 1) / NW : 0;
+    const int nk = (t.ncol + 63) >> 6;      // 64-column groups that hold a staged column (wave-uniform)
+    for (int j = 0; j < nmine; j++) {
+        const unsigned rb = (unsigned)__builtin_amdgcn_readlane((int)c.rowb, j);
+        const char *rowp = src + rb;
+        int *dst = L.T + (wave + NW * j) * L.pitchT;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (k < nk && lane + 64 * k < t.ncol) { L.T[ra * L.pitchT + lane + 64 * k] = va[k]; L.T[rb * L.pitchT + lane + 64 * k] = vb[k]; }
+        for (int k = 0; k < 4; k++)
+            if (k < nk && lane + 64 * k < t.ncol)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rowp + c.xcb[k]), (lptr_t)(dst + 64 * k), 4, 0, 0);
     }
+    if (tid < 3) L.qn[tid] = 0;          // the three rotating queue counters (qn[3]: list base scratch)
+    if (tid < t.nx) L.winx[tid] = (unsigned short)(c.wx - t.x0);
+    if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(c.wy - t.y0);
+    if (c.mapc >= 0) L.cmap[c.mapc - t.x0] = (unsigned short)(tid * 4);
+    if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(tid * L.pitchT);
 }
 
 __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
@@ -588,7 +619,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
         const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
         unsigned short *qo = L.q0 + (cur ^ 1) * kTileWin * kTileWin;
-        const StageRec st = a.stages[s];
+        const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
         if ((st.flags & 2) && n <= kTileThreads / 2) {
             // few survivors and an order-free stage sum: thread = (window slot i, stump partition p)
@@ -667,9 +698,11 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileRec t = a.tiles[tidx];
     const ScaleRec &sc = a.scales[t.scale];
     const TileLds L = carve_tile(lds, t);
-    tile_fill(a, t, sc, slot, L);
+    const TileCoords tc = tile_coords(a, t, sc);
+    tile_commit(a, t, sc, slot, L, tc);
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
-    __syncthreads();                 // qn zeroed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
+    __syncthreads();                 // qn zeroed, maps and samples staged
     // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
     for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
         const int w = base + tid, ry = w >> 5, rx = w & 31;
@@ -703,39 +736,55 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         const int fi = k / (a.band_blocks_per_frame * g), r = k - fi * a.band_blocks_per_frame * g;
         bi = r / g; slot = xcd + 8 * (fi * g + (r - bi * g));
     }
-    const BandRec b = a.bands[a.band_order[bi]];
+    const BandRec b = load_const(a.bands + a.band_order[bi]);
     const ScaleRec &sc = a.scales[b.scale];
     const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
     const uint8_t *__restrict__ sqh = (const uint8_t *)((const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + a.sum_slot) + sc.plane_off;
     const bool sq_lo_only = sc.sq32 != 0;
     const int ex0 = sc.eq[0] % sc.pitch, ey0 = sc.eq[0] / sc.pitch, ex1 = sc.eq[3] % sc.pitch, ey1 = sc.eq[3] / sc.pitch;
-    const StageRec st0 = a.stages[0];
+    const StageRec st0 = load_const(a.stages);
     const bool pair0 = a.pair_policy && (st0.flags & 1);
     {   // carried parity lives at a fixed place: the carve-up's fixed part does not depend on the tile
-        const TileRec t0 = a.tiles[b.first_tile];
+        const TileRec t0 = load_const(a.tiles + b.first_tile);
         const TileLds L0 = carve_tile(lds, t0);
         if (tid < kTileWin) L0.carry[tid] = 0;
     }
+    static_assert(kTileWin * kTileWin == kTileThreads, "one window per thread and tile");
+    const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band
     for (int ti = 0; ti < b.ntiles; ti++) {
         __syncthreads();             // previous tile completely done with LDS
-        const TileRec t = a.tiles[b.first_tile + ti];
+        const TileRec t = load_const(a.tiles + b.first_tile + ti);
         const TileLds L = carve_tile(lds, t);
-        tile_fill(a, t, sc, slot, L);
+        // this thread's window: its origin comes straight from the position tables, so that the four (eight) squared-integral
+        // corners -- uncoalesced global reads -- are requested before the tile's samples and arrive under their transfer
+        const bool active = ry < t.ny && rx < t.nx;
+        int xw = 0, yw = 0;
+        unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+        if (active) { xw = a.pos[sc.xpos_off + t.ix0 + rx]; yw = a.pos[sc.ypos_off + t.iy0 + ry]; }
+        const TileCoords tc = tile_coords(a, t, sc);            // round 1: coordinates
+        if (active) {                                            // round 2: the squared-integral corners, then the samples
+            xw -= t.x0; yw -= t.y0;
+            const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
+            const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
+            q0 = sql[e0]; q1 = sql[e1]; q2 = sql[e2]; q3 = sql[e3];
+            if (!sq_lo_only) { h0 = sqh[e0]; h1 = sqh[e1]; h2 = sqh[e2]; h3 = sqh[e3]; }
+        }
+        tile_commit(a, t, sc, slot, L, tc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
         __syncthreads();
         // variance + stage 0 for every window of the tile; a wave covers two window rows
-        for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
-            const int w = base + tid, ry = w >> 5, rx = w & 31;
-            const bool active = ry < t.ny && rx < t.nx;
+        {
             bool pass0 = false;
             if (active) {
-                const int xw = L.winx[rx], yw = L.winy[ry];
                 const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
                 auto at = [&](int rw, int cb) { return *(const int *)((const char *)L.T + ((rw << 2) + cb)); };
                 const int ws = at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
                 const double mean = (double)ws * sc.inv_area;
-                const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
-                const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
-                double vnf = window_sqsum(sql, sqh, sq_lo_only, e0, e1, e2, e3);
+                // squared-pixel sum of the variance window: exact integers below 2^53 (see window_sqsum)
+                double vnf;
+                if (sq_lo_only) vnf = (double)(unsigned)(q0 - q1 - q2 + q3);
+                else vnf = (double)(((unsigned long long)h0 << 32) | q0) - (double)(((unsigned long long)h1 << 32) | q1) -
+                           (double)(((unsigned long long)h2 << 32) | q2) + (double)(((unsigned long long)h3 << 32) | q3);
                 vnf = vnf * sc.inv_area - mean * mean;
                 vnf = vnf >= 0. ? sqrt(vnf) : 1.;
                 L.vnf_s[w] = vnf;
@@ -750,10 +799,9 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         __syncthreads();
         // OpenCV's adaptive x step: a window is visited iff the run of stage-0 rejects immediately left of it in its
         // row has even length; a run that reaches the tile's left edge continues with the carried parity
-        for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
-            const int w = base + tid, ry = w >> 5, rx = w & 31;
+        {
             bool keep = false;
-            if (ry < t.ny && rx < t.nx) {
+            if (active) {
                 const unsigned R = L.rej[ry];
                 if (!((R >> rx) & 1u)) {
                     if (!sc.adaptive) keep = true;

@@ -258,7 +258,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                     coords(yp, i0, std::min(i0 + tw, sr.endY), offy, cy);
                     worst_r = std::max(worst_r, (int)cy.size()); worst_sy = std::max(worst_sy, cy.back() - yp[i0] + 1);
                 }
-                ok = worst_c <= kTileMaxCols && worst_r * tile_pitch(worst_c) < 65536 &&
+                ok = worst_c <= kTileMaxCols && worst_r <= kTileThreads && worst_r * tile_pitch(worst_c) < 65536 &&
                      tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy) <= kTileLdsBudget;
                 if (ok) break;
             }
