@@ -19,6 +19,8 @@ LIB = os.path.join(HERE, "libnubovca_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+if os.environ.get("NVCA_BUILD_STAMPS"):      # diagnostic build: in-kernel phase stamps (scripts/stamps.py); never the shipped library
+    COMMON.append("-DNVCA_STAMPS")
 ARCH = ["--offload-arch=gfx950"]
 
 

@@ -388,6 +388,13 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
+#ifdef NVCA_STAMPS
+        {   // diagnostic build: the stamps of the last band launch are written to $NVCA_STAMPS_OUT when the context synchronises
+            static DevBuf dbgbuf;
+            a.dbg = nullptr;
+            if (getenv("NVCA_STAMPS_OUT") && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->stream); ctx->stamps = a.dbg; }
+        }
+#endif
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
         const char *band_e = getenv("NVCA_BAND");
         const int band_env = band_e ? atoi(band_e) : -1;
@@ -666,6 +673,13 @@ int nvca_ctx_synchronize(nvca_ctx *ctx)
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef NVCA_STAMPS
+    if (ctx->stamps && getenv("NVCA_STAMPS_OUT")) {
+        std::vector<unsigned long long> h(64 * 16 * 64);
+        (void)hipMemcpy(h.data(), ctx->stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("NVCA_STAMPS_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
     return NVCA_OK;
 }
 void *nvca_ctx_stream(nvca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

@@ -506,10 +506,19 @@ __device__ __forceinline__ double tile_stage_sum(const int *T, const unsigned sh
     return sum;
 }
 
+#ifdef NVCA_STAMPS
+// diagnostic build: thread 0 of the first 64 workgroups leaves s_memtime stamps per tile and phase (64 words per tile, 16 tiles)
+#define NVCA_STAMP(a, tile, id) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) { unsigned long long t__; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = t__; } } while (0)
+#else
+#define NVCA_STAMP(a, tile, id) do { } while (0)
+#endif
+
 // LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
 struct TileLds {
     double *psum; unsigned short *q0, *winx, *winy; int *qn; double *vnf_s; unsigned *rej; int *carry;
     unsigned short *cmap, *rmap; int *T; int pitchT;
+    const int *Tb; int toff;      // what the vote functions index: the start of the LDS region, and T's word offset in it (folded into rmap)
 };
 __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec &t)
 {
@@ -525,6 +534,7 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
     L.rmap = L.cmap + ((t.span_x + 3) & ~3);
     L.T = (int *)(L.rmap + ((t.span_y + 3) & ~3));
     L.pitchT = tile_pitch(t.ncol);
+    L.Tb = (const int *)lds; L.toff = (int)(L.T - (const int *)lds);      // the whole region is < 2^16 words (tile_lds_bytes <= 80 KiB)
     return L;
 }
 
@@ -574,7 +584,7 @@ __device__ __forceinline__ void tile_commit(const CascadeArgs &a, const TileRec 
     if (tid < t.nx) L.winx[tid] = (unsigned short)(c.wx - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(c.wy - t.y0);
     if (c.mapc >= 0) L.cmap[c.mapc - t.x0] = (unsigned short)(tid * 4);
-    if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(tid * L.pitchT);
+    if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(L.toff + tid * L.pitchT);     // row start as a word offset from the region start: a corner address is one shift-add
 }
 
 __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
@@ -594,7 +604,7 @@ __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, 
 // publish it for k_deep) instead of the stage-0 pre-pass's global array.  Ends with every thread past its last LDS use
 // of the queues only after the caller's next barrier.
 template <bool VNF_LDS>
-__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L)
+__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0)
 {
     const int tid = threadIdx.x;
     CTStumpRec *recs = (CTStumpRec *)sc.trecs;
@@ -613,8 +623,12 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
     for (int s = 1; s < last; s++) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
+        NVCA_STAMP(a, ti, 8 + 8 * s);
         const int n = L.qn[cin];
         if (n == 0) break;
+#ifdef NVCA_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < 64 && ti < 16 && a.dbg) a.dbg[((size_t)blockIdx.x * 16 + ti) * 64 + 8 + 8 * s + 7] = (unsigned long long)n;
+#endif
         const int cout = cin == 2 ? 0 : cin + 1;
         if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
         const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
@@ -622,38 +636,39 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
         if ((st.flags & 2) && n <= kTileThreads / 2) {
-            // few survivors and an order-free stage sum: thread = (window slot i, stump partition p)
-            int lg = 0;
-            while ((1 << lg) < n) lg++;
-            const int npad = 1 << lg;
-            int P = kTileThreads >> lg;
+            // few survivors and an order-free stage sum: thread = (window slot i, stump partition p).  A partition is a
+            // whole number of waves (the queue padded to a multiple of 64), so stump records stay wave-uniform (scalar loads)
+            const int nw = (n + 63) >> 6, npad = nw << 6;
+            int P = (kTileThreads / 64) / nw;
             if (P > st.count) P = st.count;
-            const int i = tid & (npad - 1), p = tid >> lg;
+            if (P > 16) P = 16;              // the partial sums of a window are added up by one thread
+            const int p = __builtin_amdgcn_readfirstlane((tid >> 6) / nw), i = tid - p * npad;
             double part = 0.0;
             if (i < n && p < P) {
                 const int w = qi[i];
                 const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
                 const double vnf = vnf_of(w);
-                if (lg >= 6) {               // a wave holds one partition: records stay wave-uniform (scalar loads)
-                    const int pu = __builtin_amdgcn_readfirstlane(p);
-                    part = pair ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, pu, st.count, P)
-                                : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, pu, st.count, P);
-                } else {
-                    for (int j = p; j < st.count; j += P)
-                        part += pair ? tile_vote<true, false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j])
-                                     : tile_vote<false, false>(L.T, L.cmap, L.rmap, xw, yw, vnf, recs[st.first + j]);
-                }
+                part = pair ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, p, st.count, P)
+                            : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, p, st.count, P);
             }
+            NVCA_STAMP(a, ti, 8 + 8 * s + 1);
             L.psum[tid] = part;
             __syncthreads();
+            NVCA_STAMP(a, ti, 8 + 8 * s + 2);
             bool pass = false; int w = 0;
             if (tid < n) {
                 double tot = 0.0;
-                for (int pp = 0; pp < P; pp++) tot += L.psum[(pp << lg) + tid];
+                int pp = 0;
+                for (; pp + 4 <= P; pp += 4) {       // four independent reads in flight; any order of the adds is exact here
+                    const double d0 = L.psum[pp * npad + tid], d1 = L.psum[(pp + 1) * npad + tid], d2 = L.psum[(pp + 2) * npad + tid], d3 = L.psum[(pp + 3) * npad + tid];
+                    tot += d0; tot += d1; tot += d2; tot += d3;
+                }
+                for (; pp < P; pp++) tot += L.psum[pp * npad + tid];
                 pass = !(tot < (double)st.thr);
                 w = qi[tid];
             }
             queue_push(pass, w, qo, &L.qn[cout]);
+            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
         } else
         for (int base = 0; base < n; base += kTileThreads) {
             const int i = base + tid;
@@ -662,8 +677,8 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 w = qi[i];
                 const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
                 const double vnf = vnf_of(w);
-                const double stage_sum = pair ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1)
-                                              : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1);
+                const double stage_sum = pair ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1)
+                                              : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1);
                 pass = !(stage_sum < (double)st.thr);
             }
             queue_push(pass, w, qo, &L.qn[cout]);
@@ -671,6 +686,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         cur ^= 1; cin = cout;
     }
     __syncthreads();
+    NVCA_STAMP(a, ti, 6);
     const int nh = L.qn[cin];
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
@@ -686,6 +702,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
         if (VNF_LDS && last != a.nstages) a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
     }
+    NVCA_STAMP(a, ti, 7);
 }
 
 __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(CascadeArgs a)
@@ -753,6 +770,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band
     for (int ti = 0; ti < b.ntiles; ti++) {
         __syncthreads();             // previous tile completely done with LDS
+        NVCA_STAMP(a, ti, 0);
         const TileRec t = load_const(a.tiles + b.first_tile + ti);
         const TileLds L = carve_tile(lds, t);
         // this thread's window: its origin comes straight from the position tables, so that the four (eight) squared-integral
@@ -769,15 +787,18 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             q0 = sql[e0]; q1 = sql[e1]; q2 = sql[e2]; q3 = sql[e3];
             if (!sq_lo_only) { h0 = sqh[e0]; h1 = sqh[e1]; h2 = sqh[e2]; h3 = sqh[e3]; }
         }
+        NVCA_STAMP(a, ti, 1);
         tile_commit(a, t, sc, slot, L, tc);
+        NVCA_STAMP(a, ti, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
         __syncthreads();
+        NVCA_STAMP(a, ti, 3);
         // variance + stage 0 for every window of the tile; a wave covers two window rows
         {
             bool pass0 = false;
             if (active) {
                 const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
-                auto at = [&](int rw, int cb) { return *(const int *)((const char *)L.T + ((rw << 2) + cb)); };
+                auto at = [&](int rw, int cb) { return *(const int *)((const char *)L.Tb + ((rw << 2) + cb)); };
                 const int ws = at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
                 const double mean = (double)ws * sc.inv_area;
                 // squared-pixel sum of the variance window: exact integers below 2^53 (see window_sqsum)
@@ -788,8 +809,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
                 vnf = vnf * sc.inv_area - mean * mean;
                 vnf = vnf >= 0. ? sqrt(vnf) : 1.;
                 L.vnf_s[w] = vnf;
-                const double stage_sum = pair0 ? tile_stage_sum<true>(L.T, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1)
-                                               : tile_stage_sum<false>(L.T, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1);
+                const double stage_sum = pair0 ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1)
+                                               : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1);
                 pass0 = !(stage_sum < (double)st0.thr);
             }
             const unsigned long long fb = __ballot(active && !pass0);
@@ -797,6 +818,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             if (lane == 32 && ry < t.ny) L.rej[ry] = (unsigned)(fb >> 32);
         }
         __syncthreads();
+        NVCA_STAMP(a, ti, 4);
         // OpenCV's adaptive x step: a window is visited iff the run of stage-0 rejects immediately left of it in its
         // row has even length; a run that reaches the tile's left edge continues with the carried parity
         {
@@ -827,7 +849,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             if (ones > t.nx) ones = t.nx;
             L.carry[tid] = ones == t.nx ? ((t.nx + L.carry[tid]) & 1) : (ones & 1);
         }
-        tile_stages<true>(a, t, sc, slot, L);
+        NVCA_STAMP(a, ti, 5);
+        tile_stages<true>(a, t, sc, slot, L, ti);
     }
 }
 

@@ -200,6 +200,9 @@ struct nvca_ctx {
     nvca::TrkWorkspace trk;           // tracker buffers live and die with the context
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
+#ifdef NVCA_STAMPS
+    unsigned long long *stamps = nullptr;
+#endif
     std::recursive_mutex mu;          // serialises entry points: elements on different streaming threads share one context
     void set_error(const std::string &s) { err = s; }
     nvca_ctx();
@@ -313,6 +316,9 @@ struct CascadeArgs {
     unsigned deep_cap;
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
+#ifdef NVCA_STAMPS
+    unsigned long long *dbg;       // diagnostic build only: per-phase s_memtime stamps of the first workgroups (scripts/stamps.py)
+#endif
 };
 // which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage, 5 = k_band
 // lds_grant: the calling context's record of the dynamic LDS already granted to k_tile ([0]) / k_band ([1]); returns a

@@ -55,6 +55,9 @@ int orc_equalize_lut(const int hist[256], int total, uint8_t lut[256]);
 /* cv::integral: sum int32 and sqsum double, both (h+1)*(w+1) dense. */
 void orc_integral(const uint8_t *src, int w, int h, int stride,
                   int32_t *sum, double *sqsum);
+/* the tilted integral of cv::integral (int32, (h+1)*(w+1) dense): tilted(X,Y) = sum of image(x,y) over
+ * y < Y, abs(x - X + 1) <= Y - y - 1.  Read by tilted Haar features (cvSetImagesForHaarClassifierCascade). */
+void orc_integral_tilted(const uint8_t *src, int w, int h, int stride, int32_t *tilted);
 /* cv::flip(src, dst, 1) */
 void orc_flip_h(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
 

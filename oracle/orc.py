@@ -83,6 +83,7 @@ def lib():
         L.orc_resize_linear.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
         L.orc_equalize_hist.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
         L.orc_integral.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        L.orc_integral_tilted.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.orc_flip_h.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
         L.orc_detect_multiscale.argtypes = [C.POINTER(CCascade), u8p, C.c_int, C.c_int, C.c_int, C.c_double,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -178,6 +179,14 @@ def integral(img):
     return s, q
 
 
+def integral_tilted(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    t = np.empty((h + 1, w + 1), np.int32)
+    lib().orc_integral_tilted(_u8(img), w, h, img.strides[0], t.ctypes.data_as(C.POINTER(C.c_int32)))
+    return t
+
+
 def flip_h(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
@@ -226,7 +235,8 @@ def parse_cascade_xml(text):
 
     Follows icvReadHaarClassifier (OpenCV 2.4 haar.cpp): numbers are parsed as
     double and stored as float; a <left_val>/<right_val> becomes alpha[last++]
-    with child index -last; tilted and tree-structured stage graphs rejected.
+    with child index -last; tree-structured STAGE graphs (parent / next) are rejected, tree-structured weak
+    classifiers and tilted features are read.
     """
     root = ET.fromstring(text)
     node = None
@@ -246,7 +256,7 @@ def parse_cascade_xml(text):
         parent = int(st.find("parent").text)
         nxt = int(st.find("next").text)
         if parent != si - 1 or nxt != -1:
-            raise ValueError("tree-structured stage graph not supported")
+            raise ValueError("tree-structured STAGE graph not supported (weak classifiers may be trees)")
         for tree in trees:
             cls_nnodes.append(len(tree))
             last = 0
@@ -270,8 +280,6 @@ def parse_cascade_xml(text):
                         dst.append(-last)
                         alpha.append(np.float32(float(nd.find(tag + "_val").text)))
                         last += 1
-    if any(tilted):
-        raise ValueError("tilted features not supported by the oracle")
     return Cascade(ow, oh, stage_ncls, stage_thr, cls_nnodes, rects, rweights, tilted, node_thr,
                    left, right, alpha)
 

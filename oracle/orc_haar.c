@@ -51,6 +51,7 @@ typedef struct {
     int is_stump_based;
     /* set by set_images */
     const int32_t *sum; const double *sqsum; int step; /* step in elements */
+    const int32_t *tilted;    /* tilted integral (same shape as sum) or NULL: no tilted feature in the cascade */
     int sum_w, sum_h;     /* sum.cols, sum.rows (= img+1) */
     double inv_window_area;
     int ep0, ep1, ep2, ep3;    /* equRect corner offsets */
@@ -104,14 +105,15 @@ static void hid_free(hid_cascade *h)
     free(h->nodes); free(h->cls_first_node); free(h->cls_first_alpha); free(h->stages); free(h);
 }
 
-/* cvSetImagesForHaarClassifierCascade (A.6).  Tilted features are not
- * supported by this restatement (none of the reference's cascades is believed
- * to use them); the python reader refuses such cascades. */
-static void hid_set_images(hid_cascade *h, const int32_t *sum, const double *sqsum,
+/* cvSetImagesForHaarClassifierCascade (A.6).  An upright rectangle (x,y,w,h) reads the four corners of sum; a
+ * tilted one (the rectangle rotated by 45 degrees about its top corner (x,y), w along the down-right and h along the
+ * down-left diagonal) reads the tilted integral at p0 = (y, x), p1 = (y+h, x-h), p2 = (y+w, x+w),
+ * p3 = (y+w+h, x+w-h) and its weight is halved (correction_ratio 0.5: a tilted w x h rectangle covers 2wh pixels). */
+static void hid_set_images(hid_cascade *h, const int32_t *sum, const double *sqsum, const int32_t *tilted,
                            int sum_w, int sum_h, double scale)
 {
     const orc_cascade *c = h->c;
-    h->sum = sum; h->sqsum = sqsum; h->step = sum_w; h->sum_w = sum_w; h->sum_h = sum_h;
+    h->sum = sum; h->sqsum = sqsum; h->tilted = tilted; h->step = sum_w; h->sum_w = sum_w; h->sum_h = sum_h;
     h->real_w = cv_round(c->ow * scale);
     h->real_h = cv_round(c->oh * scale);
     int ex = cv_round(scale), ey = ex;
@@ -129,8 +131,13 @@ static void hid_set_images(hid_cascade *h, const int32_t *sum, const double *sqs
             int tx = cv_round(r[0] * scale), tw = cv_round(r[2] * scale);
             int ty = cv_round(r[1] * scale), th = cv_round(r[3] * scale);
             double correction_ratio = weight_scale * (!hn->tilted ? 1 : 0.5);
-            hn->r[k].p0 = ty * sum_w + tx;          hn->r[k].p1 = ty * sum_w + tx + tw;
-            hn->r[k].p2 = (ty + th) * sum_w + tx;   hn->r[k].p3 = (ty + th) * sum_w + tx + tw;
+            if (!hn->tilted) {
+                hn->r[k].p0 = ty * sum_w + tx;          hn->r[k].p1 = ty * sum_w + tx + tw;
+                hn->r[k].p2 = (ty + th) * sum_w + tx;   hn->r[k].p3 = (ty + th) * sum_w + tx + tw;
+            } else {
+                hn->r[k].p0 = ty * sum_w + tx;                 hn->r[k].p1 = (ty + th) * sum_w + tx - th;
+                hn->r[k].p2 = (ty + tw) * sum_w + tx + tw;     hn->r[k].p3 = (ty + tw + th) * sum_w + tx + tw - th;
+            }
             hn->r[k].weight = (float)(c->rweights[n * 3 + k] * correction_ratio);
             if (k == 0)
                 area0 = tw * th;
@@ -144,13 +151,15 @@ static void hid_set_images(hid_cascade *h, const int32_t *sum, const double *sqs
     }
 }
 
-#define CALC_SUM(R, off) (h->sum[(R).p0 + (off)] - h->sum[(R).p1 + (off)] - h->sum[(R).p2 + (off)] + h->sum[(R).p3 + (off)])
+#define CALC_SUM_P(P, R, off) ((P)[(R).p0 + (off)] - (P)[(R).p1 + (off)] - (P)[(R).p2 + (off)] + (P)[(R).p3 + (off)])
+#define CALC_SUM(R, off) CALC_SUM_P(pl, R, off)
 
 /* feature value of one node under the selected accumulation policy.
  * pair_f32: this node sits in a two_rects stage of a stump cascade evaluated
  * by the SSE2 code path. */
 static inline double node_sum(const hid_cascade *h, const hid_node *n, int off, int pair_f32)
 {
+    const int32_t *pl = n->tilted ? h->tilted : h->sum;     /* the plane the feature's corner pointers refer to */
     if (pair_f32) {
         float s = CALC_SUM(n->r[0], off) * n->r[0].weight + CALC_SUM(n->r[1], off) * n->r[1].weight;
         return (double)s;
@@ -327,10 +336,13 @@ static int detect_impl(const orc_cascade *c, const uint8_t *img, int cols, int r
     /* DO_CANNY_PRUNING is never set by the reference; not restated. */
 
     hid_cascade *h = (grid ? NULL : hid_create(c, policy, stats));
-    int32_t *sum = NULL; double *sqsum = NULL;
+    int32_t *sum = NULL, *tilted = NULL; double *sqsum = NULL;
     if (!grid) {
         sum = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows + 1) * (cols + 1));
         sqsum = (double *)malloc(sizeof(double) * (size_t)(rows + 1) * (cols + 1));
+        int has_tilted = 0;                  /* hid_cascade->has_tilted_features: the third plane of cvIntegral */
+        for (int n = 0; n < c->n_nodes; n++) has_tilted |= c->tilted[n] != 0;
+        if (has_tilted) tilted = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows + 1) * (cols + 1));
     }
 
     if (flags & ORC_HAAR_SCALE_IMAGE) {
@@ -346,7 +358,8 @@ static int detect_impl(const orc_cascade *c, const uint8_t *img, int cols, int r
             if (stats) stats->n_scales++;
             orc_resize_linear(img, cols, rows, stride, 1, small, szw, szh, szw);
             orc_integral(small, szw, szh, szw, sum, sqsum);
-            hid_set_images(h, sum, sqsum, szw + 1, szh + 1, 1.);
+            if (tilted) orc_integral_tilted(small, szw, szh, szw, tilted);
+            hid_set_images(h, sum, sqsum, tilted, szw + 1, szh + 1, 1.);
             int ystep = factor > 2 ? 1 : 2;
             /* strips only partition rows into multiples of ystep: same set of y */
             int y2 = (szh + 1) - 1 - c->oh;
@@ -363,7 +376,7 @@ static int detect_impl(const orc_cascade *c, const uint8_t *img, int cols, int r
     } else {
         int n_factors = 0;
         orc_rect scanROI = { 0, 0, 0, 0 };
-        if (!grid) orc_integral(img, cols, rows, stride, sum, sqsum);
+        if (!grid) { orc_integral(img, cols, rows, stride, sum, sqsum); if (tilted) orc_integral_tilted(img, cols, rows, stride, tilted); }
         for (n_factors = 0, factor = 1;
              factor * c->ow < cols - 10 && factor * c->oh < rows - 10;
              n_factors++, factor *= scaleFactor)
@@ -380,7 +393,7 @@ static int detect_impl(const orc_cascade *c, const uint8_t *img, int cols, int r
             if (winw > maxw || winh > maxh) { if (!findBiggest) break; continue; }
             if (grid) { if (*grid_n < grid_cap) grid[*grid_n] = factor; (*grid_n)++; continue; }
             if (stats) stats->n_scales++;
-            hid_set_images(h, sum, sqsum, cols + 1, rows + 1, factor);
+            hid_set_images(h, sum, sqsum, tilted, cols + 1, rows + 1, factor);
             if (scanROI.w * scanROI.h > 0) {
                 startY = cv_round(scanROI.y / ystep);
                 endY = cv_round((scanROI.y + scanROI.h - winh) / ystep);
@@ -437,7 +450,7 @@ static int detect_impl(const orc_cascade *c, const uint8_t *img, int cols, int r
     }
     int nout = n < cap ? n : cap;
     if (nout > 0) memcpy(out, all.v, sizeof(orc_rect) * nout);
-    free(all.v); free(sum); free(sqsum); hid_free(h);
+    free(all.v); free(sum); free(sqsum); free(tilted); hid_free(h);
     return nout;
 }
 

@@ -174,6 +174,41 @@ void orc_integral(const uint8_t *src, int w, int h, int stride,
     }
 }
 
+/* The "tilted" (45 degree rotated) integral cv::integral also produces, as published for OpenCV 2.4
+ * (imgproc, "integral"):  tilted(X,Y) = sum over y < Y, abs(x - X + 1) <= Y - y - 1 of image(x,y);
+ * int32, (h+1)*(w+1) dense like sum.  cvHaarDetectObjectsForROC asks for it whenever the cascade has a tilted
+ * feature (haar.cpp: cvIntegral(img, sum, sqsum, tilted)).  Restated from the definition: a row of the triangle
+ * under (X,Y) differs from the row of the triangle under (X,Y-1) by its two end pixels, which lie on the two
+ * diagonals through (X-2,Y-2) and (X,Y-2); dl / dr are the running sums along those diagonals. */
+void orc_integral_tilted(const uint8_t *src, int w, int h, int stride, int32_t *tilted)
+{
+    int W1 = w + 1;
+    int32_t *dl = (int32_t *)calloc((size_t)w * (h > 0 ? h : 1), sizeof(int32_t));   /* dl[y][c] = sum_k src[y-k][c-k] */
+    int32_t *dr = (int32_t *)calloc((size_t)w * (h > 0 ? h : 1), sizeof(int32_t));   /* dr[y][c] = sum_k src[y-k][c+k] */
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = src + (size_t)y * stride;
+        for (int c = 0; c < w; c++) {
+            dl[(size_t)y * w + c] = s[c] + (y > 0 && c > 0 ? dl[(size_t)(y - 1) * w + c - 1] : 0);
+            dr[(size_t)y * w + c] = s[c] + (y > 0 && c + 1 < w ? dr[(size_t)(y - 1) * w + c + 1] : 0);
+        }
+    }
+    for (int X = 0; X < W1; X++) tilted[X] = 0;
+    for (int Y = 1; Y <= h; Y++) {
+        const uint8_t *s = src + (size_t)(Y - 1) * stride;
+        int32_t *trow = tilted + (size_t)Y * W1, *tprev = trow - W1;
+        for (int X = 0; X < W1; X++) {
+            int32_t v = tprev[X];
+            if (X >= 1) v += s[X - 1];                                       /* the apex row: pixel (X-1, Y-1) */
+            if (Y >= 2) {
+                if (X >= 2) v += dl[(size_t)(Y - 2) * w + X - 2];            /* left ends  (X-1-k, Y-1-k), k >= 1 */
+                if (X < w) v += dr[(size_t)(Y - 2) * w + X];                 /* right ends (X-1+k, Y-1-k), k >= 1 */
+            }
+            trow[X] = v;
+        }
+    }
+    free(dl); free(dr);
+}
+
 void orc_flip_h(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
 {
     for (int y = 0; y < h; y++) {
