@@ -78,7 +78,7 @@ __device__ __forceinline__ double stump_vote(const int *__restrict__ sum, unsign
     } else {
         v = (double)((float)s0 * f.w[0]);
         v += (double)((float)s1 * f.w[1]);
-        if (f.nrect == 3) {
+        if ((f.nrect & 255) == 3) {
             const int s2 = rs(2);
             v += (double)((float)s2 * f.w[2]);
         }
@@ -433,7 +433,7 @@ __device__ __forceinline__ double tile_vote(const int *T, const unsigned short *
     } else {
         v = (double)((float)s0 * f.w[0]);
         v += (double)((float)s1 * f.w[1]);
-        if (f.nrect == 3) {
+        if ((f.nrect & 255) == 3) {
             const int s2 = rs(2);
             v += (double)((float)s2 * f.w[2]);
         }
@@ -456,23 +456,41 @@ __device__ __forceinline__ SRec load_srec(const TStumpRec *p)
                  : "=&s"(r.a), "=&s"(r.b) : "s"(p) : "memory");
     return r;
 }
-template <bool PAIR>
-__device__ __forceinline__ double tile_vote_s(const int *T, const unsigned short *cmap, const unsigned short *rmap,
-                                              int xw, int yw, double vnf, const SRec &f)
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+// LDS by absolute byte address (the tile kernels keep map / sample addresses as integers: no generic-pointer base in the way)
+typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
+typedef __attribute__((address_space(3))) const int lds_ci32;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"      // the host pass sees 64-bit pointers; device LDS pointers are 32 bits
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(unsigned long long)(lptr_t)p; }
+__device__ __forceinline__ int lds_u16(unsigned a) { return *(lds_cu16 *)a; }
+// sample at (row start word address r, column byte offset c): one shift-add, one read
+__device__ __forceinline__ int lds_sample(int r, int c)
 {
-    // dwords: x0[3] 0-2 | x1[3] 3-5 | y0[3] 6-8 | y1[3] 9-11 | w[3] 12-14 | nrect 15 || thr 0-1 | a0 2-3 | a1 4-5 | share 6
-    auto at = [&](int rw, int cb) { return *(const int *)((const char *)T + ((rw << 2) + cb)); };
-    // dword b[6]: which pairs a later rectangle shares with rectangle 0 (wave-uniform: scalar branches)
-    const int share = f.b[6];
-    const int ca = cmap[xw + f.a[0]], cb = cmap[xw + f.a[3]];
-    const int ra = rmap[yw + f.a[6]], rb = rmap[yw + f.a[9]];
+    unsigned a;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(r), "v"(c));
+    return *(lds_ci32 *)a;
+}
+#pragma clang diagnostic pop
+// cm / rm: LDS byte addresses of this window's entries in the column / row map (map base + 2 * window offset); the column
+// map holds byte offsets of the compacted columns, the row map absolute word addresses of the staged rows
+// Sum = double: the vote as OpenCV adds it (f64).  Sum = int: the vote as an integer multiple of 2^vote_exp (StageRec flag bit 2).
+template <bool PAIR, class Sum>
+__device__ __forceinline__ Sum tile_vote_s(unsigned cm, unsigned rm, double vnf, const SRec &f)
+{
+    // dwords: x0[3] 0-2 | x1[3] 3-5 | y0[3] 6-8 | y1[3] 9-11 | w[3] 12-14 | nrect + share 15 || thr 0-1 | a0 2-3 | a1 4-5 | a0i 6 | a1i 7
+    // share (bits 8.. of dword 15): which pairs a later rectangle shares with rectangle 0 (wave-uniform: scalar branches)
+    const int share = f.a[15] >> 8;
+    const int ca = lds_u16(cm + 2 * f.a[0]), cb = lds_u16(cm + 2 * f.a[3]);
+    const int ra = lds_u16(rm + 2 * f.a[6]), rb = lds_u16(rm + 2 * f.a[9]);
     auto rs = [&](int x0, int x1, int y0, int y1, int sh) {
         int c0 = ca, c1 = cb, r0 = ra, r1 = rb;
-        if (!(sh & 2)) { c0 = cmap[xw + x0]; c1 = cmap[xw + x1]; }
-        if (!(sh & 1)) { r0 = rmap[yw + y0]; r1 = rmap[yw + y1]; }
-        return at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
+        if (!(sh & 2)) { c0 = lds_u16(cm + 2 * x0); c1 = lds_u16(cm + 2 * x1); }
+        if (!(sh & 1)) { r0 = lds_u16(rm + 2 * y0); r1 = lds_u16(rm + 2 * y1); }
+        return lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
     };
-    const int s0 = at(ra, ca) - at(ra, cb) - at(rb, ca) + at(rb, cb);
+    const int s0 = lds_sample(ra, ca) - lds_sample(ra, cb) - lds_sample(rb, ca) + lds_sample(rb, cb);
     const int s1 = rs(f.a[1], f.a[4], f.a[7], f.a[10], share);
     const double t = __hiloint2double(f.b[1], f.b[0]) * vnf;
     const float w0 = __int_as_float(f.a[12]), w1 = __int_as_float(f.a[13]);
@@ -483,27 +501,38 @@ __device__ __forceinline__ double tile_vote_s(const int *T, const unsigned short
     } else {
         v = (double)((float)s0 * w0);
         v += (double)((float)s1 * w1);
-        if (f.a[15] == 3) {
+        if ((f.a[15] & 255) == 3) {
             const int s2 = rs(f.a[2], f.a[5], f.a[8], f.a[11], share >> 2);
             v += (double)((float)s2 * __int_as_float(f.a[14]));
         }
     }
+    if (sizeof(Sum) == sizeof(int)) return (Sum)(v >= t ? f.b[7] : f.b[6]);
     const double a0 = __hiloint2double(f.b[3], f.b[2]), a1 = __hiloint2double(f.b[5], f.b[4]);
-    return v >= t ? a1 : a0;
+    return (Sum)(v >= t ? a1 : a0);
 }
 // one stage's sum over stumps j0, j0 + step, ... < count for one window, records wave-uniform
-template <bool PAIR>
-__device__ __forceinline__ double tile_stage_sum(const int *T, const unsigned short *cmap, const unsigned short *rmap, int xw, int yw,
-                                                 double vnf, const TStumpRec *recs, int j0, int count, int step)
+template <bool PAIR, class Sum = double>
+__device__ __forceinline__ Sum tile_stage_sum(unsigned cm, unsigned rm, double vnf, const TStumpRec *recs, int j0, int count, int step)
 {
     // the table pointer is wave-uniform but comes out of a vector load: hand the asm a scalar copy
     const unsigned long long u = (unsigned long long)recs;
     const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)u);
     const TStumpRec *base = (const TStumpRec *)ub;
-    double sum = 0.0;
-    for (int j = j0; j < count; j += step) sum += tile_vote_s<PAIR>(T, cmap, rmap, xw, yw, vnf, load_srec(base + j));
+    asm("" : "+v"(cm), "+v"(rm));        // keep the two per-window addresses whole: a look-up address is then one shift-add of a scalar
+    Sum sum = 0;
+    for (int j = j0; j < count; j += step) sum += tile_vote_s<PAIR, Sum>(cm, rm, vnf, load_srec(base + j));
     return sum;
+}
+// does a window pass the stage?  (all of the stage's stumps on this thread)
+__device__ __forceinline__ bool tile_stage_pass(unsigned cm, unsigned rm, double vnf, const TStumpRec *recs, const StageRec &st, bool pair)
+{
+    if (st.flags & 4) {
+        const int sum = pair ? tile_stage_sum<true, int>(cm, rm, vnf, recs + st.first, 0, st.count, 1) : tile_stage_sum<false, int>(cm, rm, vnf, recs + st.first, 0, st.count, 1);
+        return sum >= st.thr_i;
+    }
+    const double sum = pair ? tile_stage_sum<true>(cm, rm, vnf, recs + st.first, 0, st.count, 1) : tile_stage_sum<false>(cm, rm, vnf, recs + st.first, 0, st.count, 1);
+    return !(sum < (double)st.thr);
 }
 
 #ifdef NVCA_STAMPS
@@ -518,7 +547,8 @@ __device__ __forceinline__ double tile_stage_sum(const int *T, const unsigned sh
 struct TileLds {
     double *psum; unsigned short *q0, *winx, *winy; int *qn; double *vnf_s; unsigned *rej; int *carry;
     unsigned short *cmap, *rmap; int *T; int pitchT;
-    const int *Tb; int toff;      // what the vote functions index: the start of the LDS region, and T's word offset in it (folded into rmap)
+    int tword;                    // absolute LDS word address of T: the row map holds tword + r * pitchT
+    unsigned cmA, rmA;            // LDS byte addresses of the maps
 };
 __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec &t)
 {
@@ -534,7 +564,8 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
     L.rmap = L.cmap + ((t.span_x + 3) & ~3);
     L.T = (int *)(L.rmap + ((t.span_y + 3) & ~3));
     L.pitchT = tile_pitch(t.ncol);
-    L.Tb = (const int *)lds; L.toff = (int)(L.T - (const int *)lds);      // the whole region is < 2^16 words (tile_lds_bytes <= 80 KiB)
+    L.tword = (int)(lds_addr(L.T) >> 2);          // < 2^16: the whole of LDS is 160 KiB = 40 Ki words
+    L.cmA = lds_addr(L.cmap); L.rmA = lds_addr(L.rmap);
     return L;
 }
 
@@ -545,8 +576,6 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
 // destination is 64 consecutive words of the row, no registers in between).  A wave takes rows wave, wave + 16, ...; every
 // transfer of the tile is in flight before the first one is waited for (register staging kept two rows per wave in
 // flight: the copy was a chain of dependent round trips).  The caller waits: s_waitcnt vmcnt(0) + barrier before T is read.
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 struct TileCoords { int mapc, mapr, wx, wy; unsigned rowb, xcb[4]; };
 __device__ __forceinline__ TileCoords tile_coords(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc)
 {
@@ -584,7 +613,7 @@ __device__ __forceinline__ void tile_commit(const CascadeArgs &a, const TileRec 
     if (tid < t.nx) L.winx[tid] = (unsigned short)(c.wx - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(c.wy - t.y0);
     if (c.mapc >= 0) L.cmap[c.mapc - t.x0] = (unsigned short)(tid * 4);
-    if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(L.toff + tid * L.pitchT);     // row start as a word offset from the region start: a corner address is one shift-add
+    if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(L.tword + tid * L.pitchT);     // absolute word address of the row: a corner address is one shift-add
 }
 
 __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
@@ -607,7 +636,6 @@ template <bool VNF_LDS>
 __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0)
 {
     const int tid = threadIdx.x;
-    CTStumpRec *recs = (CTStumpRec *)sc.trecs;
     const TStumpRec *urecs = sc.trecs;
     const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
     const double *__restrict__ vnfp = a.vnf + vbase;
@@ -643,28 +671,38 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
             if (P > st.count) P = st.count;
             if (P > 16) P = 16;              // the partial sums of a window are added up by one thread
             const int p = __builtin_amdgcn_readfirstlane((tid >> 6) / nw), i = tid - p * npad;
-            double part = 0.0;
+            const bool ivote = (st.flags & 4) != 0;          // integer votes: the partial sums travel as 32-bit integers
+            double part = 0.0; int parti = 0;
             if (i < n && p < P) {
                 const int w = qi[i];
                 const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
                 const double vnf = vnf_of(w);
-                part = pair ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, p, st.count, P)
-                            : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, p, st.count, P);
+                const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
+                if (ivote) parti = pair ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + st.first, p, st.count, P) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + st.first, p, st.count, P);
+                else part = pair ? tile_stage_sum<true>(cm, rm, vnf, urecs + st.first, p, st.count, P) : tile_stage_sum<false>(cm, rm, vnf, urecs + st.first, p, st.count, P);
             }
             NVCA_STAMP(a, ti, 8 + 8 * s + 1);
-            L.psum[tid] = part;
+            int *psi = (int *)L.psum;
+            if (ivote) psi[tid] = parti; else L.psum[tid] = part;
             __syncthreads();
             NVCA_STAMP(a, ti, 8 + 8 * s + 2);
             bool pass = false; int w = 0;
             if (tid < n) {
-                double tot = 0.0;
-                int pp = 0;
-                for (; pp + 4 <= P; pp += 4) {       // four independent reads in flight; any order of the adds is exact here
-                    const double d0 = L.psum[pp * npad + tid], d1 = L.psum[(pp + 1) * npad + tid], d2 = L.psum[(pp + 2) * npad + tid], d3 = L.psum[(pp + 3) * npad + tid];
-                    tot += d0; tot += d1; tot += d2; tot += d3;
+                if (ivote) {
+                    int tot = 0, pp = 0;
+                    for (; pp + 4 <= P; pp += 4) tot += psi[pp * npad + tid] + psi[(pp + 1) * npad + tid] + psi[(pp + 2) * npad + tid] + psi[(pp + 3) * npad + tid];
+                    for (; pp < P; pp++) tot += psi[pp * npad + tid];
+                    pass = tot >= st.thr_i;
+                } else {
+                    double tot = 0.0;
+                    int pp = 0;
+                    for (; pp + 4 <= P; pp += 4) {       // four independent reads in flight; any order of the adds is exact here
+                        const double d0 = L.psum[pp * npad + tid], d1 = L.psum[(pp + 1) * npad + tid], d2 = L.psum[(pp + 2) * npad + tid], d3 = L.psum[(pp + 3) * npad + tid];
+                        tot += d0; tot += d1; tot += d2; tot += d3;
+                    }
+                    for (; pp < P; pp++) tot += L.psum[pp * npad + tid];
+                    pass = !(tot < (double)st.thr);
                 }
-                for (; pp < P; pp++) tot += L.psum[pp * npad + tid];
-                pass = !(tot < (double)st.thr);
                 w = qi[tid];
             }
             queue_push(pass, w, qo, &L.qn[cout]);
@@ -677,9 +715,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 w = qi[i];
                 const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
                 const double vnf = vnf_of(w);
-                const double stage_sum = pair ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1)
-                                              : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, urecs + st.first, 0, st.count, 1);
-                pass = !(stage_sum < (double)st.thr);
+                pass = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, urecs, st, pair);
             }
             queue_push(pass, w, qo, &L.qn[cout]);
         }
@@ -798,8 +834,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             bool pass0 = false;
             if (active) {
                 const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
-                auto at = [&](int rw, int cb) { return *(const int *)((const char *)L.Tb + ((rw << 2) + cb)); };
-                const int ws = at(r0, c0) - at(r0, c1) - at(r1, c0) + at(r1, c1);
+                const int ws = lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
                 const double mean = (double)ws * sc.inv_area;
                 // squared-pixel sum of the variance window: exact integers below 2^53 (see window_sqsum)
                 double vnf;
@@ -809,9 +844,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
                 vnf = vnf * sc.inv_area - mean * mean;
                 vnf = vnf >= 0. ? sqrt(vnf) : 1.;
                 L.vnf_s[w] = vnf;
-                const double stage_sum = pair0 ? tile_stage_sum<true>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1)
-                                               : tile_stage_sum<false>(L.Tb, L.cmap, L.rmap, xw, yw, vnf, sc.trecs + st0.first, 0, st0.count, 1);
-                pass0 = !(stage_sum < (double)st0.thr);
+                pass0 = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, sc.trecs, st0, pair0);
             }
             const unsigned long long fb = __ballot(active && !pass0);
             if (lane == 0 && ry < t.ny) L.rej[ry] = (unsigned)fb;

@@ -45,7 +45,13 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
 // --------------------------------------------------------------------------
 struct StageRec {
     int first, count; float thr;
-    int flags;              // bit 0: two_rects (every stump has 2 rects); bit 1: votes may be summed in any order
+    int flags;              // bit 0: two_rects (every stump has 2 rects); bit 1: votes may be summed in any order;
+                            // bit 2: every vote is an integer multiple of 2^vote_exp and the stage's sums stay below 2^31 of them:
+                            // the tile kernels add the integer votes (TStumpRec::a0i / a1i) and compare with thr_i -- bit for bit
+                            // the f64 sum OpenCV forms, whatever the order
+    int thr_i;              // pass  <=>  integer sum >= thr_i   (== !(sum * 2^vote_exp < (double)thr))
+    int vote_exp;
+    int pad0, pad1;
 };
 
 struct ScaleRec {           // one evaluated scale
@@ -81,10 +87,12 @@ struct TileRec {
 };
 struct TStumpRec {          // a stump with separate corner columns / rows (window-relative pixels)
     int x0[3], x1[3], y0[3], y1[3];
-    float w[3]; int nrect;
+    float w[3];
+    int nrect;              // low byte: rectangles (2 or 3); bits 8..11 "share": bit 8 / 9: rectangle 1 has rectangle 0's rows /
+                            // columns; bit 10 / 11: rectangle 2 likewise
     double thr, a0, a1;
-    int share;              // bit 0 / 1: rectangle 1 has rectangle 0's rows / columns; bit 2 / 3: rectangle 2 likewise
-    int pad;                // 96 bytes: the tile kernels fetch a record with two wide scalar loads (16 + 8 dwords)
+    int a0i, a1i;           // the votes as integers (a / 2^vote_exp of the stump's stage) where StageRec flag bit 2 is set
+                            // 96 bytes: the tile kernels fetch a record with two wide scalar loads (16 + 8 dwords)
 };
 static_assert(sizeof(TStumpRec) == 96, "TStumpRec layout is read dword by dword in kernels_cascade.hip");
 // A band is one row of tiles (<= 32 window rows of one scale, the full scan width): k_band walks it left to right in one

@@ -110,8 +110,18 @@ void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
         // an x2 / x3 feature's rectangles span the same rows, a y2 / y3 feature's the same columns (same y and height, or
         // same x and width, go through the same rounding): the tile kernels look the shared pair up once
         for (int q = 1; q < n.nrect; q++) {
-            if (r.y0[q] == r.y0[0] && r.y1[q] == r.y1[0]) r.share |= 1 << (2 * (q - 1));
-            if (r.x0[q] == r.x0[0] && r.x1[q] == r.x1[0]) r.share |= 2 << (2 * (q - 1));
+            if (r.y0[q] == r.y0[0] && r.y1[q] == r.y1[0]) r.nrect |= 256 << (2 * (q - 1));
+            if (r.x0[q] == r.x0[0] && r.x1[q] == r.x1[0]) r.nrect |= 512 << (2 * (q - 1));
+        }
+    }
+    // integer votes of the stages whose sums are provably exact as 32-bit integers (StageRec flag bit 2)
+    std::vector<StageRec> st;
+    build_stage_recs(c, st);
+    for (const StageRec &sr : st) {
+        if (!(sr.flags & 4)) continue;
+        for (int j = 0; j < sr.count; j++) {
+            TStumpRec &r = t.host[sr.first + j];
+            r.a0i = (int)std::ldexp(r.a0, -sr.vote_exp); r.a1i = (int)std::ldexp(r.a1, -sr.vote_exp);
         }
     }
 }
@@ -147,6 +157,13 @@ void build_stage_recs(const Cascade &c, std::vector<StageRec> &out)
         }
         bool order_free = finite && (emin == INT_MAX || (bound == 0) || std::ilogb(bound) + 1 <= emin + 52);
         r.flags = (two_rects ? 1 : 0) | (order_free ? 2 : 0);
+        // integer votes: every vote an exact multiple of 2^emin, the sum of their magnitudes (hence every partial sum of every
+        // subset) below 2^31 multiples, and the threshold comparable as an integer:  !(S * 2^e < T)  <=>  S >= ceil(T / 2^e)
+        r.thr_i = 0; r.vote_exp = 0; r.pad0 = r.pad1 = 0;
+        if (finite && emin != INT_MAX && emin != INT_MIN && emin > -1000 && emin < 1000 && std::ldexp(bound, -emin) < 2147483000.0) {
+            const double tq = std::ceil(std::ldexp((double)r.thr, -emin));
+            if (std::isfinite(tq) && std::fabs(tq) < 2147483000.0) { r.flags |= 4 | 2; r.thr_i = (int)tq; r.vote_exp = emin; }
+        }
         out.push_back(r);
     }
 }
