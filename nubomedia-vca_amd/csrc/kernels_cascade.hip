@@ -1133,14 +1133,22 @@ void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, in
     NVCA_LAUNCH(k_group, dim3(batch), dim3(256), 0, st, a, group_thr, out, out_cap);
 }
 
-// dynamic LDS above 64 KiB has to be granted per function and device; the record of what has been granted lives in the
-// calling context (entry points hold that context's lock), so two contexts never share a word here
-static int grant_lds(const void *fn, int bytes, int *granted)
+// Dynamic LDS above 64 KiB has to be granted per function and device (hipFuncSetAttribute SETS the limit, it does not raise
+// it): the limit only ever grows, under one process-wide lock, so a context that needs less can never lower what another
+// context on the same device was granted.  `granted` is the calling context's own record (skips the lock once it is covered).
+static int grant_lds(const void *fn, int which, int bytes, int *granted)
 {
     if (bytes <= *granted) return 0;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
-    *granted = bytes;
+    static std::mutex mu;
+    static int dev_max[2][64] = {{0}};
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+    if (bytes > dev_max[which][dev]) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        dev_max[which][dev] = bytes;
+    }
+    *granted = dev_max[which][dev];
     return 0;
 }
 
@@ -1163,12 +1171,12 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
             NVCA_LAUNCH(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
         if (a.tile_blocks_per_frame > 0) {
-            if (int e = grant_lds(reinterpret_cast<const void *>(k_tile), a.tile_lds, &lds_grant[0])) return e;
+            if (int e = grant_lds(reinterpret_cast<const void *>(k_tile), 0, a.tile_lds, &lds_grant[0])) return e;
             NVCA_LAUNCH(k_tile, dim3((unsigned)a.tile_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 5) {
         if (a.band_blocks_per_frame > 0) {
-            if (int e = grant_lds(reinterpret_cast<const void *>(k_band), a.tile_lds, &lds_grant[1])) return e;
+            if (int e = grant_lds(reinterpret_cast<const void *>(k_band), 1, a.tile_lds, &lds_grant[1])) return e;
             NVCA_LAUNCH(k_band, dim3((unsigned)a.band_blocks_per_frame * (unsigned)batch), dim3(kTileThreads), (size_t)a.tile_lds, st, a);
         }
     } else if (which == 1) {
