@@ -162,25 +162,112 @@ def _f(v):
 
 
 def cascade_to_xml(casc):
-    """Old-format OpenCV Haar cascade XML (type_id opencv-haar-classifier)."""
+    """Old-format OpenCV Haar cascade XML (type_id opencv-haar-classifier).
+
+    A stage is either the stump form {features, thresholds, left, right, stage_threshold [, tilted]} (one root node per
+    weak classifier; `tilted`: per-feature 0/1) or the general form {trees, stage_threshold}: `trees` is a list of weak
+    classifiers, each a list of nodes {feature, tilted, threshold, left, right} whose left / right is ("val", v) for a
+    leaf or ("node", i) for the index of a later node of the same tree (icvReadHaarClassifier's <left_node>)."""
     L = ['<?xml version="1.0"?>', "<opencv_storage>",
          '<%s type_id="opencv-haar-classifier">' % casc["name"],
          "  <size>%d %d</size>" % casc["size"], "  <stages>"]
     for si, st in enumerate(casc["stages"]):
+        if "trees" in st:
+            trees = st["trees"]
+        else:
+            tl = st.get("tilted", [0] * len(st["features"]))
+            trees = [[dict(feature=f, tilted=tl[j], threshold=st["thresholds"][j], left=("val", st["left"][j]),
+                           right=("val", st["right"][j]))] for j, f in enumerate(st["features"])]
         L += ["    <_>", "      <!-- stage %d -->" % si, "      <trees>"]
-        for j, feat in enumerate(st["features"]):
-            L += ["        <_>", "          <!-- tree %d -->" % j, "          <_>",
-                  "            <!-- root node -->", "            <feature>", "              <rects>"]
-            for (x, y, w, h, wt) in feat:
-                L.append("                <_>%d %d %d %d %d.</_>" % (x, y, w, h, int(wt)))
-            L += ["              </rects>", "              <tilted>0</tilted></feature>",
-                  "            <threshold>%s</threshold>" % _f(st["thresholds"][j]),
-                  "            <left_val>%s</left_val>" % _f(st["left"][j]),
-                  "            <right_val>%s</right_val></_></_>" % _f(st["right"][j])]
+        for j, tree in enumerate(trees):
+            L += ["        <_>", "          <!-- tree %d -->" % j]
+            for k, nd in enumerate(tree):
+                L += ["          <_>", "            <!-- %s -->" % ("root node" if k == 0 else "node %d" % k), "            <feature>", "              <rects>"]
+                for (x, y, w, h, wt) in nd["feature"]:
+                    L.append("                <_>%d %d %d %d %d.</_>" % (x, y, w, h, int(wt)))
+                L += ["              </rects>", "              <tilted>%d</tilted></feature>" % int(nd.get("tilted", 0)),
+                      "            <threshold>%s</threshold>" % _f(nd["threshold"])]
+                for side in ("left", "right"):
+                    kind, v = nd[side]
+                    L.append("            <%s_%s>%s</%s_%s>" % (side, kind, _f(v) if kind == "val" else "%d" % v, side, kind))
+                L[-1] += "</_>"
+            L[-1] += "</_>"
         L += ["      </trees>", "      <stage_threshold>%s</stage_threshold>" % _f(st["stage_threshold"]),
               "      <parent>%d</parent>" % (si - 1), "      <next>-1</next></_>"]
     L += ["  </stages></%s>" % casc["name"], "</opencv_storage>", ""]
     return "\n".join(L)
+
+
+def _rand_tilted_feature(rng, ow, oh):
+    """A tilted (45 degree) two-rectangle feature inside the window: rect (x, y, w, h) tilted covers columns x-h .. x+w and
+    rows y .. y+w+h (OpenCV's convention: w along the down-right diagonal, h along the down-left one)."""
+    for _ in range(200):
+        w, h = int(rng.randint(1, max(2, ow // 3))) * 2, int(rng.randint(1, max(2, oh // 3)))
+        x, y = int(rng.randint(0, ow)), int(rng.randint(0, oh))
+        if x - h < 1 or x + w > ow - 1 or y < 1 or y + w + h > oh - 1:
+            continue
+        if rng.rand() < 0.5:       # halves along w
+            return [(x, y, w, h, -1.0), (x, y, w // 2, h, 2.0)]
+        if h % 2 == 0:             # halves along h
+            return [(x, y, w, h, -1.0), (x, y, w, h // 2, 2.0)]
+    raise RuntimeError("tilted feature sampling failed")
+
+
+def _rand_upright_feature(rng, ow, oh):
+    while True:
+        w, h = int(rng.randint(2, ow + 1)), int(rng.randint(2, oh + 1))
+        x, y = int(rng.randint(0, ow - w + 1)), int(rng.randint(0, oh - h + 1))
+        kind = int(rng.randint(0, 4))
+        if kind == 0 and w % 2 == 0:
+            return [(x, y, w, h, -1.0), (x + w // 2, y, w // 2, h, 2.0)]
+        if kind == 1 and h % 2 == 0:
+            return [(x, y, w, h, -1.0), (x, y + h // 2, w, h // 2, 2.0)]
+        if kind == 2 and w % 3 == 0:
+            return [(x, y, w, h, -1.0), (x + w // 3, y, w // 3, h, 3.0)]
+        if kind == 3 and w % 2 == 0 and h % 2 == 0:
+            return [(x, y, w, h, -1.0), (x, y, w // 2, h // 2, 2.0), (x + w // 2, y + h // 2, w // 2, h // 2, 2.0)]
+
+
+def make_generic_cascade(ow=20, oh=20, seed=1, stage_sizes=(3, 8, 12, 16, 20, 24, 28), tilt_frac=0.25, tree_frac=0.35, max_nodes=3):
+    """A lenient cascade that exercises what haarcascade_profileface / the mcs_* files may contain:
+    tilted features and tree-structured weak classifiers (up to `max_nodes` nodes, children always later nodes).  Votes are
+    symmetric around zero and thresholds near zero, so about half of all windows pass each stage on any image and a handful
+    survive every stage.  A workload / parity generator, not a detector."""
+    rng = np.random.RandomState(seed)
+    stages = []
+    for n in stage_sizes:
+        trees = []
+        for _ in range(n):
+            nn = int(rng.randint(2, max_nodes + 1)) if rng.rand() < tree_frac else 1
+            nodes = []
+            for k in range(nn):
+                tilted = 1 if rng.rand() < tilt_frac else 0
+                feat = _rand_tilted_feature(rng, ow, oh) if tilted else _rand_upright_feature(rng, ow, oh)
+                a = float(rng.uniform(0.3, 1.0))
+
+                def child(later):
+                    if later and rng.rand() < 0.7:
+                        return ("node", later.pop(0))
+                    return ("val", a if rng.rand() < 0.5 else -a)
+                later = list(range(k + 1, nn))
+                # every later node must be reachable: node k points at k+1 on one side when there is one
+                if later:
+                    nxt = later.pop(0)
+                    sides = [("node", nxt), child(later)]
+                    if rng.rand() < 0.5:
+                        sides.reverse()
+                else:
+                    v = a if rng.rand() < 0.5 else -a
+                    sides = [("val", v), ("val", -v)]
+                nodes.append(dict(feature=feat, tilted=tilted, threshold=float(rng.normal(0, 0.02)), left=sides[0], right=sides[1]))
+            # node indices must refer to existing later nodes only; unreachable extras are legal but pointless: trim to the chain
+            trees.append(nodes)
+        stages.append(dict(trees=trees, stage_threshold=float(rng.uniform(-0.3, 0.1))))
+    return dict(name="generic_%dx%d" % (ow, oh), size=(ow, oh), stages=stages)
+
+
+def generic_cascade_xml(**kw):
+    return cascade_to_xml(make_generic_cascade(**kw))
 
 
 def synthetic_cascade_xml(seed=2016, stages=None):

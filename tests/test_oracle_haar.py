@@ -133,3 +133,73 @@ def test_scale_image_raw_grid_hand_checked():
     # f=1: sz 20x16, y in [0,4) step 2, x in [0,8) step 2 -> 2*4 = 8 hits of 12x12
     # f=1.5: win 18, sz = (round(13.33), round(10.67)) = 13x11 -> sz1 = 2x0 -> break
     assert len(raw) == 8 and set(raw[:, 2]) == {12}
+
+
+# ------------------------------------------------------------------ tilted features and tree weak classifiers
+def _tilted_rect_sum(img, x, y, w, h):
+    """pixel sum of OpenCV's tilted rectangle from the definition of the tilted integral (independent of orc_haar.c)"""
+    T = orc.integral_tilted(img).astype(np.int64)
+    return int(T[y, x] - T[y + h, x - h] - T[y + w, x + w] + T[y + w + h, x + w - h])
+
+
+def test_tilted_stump_hand_computed():
+    """12x12 window, one tilted stump: rect0 = (6,1,4,2) tilted weight -1, rect1 = (6,1,2,2) tilted weight 2.
+    equRect (1,1,10,10), inv_area 1/100, tilted correction 0.5: w1 = 2 * 0.005 = .01, w0 = -(w1 * 2*2) / (4*2) = -.005
+    (areas as cvSetImages computes them: width*height of the unrotated rect).  On an image that is 0 except a 200-valued
+    block covering rect1's pixels the feature is s0*w0 + s1*w1 with s0 = s1 = (pixels of rect1) * 200."""
+    img = np.zeros((23, 23), np.uint8)
+    # rect1 (6,1,2,2) tilted covers 8 pixels; paint them through the one-hot probe so the test does not re-derive geometry
+    pix = []
+    for py in range(12):
+        for px in range(12):
+            probe = np.zeros((23, 23), np.uint8); probe[py, px] = 1
+            if _tilted_rect_sum(probe, 6, 1, 2, 2):
+                pix.append((py, px))
+    assert len(pix) == 8
+    for (py, px) in pix:
+        img[py, px] = 200
+    s1 = _tilted_rect_sum(img, 6, 1, 2, 2); s0 = _tilted_rect_sum(img, 6, 1, 4, 2)
+    assert s1 == 1600 and s0 == 1600                      # rect1's pixels are inside rect0
+    feat = np.float32(s0) * np.float32(-0.005) + np.float32(s1) * np.float32(0.01)       # = 8
+    inner = img[1:11, 1:11].astype(np.float64)
+    std = np.sqrt((inner ** 2).sum() / 100 - (inner.sum() / 100) ** 2)
+    val = float(feat) / std
+    tilted_stage = lambda thr: dict(name="t", size=(12, 12), stages=[dict(
+        features=[[(6, 1, 4, 2, -1.0), (6, 1, 2, 2, 2.0)]], tilted=[1], thresholds=[thr], left=[-1.0], right=[1.0], stage_threshold=0.5)])
+    for thr, expect in ((val - 0.01, True), (val + 0.01, False)):
+        c = orc.parse_cascade_xml(synth.cascade_to_xml(tilted_stage(thr)))
+        assert int(c.tilted.sum()) == 1
+        raw = orc.detect_raw(c, img, 1.1, 0)
+        assert ([0, 0, 12, 12] in raw.tolist()) == expect, (thr, val, raw)
+
+
+def test_two_node_tree_hand_computed():
+    """one weak classifier with two nodes on the image of test_single_stump_hand_computed (x2 edge feature, normalised value
+    .32 at window (0,0)): root sends value < t0 to the leaf -1 and value >= t0 to node 1; node 1 (same feature) votes -1
+    below t1 and +1 from t1 on.  The window passes the stage (threshold .5) iff value >= t0 and value >= t1."""
+    img = np.zeros((23, 23), np.uint8)
+    img[:, 6:] = 200
+    feat = [(2, 2, 8, 4, -1.0), (6, 2, 4, 4, 2.0)]
+
+    def casc(t0, t1):
+        tree = [dict(feature=feat, tilted=0, threshold=t0, left=("val", -1.0), right=("node", 1)),
+                dict(feature=feat, tilted=0, threshold=t1, left=("val", -1.0), right=("val", 1.0))]
+        return orc.parse_cascade_xml(synth.cascade_to_xml(dict(name="t", size=(12, 12), stages=[dict(trees=[tree], stage_threshold=0.5)])))
+    for t0, t1, expect in ((0.31, 0.31, True), (0.33, 0.31, False), (0.31, 0.33, False), (0.1, 0.2, True)):
+        c = casc(t0, t1)
+        assert c.cls_nnodes.tolist() == [2] and c.left.tolist() == [0, -1] and c.right.tolist() == [1, -2]
+        raw = orc.detect_raw(c, img, 1.1, 0)
+        assert ([0, 0, 12, 12] in raw.tolist()) == expect, (t0, t1, raw)
+
+
+def test_generic_cascade_all_scan_variants_run():
+    """tilted + tree cascade (synth.make_generic_cascade) through the three detectMultiScale variants; the tree walk and the
+    tilted plane are exercised on thousands of windows, and SCALE_IMAGE (tilted integral per pyramid level) agrees with the
+    scale-cascade scan on where the strongest cluster is"""
+    oc = orc.parse_cascade_xml(synth.generic_cascade_xml(seed=3))
+    assert int(oc.tilted.sum()) > 10 and int((oc.cls_nnodes > 1).sum()) > 10
+    img = orc.equalize_hist(synth.make_gray(200, 150, 5, "natural"))
+    raw, st = orc.detect_raw(oc, img, 1.2, 0, return_stats=True)
+    assert len(raw) > 5 and st.stumps > 10 * st.windows
+    assert len(orc.detect_raw(oc, img, 1.2, orc.HAAR_SCALE_IMAGE)) > 5
+    assert len(orc.detect_multiscale(oc, img, 1.2, 2, orc.HAAR_FIND_BIGGEST_OBJECT, (1, 1))) == 1

@@ -2,6 +2,7 @@
 (SURVEY.md 8c / Appendix A.1-A.4).  The reference holds no fixtures for this
 path, so these hand-derived cases are the only anchors ("parity unpinned")."""
 import numpy as np
+import pytest
 import orc
 
 
@@ -124,3 +125,40 @@ def test_resize_constant_rows_stay_constant():
     for (sw, sh, dw, dh) in [(97, 61, 41, 29), (640, 480, 213, 160), (33, 17, 100, 50)]:
         img = np.full((sh, sw), 173, np.uint8)
         assert np.all(orc.resize_linear(img, dw, dh) == 173)
+
+
+# ------------------------------------------------------------------ tilted integral (cv::integral's third output)
+def _tilted_by_definition(img):
+    """tilted(X,Y) = sum of image(x,y) over y < Y, abs(x - X + 1) <= Y - y - 1  (OpenCV 2.4 imgproc documentation)"""
+    h, w = img.shape
+    T = np.zeros((h + 1, w + 1), np.int64)
+    for Y in range(h + 1):
+        for X in range(w + 1):
+            for y in range(Y):
+                lo, hi = max(0, X - 1 - (Y - y - 1)), min(w - 1, X - 1 + (Y - y - 1))
+                if hi >= lo:
+                    T[Y, X] += int(img[y, lo:hi + 1].sum())
+    return T.astype(np.int32)
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 6), (6, 1), (2, 2), (7, 5), (6, 11), (13, 13), (3, 20), (20, 3)])
+def test_tilted_integral_matches_the_published_definition(h, w):
+    img = np.random.default_rng(h * 31 + w).integers(0, 256, size=(h, w)).astype(np.uint8)
+    assert np.array_equal(orc.integral_tilted(img), _tilted_by_definition(img))
+
+
+def test_tilted_integral_known_answers():
+    # first row and the apex rule: tilted(X, 1) = image(X-1, 0); tilted(X, 2) adds the three pixels above the apex
+    img = np.arange(1, 13, dtype=np.uint8).reshape(3, 4)          # rows [1 2 3 4], [5 6 7 8], [9 10 11 12]
+    T = orc.integral_tilted(img)
+    assert T[0].tolist() == [0, 0, 0, 0, 0]
+    assert T[1].tolist() == [0, 1, 2, 3, 4]
+    assert T[2].tolist() == [1, 5 + 1 + 2, 6 + 1 + 2 + 3, 7 + 2 + 3 + 4, 8 + 3 + 4]      # column 0: only pixel (0,0) lies under apex (-1,1)
+    # a tilted rectangle (x, y, w, h) covers exactly 2*w*h pixels: on a constant image its four-corner sum is 2*w*h*v
+    flat = np.full((40, 40), 7, np.uint8)
+    T = orc.integral_tilted(flat).astype(np.int64)
+    for (x, y, w, h) in [(10, 3, 4, 3), (12, 2, 6, 2), (20, 5, 2, 7)]:
+        assert T[y, x] - T[y + h, x - h] - T[y + w, x + w] + T[y + w + h, x + w - h] == 2 * w * h * 7
+    # whole image under a far apex: the last row's widest triangle
+    ones = np.ones((5, 9), np.uint8)
+    assert orc.integral_tilted(ones)[5, 5] == 1 + 3 + 5 + 7 + 9
