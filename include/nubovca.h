@@ -30,7 +30,8 @@ extern "C" {
 #define NVCA_ERR_HIP        -3   /* a HIP runtime call failed (see nvca_last_error)*/
 #define NVCA_ERR_IO         -4   /* cascade file unreadable                        */
 #define NVCA_ERR_PARSE      -5   /* cascade XML malformed                          */
-#define NVCA_ERR_UNSUPPORTED -6  /* tilted / tree-structured cascade               */
+#define NVCA_ERR_UNSUPPORTED -6  /* tree-structured STAGE graph (parent / next), or a
+                                    feature that leaves the image at some scale    */
 #define NVCA_ERR_OVERFLOW   -7   /* more raw candidates than the context's cap     */
 #define NVCA_ERR_NOMEM      -8
 
@@ -112,12 +113,15 @@ const char *nvca_kernel_name(int k);
 /* ---- cascade: replaces cv::CascadeClassifier::load ---------------------
  * FACE/kmsfacedetect.cpp:162-177 (HAAR_CONF_FILE :40), EYE/kmseyedetect.cpp:27-29,
  * NOSE/kmsnosedetect.cpp:31-32, MOUTH/kmsmouthdetect.cpp:37-38, EAR/kmseardetect.cpp:29-31.
- * Old-format ("opencv-haar-classifier") XML only. */
+ * Old-format ("opencv-haar-classifier") XML only: stump or tree-structured weak classifiers, upright or tilted
+ * features (cascades with trees / tilted features run through the general evaluator). */
 int  nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out);
 int  nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out);
 void nvca_cascade_free(nvca_cascade *c);
 /* window size, stage count, weak-classifier count (any pointer may be NULL) */
 int  nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stages, int *n_weak);
+/* has_tilted / has_trees (either pointer may be NULL): what kind of cascade the loader found */
+int  nvca_cascade_kind(const nvca_cascade *c, int *has_tilted, int *has_trees);
 /* flat dump for cross-checking the loader: arrays sized by nvca_cascade_info;
  * rects[n_weak*12] (3 rects x,y,w,h), weights[n_weak*3], thr/left_val/right_val[n_weak],
  * stage_sizes/stage_thr[n_stages] (stump cascades only) */
@@ -141,6 +145,11 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src_gray, int w, int h, int 
  * both dense (h+1)*(w+1) */
 int nvca_integral(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
                   int32_t *sum, double *sqsum);
+
+/* the third plane of cv::integral, which cvHaarDetectObjectsForROC asks for when the cascade holds tilted features
+ * (haarcascade_profileface.xml, EAR/kmseardetect.cpp:29): tilted(X,Y) = sum of image(x,y) over y < Y,
+ * abs(x - X + 1) <= Y - y - 1; int32, dense (h+1)*(w+1) */
+int nvca_integral_tilted(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem, int32_t *tilted);
 
 /* ---- detectMultiScale ---------------------------------------------------
  * cv::CascadeClassifier::detectMultiScale(gray, objects, scaleFactor, minNeighbors,

@@ -108,14 +108,14 @@ struct ResultBufs {
     void release() { hits.release(); grp.release(); gthr.release(); staging.release(); srcptrs.release(); h_hits.release(); h_grp.release(); h_gthr.release(); h_srcptrs.release(); gthr_last.clear(); }
 };
 struct Workspace {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, tilted, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
     ResultBufs res[3];
     int cur_res = 0;
     int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
-        sqsum.release(); staging.release(); aux.release();
+        sqsum.release(); tilted.release(); staging.release(); aux.release();
         failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
         for (ResultBufs &r : res) r.release();
     }
@@ -229,7 +229,7 @@ static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
     e |= ws.lut.ensure((size_t)batch * 256);
     e |= ws.bandsum.ensure(g.band_slot * batch * sizeof(unsigned));
     e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
-    e |= ws.sum.ensure(g.sum_slot * batch * sizeof(int));
+    e |= ws.sum.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int));      // a few spare rows: a scaled feature corner may round past the window by a pixel or two
     e |= ws.sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
     e |= ws.res[ws.cur_res].srcptrs.ensure((size_t)batch * sizeof(void *));
     e |= ws.res[ws.cur_res].h_srcptrs.ensure((size_t)batch * sizeof(void *));
@@ -289,6 +289,21 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
       launch_bandscan(ctx->stream, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
       launch_integral(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), sum, sq, batch); }
+}
+
+// tilted integral planes for `batch` slots (cascades with tilted features only); same geometry and equalisation LUT as run_integral
+static int run_tilted(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int batch, const uint8_t *gray = nullptr, int *tilted = nullptr)
+{
+    Workspace &ws = *ctx->ws;
+    if (g.w + 1 > 8 * 1024 || (size_t)2 * (g.w + g.h + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
+    if (!tilted) {
+        if (ws.tilted.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int))) { ctx->set_error("device allocation failed (tilted integral)"); return NVCA_ERR_NOMEM; }
+        tilted = ws.tilted.as<int>();
+    }
+    if (!gray) gray = ws.gray.as<uint8_t>();
+    TimedLaunch t(ctx, NVCA_K_INTEGRAL);
+    launch_tilted(ctx->stream, gray, lut, 256, g, tilted, batch);
+    return NVCA_OK;
 }
 
 // cascade scan over the integral planes of slots [0, n); fills raw[b] (canonical scale,y,x order)
@@ -388,6 +403,16 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
+        a.tilted = dp.needs_tilted ? ws.tilted.as<int>() : nullptr;
+        a.galpha = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_galpha; a.gcls_first = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_gcls_first;
+        a.stump_based = dp.generic_stumps ? 1 : 0;
+        if (dp.generic) {
+            // tree weak classifiers / tilted features: stage-0 pre-pass for every window, then the remaining stages on the
+            // visited survivors, window per lane (kernels_cascade.hip, "general cascades")
+            if (dp.needs_tilted && !a.tilted) { ctx->set_error("internal: tilted integral missing"); return NVCA_ERR_ARG; }
+            { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_generic(ctx->stream, a, batch, 0); }
+            { TimedLaunch t(ctx, NVCA_K_STRIP); launch_generic(ctx->stream, a, batch, 1); }
+        } else {
 #ifdef NVCA_STAMPS
         {   // diagnostic build: the stamps of the last band launch are written to $NVCA_STAMPS_OUT when the context synchronises
             static DevBuf dbgbuf;
@@ -432,6 +457,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             { TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(1)) return NVCA_ERR_HIP; }
         }
         { TimedLaunch t(ctx, NVCA_K_DEEP); if (launch(2)) return NVCA_ERR_HIP; }
+        }
         // the box tables are small (a few KB per frame): the grouping kernel stores them straight into the page-locked host
         // buffer (plain stores, visible to the host once the stream has drained) -- no copy operation behind the last kernel
         if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
@@ -794,6 +820,14 @@ int nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stag
     return NVCA_OK;
 }
 
+int nvca_cascade_kind(const nvca_cascade *c, int *has_tilted, int *has_trees)
+{
+    if (!c) return NVCA_ERR_ARG;
+    if (has_tilted) *has_tilted = c->c.has_tilted ? 1 : 0;
+    if (has_trees) *has_trees = c->c.stump_based ? 0 : 1;
+    return NVCA_OK;
+}
+
 int nvca_cascade_dump(const nvca_cascade *c, int *rects, float *weights, float *thr, float *left_val,
                       float *right_val, int *stage_sizes, float *stage_thr)
 {
@@ -1038,6 +1072,21 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     return NVCA_OK;
 }
 
+int nvca_integral_tilted(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *tilted)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    int rc = check_img(ctx, src, w, h, stride, 1, mem);
+    if (rc || !tilted) return NVCA_ERR_ARG;
+    if (mem != NVCA_MEM_HOST) { ctx->set_error("nvca_integral_tilted: host output only"); return NVCA_ERR_ARG; }
+    (void)hipSetDevice(ctx->device);
+    Workspace &ws = *ctx->ws;
+    PreGeom g; make_geom(g, w, h, stride, 1, w, h);
+    if ((rc = ensure_ws(ctx, g, 1))) return rc;
+    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    if ((rc = run_tilted(ctx, g, nullptr, 1))) return rc;
+    return unstage_2d(ctx, tilted, (size_t)(w + 1) * 4, ws.tilted.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+}
+
 // =========================================================================
 // detectMultiScale
 // =========================================================================
@@ -1115,9 +1164,11 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
     const size_t gray_total = pp->gray_total, plane_total = pp->plane_total;
     PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
     if ((rc = ensure_ws(ctx, g0, nimg))) return rc;
-    if (ws.aux.ensure(gray_total * nimg + 64) || ws.sum.ensure(plane_total * nimg * sizeof(int)) || ws.sqsum.ensure(plane_total * nimg * sizeof(unsigned long long))) {
+    if (ws.aux.ensure(gray_total * nimg + 64) || ws.sum.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)) || ws.sqsum.ensure(plane_total * nimg * sizeof(unsigned long long)) ||
+        (c.has_tilted && ws.tilted.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)))) {
         ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
     }
+    if (c.has_tilted && (size_t)2 * (pp->pyr_maxw + pp->pyr_maxh + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
     for (int k = 0; k < nimg; k++)
         if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, grays[k], stride, cols, rows, mem))) return rc;
     if (pp->pyr_ok) {            // all levels of all images: one resize launch, one integral launch
@@ -1127,6 +1178,11 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
           launch_pyr_integral(ctx->stream, ws.aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
                               ws.sum.as<int>(), ws.sqsum.as<unsigned>(), plane_total, P); }
+        if (c.has_tilted) {          // cvIntegral(&img1, &sum1, &sqsum1, _tilted) per level
+            TimedLaunch t(ctx, NVCA_K_INTEGRAL);
+            launch_pyr_tilted(ctx->stream, ws.aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
+                              ws.tilted.as<int>(), plane_total, P, pp->pyr_maxw, pp->pyr_maxh);
+        }
     } else
     for (size_t li = 0; li < pp->lv.size(); li++) {
         const PyrLevel &L = pp->lv[li];
@@ -1140,6 +1196,7 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
         run_integral(ctx, g, nullptr, nimg, lg, ws.sum.as<int>() + L.plane_off,
                      (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
+        if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, nimg, lg, ws.tilted.as<int>() + L.plane_off))) return rc;
     }
     std::vector<std::vector<nvca_rect>> raw;
     rc = run_cascade(ctx, pp->det, plane_total, P, nimg, raw);
@@ -1175,6 +1232,7 @@ static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const vo
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
     if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, gray, stride, cols, rows, mem))) return rc;
     run_integral(ctx, g, nullptr, 1);
+    if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, 1))) return rc;
     // the ladder of factors, largest first, exactly as the serial loop walks it
     struct Step { double factor, ystep; int winw, winh; };
     std::vector<Step> ladder;
@@ -1330,6 +1388,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
     if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
     if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, gray, stride, w, h, mem))) return rc;
     run_integral(ctx, gp->g, nullptr, 1);
+    if (casc->c.has_tilted && (rc = run_tilted(ctx, gp->g, nullptr, 1))) return rc;
     std::vector<std::vector<nvca_rect>> raw;
     const int gthr = (!raw_only && min_neighbors != 0) ? std::max(min_neighbors, 1) : 0;
     std::vector<char> grouped;
@@ -1592,6 +1651,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
             job.counters_zeroed = true;
             ws.hist_clean = hist_clean;
             run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), nc);
+            if (streams[idx[0]]->cascade->c.has_tilted && (rc = run_tilted(ctx, gp->g, ws.lut.as<uint8_t>(), nc))) return rc;
             if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
             jobs.push_back(job);
         }

@@ -124,7 +124,7 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
         err = "bad <size>"; return NVCA_ERR_PARSE;
     }
     out.stages.clear(); out.cls.clear(); out.nodes.clear(); out.alpha.clear();
-    out.stump_based = true;
+    out.stump_based = true; out.has_tilted = false;
     int si = 0;
     for (auto &st : stages->kids) {
         const XNode *trees = st->child("trees"), *sthr = st->child("stage_threshold");
@@ -155,12 +155,19 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
                     }
                     for (int q = 0; q < 4; q++) hn.rect[k][q] = r[q];
                     hn.weight[k] = (float)wt;
-                    if (r[0] < 0 || r[1] < 0 || r[2] <= 0 || r[3] <= 0 || r[0] + r[2] > out.ow || r[1] + r[3] > out.oh) {
-                        err = "rect outside the window"; return NVCA_ERR_PARSE;
-                    }
+                    if (r[0] < 0 || r[1] < 0 || r[2] <= 0 || r[3] <= 0) { err = "rect outside the window"; return NVCA_ERR_PARSE; }
                 }
                 if (!to_int(tilted->text, hn.tilted)) { err = "bad <tilted>"; return NVCA_ERR_PARSE; }
-                if (hn.tilted) { err = "tilted features are not supported"; return NVCA_ERR_UNSUPPORTED; }
+                hn.tilted = hn.tilted != 0;
+                for (size_t k = 0; k < rects->kids.size(); k++) {
+                    const int *r = hn.rect[k];
+                    // upright: x .. x+w, y .. y+h.  tilted: the rectangle rotated about (x, y) reads the tilted integral at
+                    // columns x-h .. x+w and rows y .. y+w+h (cvSetImagesForHaarClassifierCascade)
+                    const bool inside = !hn.tilted ? (r[0] + r[2] <= out.ow && r[1] + r[3] <= out.oh)
+                                                   : (r[0] - r[3] >= 0 && r[0] + r[2] <= out.ow && r[1] + r[2] + r[3] <= out.oh);
+                    if (!inside) { err = hn.tilted ? "tilted rect outside the window" : "rect outside the window"; return NVCA_ERR_PARSE; }
+                }
+                if (hn.tilted) out.has_tilted = true;
                 // icvCreateHidHaarClassifierCascade: rect[2] is dropped when its weight or size is zero
                 hn.nrect = (fabs(hn.weight[2]) < DBL_EPSILON || hn.rect[2][2] == 0 || hn.rect[2][3] == 0) ? 2 : 3;
                 if (!to_double(thr->text, d)) { err = "bad <threshold>"; return NVCA_ERR_PARSE; }

@@ -169,6 +169,127 @@ __device__ __forceinline__ bool visited(const unsigned long long *__restrict__ r
     return !(d & 1);
 }
 
+// ---- general cascades: tree-structured weak classifiers and / or tilted features ----------------------------------------
+// cvRunHaarClassifierCascadeSum's general branch: per weak classifier a walk idx = sum < t ? left : right from the root to
+// a leaf, whose value is the vote; a feature's rectangles read the integral image or, for a tilted feature, the tilted
+// integral.  Window per lane, global reads (these cascades run on the part detectors' small working images; the LDS tile
+// machinery above is built around upright stumps).  The stage loop is wave-uniform, so the root of every weak classifier is
+// a scalar record; only the nodes below it are per-lane.
+typedef const __attribute__((address_space(4))) GNodeRec CGNodeRec;
+template <class Rec>
+__device__ __forceinline__ double gen_node_sum(const int *__restrict__ pl, unsigned off, int pitch, const Rec &n, bool pair)
+{
+    auto rs = [&](int q) {
+        return pl[off + (unsigned)(n.dy[q][0] * pitch + n.dx[q][0])] - pl[off + (unsigned)(n.dy[q][1] * pitch + n.dx[q][1])] -
+               pl[off + (unsigned)(n.dy[q][2] * pitch + n.dx[q][2])] + pl[off + (unsigned)(n.dy[q][3] * pitch + n.dx[q][3])];
+    };
+    const int s0 = rs(0), s1 = rs(1);
+    if (pair) return (double)((float)s0 * n.w[0] + (float)s1 * n.w[1]);       // SSE2 path of two-rectangle stump stages
+    double v = (double)((float)s0 * n.w[0]);
+    v += (double)((float)s1 * n.w[1]);
+    if ((n.flags & 255) == 3) v += (double)((float)rs(2) * n.w[2]);
+    return v;
+}
+__device__ __forceinline__ bool gen_stage(const CascadeArgs &a, const int *__restrict__ sum, const int *__restrict__ tilt, unsigned off, int pitch,
+                                          double vnf, const GNodeRec *recs, const StageRec &st)
+{
+    const bool pair = a.pair_policy && a.stump_based && (st.flags & 1);
+    double stage_sum = 0.0;
+    for (int j = 0; j < st.count; j++) {
+        const int base = a.gcls_first[st.first + j];
+        CGNodeRec &root = ((CGNodeRec *)recs)[base];
+        const double s = gen_node_sum((root.flags & 256) ? tilt : sum, off, pitch, root, pair);
+        int idx = s < (double)root.thr * vnf ? root.left : root.right;      // node->threshold * variance_norm_factor
+        while (idx > 0) {                                                   // below the root the lanes of a wave part ways
+            const GNodeRec &n = recs[base + idx];
+            const double sn = gen_node_sum((n.flags & 256) ? tilt : sum, off, pitch, n, false);
+            idx = sn < (double)n.thr * vnf ? n.left : n.right;
+        }
+        stage_sum += (double)a.galpha[-idx];
+    }
+    return !(stage_sum < (double)st.thr);
+}
+
+__global__ __launch_bounds__(256) void k_gen_stage0(CascadeArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot, bidx;
+    if (!xcd_chunk_index((a.ntasks + 3) / 4, slot, bidx)) return;
+    const int t = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);
+    if (t >= a.ntasks) return;
+    const unsigned task = a.tasks[t];
+    const int s = task >> 20, iy = (task >> 7) & 8191, k = task & 127;
+    const ScaleRec &sc = a.scales[s];
+    const int ix = k * 64 + lane;
+    const bool active = ix < sc.endX;
+    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+    const int *__restrict__ tilt = a.tilted ? a.tilted + (size_t)slot * a.sum_slot + sc.plane_off : sum;
+    const unsigned *__restrict__ sql = (const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + sc.plane_off;
+    const uint8_t *__restrict__ sqh = (const uint8_t *)((const unsigned *)a.sqsum + (size_t)slot * 2 * a.sum_slot + a.sum_slot) + sc.plane_off;
+    bool pass0 = false;
+    double vnf = 1.;
+    if (active) {
+        const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
+        const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
+        const int ws = sum[e0] - sum[e1] - sum[e2] + sum[e3];
+        const double mean = (double)ws * sc.inv_area;
+        vnf = window_sqsum(sql, sqh, sc.sq32 != 0, e0, e1, e2, e3);
+        vnf = vnf * sc.inv_area - mean * mean;
+        vnf = vnf >= 0. ? sqrt(vnf) : 1.;
+        pass0 = gen_stage(a, sum, tilt, off, sc.pitch, vnf, sc.grecs, a.stages[0]);
+    }
+    const unsigned long long fb = __ballot(active && !pass0);
+    const size_t o = (size_t)slot * a.ntasks + t;
+    if (lane == 0) a.failbits[o] = fb;
+    a.vnf[o * 64 + lane] = vnf;
+}
+
+__global__ __launch_bounds__(256) void k_gen_rest(CascadeArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot, bidx;
+    if (!xcd_chunk_index((a.ntasks + 3) / 4, slot, bidx)) return;
+    const int t = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);
+    if (t >= a.ntasks) return;
+    const unsigned task = a.tasks[t];
+    const int s = task >> 20, iy = (task >> 7) & 8191, k = task & 127;
+    const ScaleRec &sc = a.scales[s];
+    const int ix = k * 64 + lane;
+    const unsigned long long *rb = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr;
+    bool alive = false;
+    if (ix < sc.endX && !((rb[k] >> lane) & 1ull)) alive = sc.adaptive ? visited(rb, ix) : true;
+    if (!__any(alive)) return;
+    const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
+    const int *__restrict__ tilt = a.tilted ? a.tilted + (size_t)slot * a.sum_slot + sc.plane_off : sum;
+    unsigned off = 0; double vnf = 1.;
+    if (alive) {
+        off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
+        vnf = a.vnf[((size_t)slot * a.ntasks + t) * 64 + lane];
+    }
+    for (int st_i = 1; st_i < a.nstages; st_i++) {           // wave-uniform stage loop: lanes that fell out idle
+        if (!__any(alive)) return;
+        if (alive) alive = gen_stage(a, sum, tilt, off, sc.pitch, vnf, sc.grecs, a.stages[st_i]);
+    }
+    const unsigned long long hm = __ballot(alive);
+    if (!hm) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.hits, (unsigned long long)__popcll(hm));
+    base = __shfl(base, 0);
+    if (alive) {
+        const unsigned long long pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+        const unsigned key = ((unsigned)s << 26) | ((unsigned)iy << 13) | (unsigned)ix;
+        if (pos < a.hit_cap) a.hits[1 + pos] = ((unsigned long long)slot << 32) | key;
+    }
+}
+
+void launch_generic(hipStream_t st, const CascadeArgs &a, int batch, int which)
+{
+    if (batch <= 0 || a.ntasks <= 0) return;
+    const int blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
+    if (which == 0) NVCA_LAUNCH(k_gen_stage0, dim3((unsigned)blocks * (unsigned)batch), dim3(256), 0, st, a);
+    else NVCA_LAUNCH(k_gen_rest, dim3((unsigned)blocks * (unsigned)batch), dim3(256), 0, st, a);
+}
+
 // ---- K5b: stages 1 .. deep_stage-1 on strips ---------------------------------
 __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
 {

@@ -625,6 +625,77 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
     }
 }
 
+// ---- tilted integral: cv::integral's third plane, read by tilted Haar features ------------------------------------------
+// tilted(X,Y) = sum of image(x,y) over y < Y, abs(x - X + 1) <= Y - y - 1  (int32, (h+1) x (w+1), row 0 zero).
+// Row Y of the triangle under (X,Y) differs from row Y-1's by the apex pixel (X-1,Y-1) and by its two end pixels per
+// earlier row, which lie on the diagonals through (X-2,Y-2) and (X,Y-2): dl[c - y] / dr[c + y] are running sums along the two
+// diagonal families.  One workgroup per image walks the rows; thread X reads its two diagonal sums (as of row Y-2), emits
+// tilted(X,Y), then adds pixel (X-1,Y-1) to exactly those two sums -- the element a thread reads in a row is the one it
+// updates, so one barrier per row orders everything.  Serial in the rows (cheap: the path is only taken for cascades that
+// hold tilted features, on the small working images of the part detectors); exact 32-bit integer arithmetic.
+static constexpr int kTiltedCols = 8;                 // columns per thread: w + 1 <= 8 * 1024
+__device__ __forceinline__ void tilted_image(const uint8_t *__restrict__ g, int gpitch, const uint8_t *__restrict__ lut, int w, int h,
+                                             int *__restrict__ out, int opitch, int *dl, int *dr)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < w + h + 2; i += 1024) { dl[i] = 0; dr[i] = 0; }
+    for (int X = tid; X <= w; X += 1024) out[X] = 0;
+    int prev[kTiltedCols];
+#pragma unroll
+    for (int k = 0; k < kTiltedCols; k++) prev[k] = 0;
+    __syncthreads();
+    for (int Y = 1; Y <= h; Y++) {
+        const uint8_t *row = g + (size_t)(Y - 1) * gpitch;
+#pragma unroll
+        for (int k = 0; k < kTiltedCols; k++) {
+            const int X = tid + 1024 * k;
+            if (X > w) break;
+            int p = 0;
+            if (X >= 1) { p = row[X - 1]; if (lut) p = lut[p]; }
+            int v = prev[k] + p;
+            const int il = X - Y + h, ir = X + Y - 2;         // dl index of diagonal c - y = X - Y (shifted by h), dr index of c + y
+            if (Y >= 2) {
+                if (X >= 2) v += dl[il];
+                if (X < w) v += dr[ir];
+            }
+            if (X >= 1) { dl[il] += p; dr[ir] += p; }
+            out[(size_t)Y * opitch + X] = v;
+            prev[k] = v;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tilted(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut, int lut_stride, PreGeom g,
+                                                 int *__restrict__ tilted)
+{
+    extern __shared__ int tl_lds[];
+    const int slot = blockIdx.x;
+    tilted_image(gray + (size_t)slot * g.gray_slot, g.gpitch, lut ? lut + (size_t)slot * lut_stride : nullptr, g.w, g.h,
+                 tilted + (size_t)slot * g.sum_slot, g.spitch, tl_lds, tl_lds + g.w + g.h + 2);
+}
+
+__global__ __launch_bounds__(1024) void k_pyr_tilted(const uint8_t *__restrict__ aux, size_t aux_slot, const PyrLevelDev *__restrict__ levels,
+                                                     int nimg, int *__restrict__ tilted, size_t sum_slot, int P, int lds_half)
+{
+    extern __shared__ int tl_lds[];
+    const int lev = blockIdx.x / nimg, img = blockIdx.x - lev * nimg;
+    const PyrLevelDev L = levels[lev];
+    tilted_image(aux + (size_t)img * aux_slot + L.gray_off, L.gpitch, nullptr, L.szw, L.szh,
+                 tilted + (size_t)img * sum_slot + L.plane_off, P, tl_lds, tl_lds + lds_half);
+}
+
+void launch_tilted(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g, int *tilted, int batch)
+{
+    NVCA_LAUNCH(k_tilted, dim3(batch), dim3(1024), (size_t)2 * (g.w + g.h + 2) * sizeof(int), st, gray, lut, lut_stride, g, tilted);
+}
+void launch_pyr_tilted(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
+                       int *tilted, size_t sum_slot, int P, int maxw, int maxh)
+{
+    const int half = maxw + maxh + 2;
+    NVCA_LAUNCH(k_pyr_tilted, dim3(nlev * nimg), dim3(1024), (size_t)2 * half * sizeof(int), st, aux, aux_slot, levels, nimg, tilted, sum_slot, P, half);
+}
+
 void launch_pyr_resize(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, size_t src_slot, const PyrLevelDev *levels,
                        int nlev, int nimg, int maxw, int maxh, uint8_t *aux, size_t aux_slot)
 {

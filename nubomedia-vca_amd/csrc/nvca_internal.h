@@ -33,6 +33,8 @@ struct Cascade {
     std::vector<HaarNode> nodes;
     std::vector<float> alpha;
     bool stump_based = true;
+    bool has_tilted = false; // some feature reads the tilted integral
+    bool generic() const { return !stump_based || has_tilted; }   // evaluated by the general kernels (kernels_generic.hip)
     uint64_t uid = 0;       // identity for plan caching
     mutable std::vector<unsigned char> stage_rec_cache;   // StageRec[] (plan.cpp, built on first use: the summation-order proof is per cascade)
 };
@@ -69,7 +71,22 @@ struct ScaleRec {           // one evaluated scale
     double inv_area;
     double factor;
     const struct TStumpRec *trecs;   // the cascade's stumps at this scale's factor (device; shared by every plan that uses the factor)
+    const struct GNodeRec *grecs;    // general cascades (tree weak classifiers / tilted features): every node at this scale's factor
+    long long pad_g;
 };
+
+// A node of a weak classifier in its general form: up to three rectangles, upright (corners of the integral image) or
+// tilted (corners of the tilted integral), a threshold and two children.  Corner offsets are window-relative pixels in the
+// order + - - + (cvSetImagesForHaarClassifierCascade: p0 - p1 - p2 + p3), per (cascade, factor) like TStumpRec.
+struct GNodeRec {
+    short dx[3][4], dy[3][4];
+    float w[3];
+    float thr;
+    int left, right;        // > 0: node index inside the weak classifier; <= 0: leaf, alpha index = -value (absolute)
+    int flags;              // low byte: rectangles (2 or 3); bit 8: tilted
+    int pad;
+};
+static_assert(sizeof(GNodeRec) == 80, "GNodeRec layout");
 
 struct StripRec { int scale, iy0, nrows, ix0, ncols, pad0, pad1, pad2; };   // a block's share of the scan: nrows x ncols windows
 // A tile is a block of nx x ny windows (<= 32 x 32) of one scale.  The windows of a scale only ever touch the integral
@@ -324,6 +341,11 @@ struct CascadeArgs {
     unsigned deep_cap;
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
+    // general cascades (kernels_generic.hip)
+    const int *tilted;             // tilted integral planes, laid out like sum (null: the cascade has no tilted feature)
+    const float *galpha;           // leaf values of every weak classifier, concatenated
+    const int *gcls_first;         // first node of weak classifier c
+    int stump_based;
 #ifdef NVCA_STAMPS
     unsigned long long *dbg;       // diagnostic build only: per-phase s_memtime stamps of the first workgroups (scripts/stamps.py)
 #endif
@@ -335,6 +357,13 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
 // detectMultiScale(CV_HAAR_SCALE_IMAGE) on two images of one geometry with shared launches (api.cpp; used by parts.cpp)
 int detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
                             int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs /* [2] */);
+// general cascades: which = 0: variance + stage 0 for every window (reject bits + normaliser), 1: the remaining stages on the
+// visited stage-0 survivors, window per lane
+void launch_generic(hipStream_t st, const CascadeArgs &a, int batch, int which);
+// tilted integral (cv::integral's third plane) of `batch` images / of every pyramid level: one workgroup per image
+void launch_tilted(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g, int *tilted, int batch);
+void launch_pyr_tilted(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
+                       int *tilted, size_t sum_slot, int P, int maxw, int maxh);
 // groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
 void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch);
 

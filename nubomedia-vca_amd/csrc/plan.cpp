@@ -83,6 +83,51 @@ void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
     const double weight_scale = 1. / (t.ew * t.eh);
     t.winw = cv_round(c.ow * factor); t.winh = cv_round(c.oh * factor);
     t.inv_area = weight_scale;
+    t.ghost.clear(); t.galpha.clear(); t.gcls_first.clear();
+    if (c.generic()) {
+        // every node of every weak classifier; corners in the order p0 - p1 - p2 + p3 of cvSetImagesForHaarClassifierCascade
+        t.host.clear();
+        t.galpha = c.alpha;
+        for (const HaarClassifier &hc : c.cls) {
+            t.gcls_first.push_back((int)t.ghost.size());
+            for (int l = 0; l < hc.nnodes; l++) {
+                const HaarNode &n = c.nodes[hc.first_node + l];
+                GNodeRec r; memset(&r, 0, sizeof(r));
+                double sum0 = 0, area0 = 0;
+                for (int q = 0; q < n.nrect; q++) {
+                    const int tx = cv_round(n.rect[q][0] * factor), tw = cv_round(n.rect[q][2] * factor);
+                    const int ty = cv_round(n.rect[q][1] * factor), th = cv_round(n.rect[q][3] * factor);
+                    const double correction_ratio = weight_scale * (!n.tilted ? 1 : 0.5);
+                    if (!n.tilted) {
+                        r.dx[q][0] = (short)tx;        r.dy[q][0] = (short)ty;
+                        r.dx[q][1] = (short)(tx + tw); r.dy[q][1] = (short)ty;
+                        r.dx[q][2] = (short)tx;        r.dy[q][2] = (short)(ty + th);
+                        r.dx[q][3] = (short)(tx + tw); r.dy[q][3] = (short)(ty + th);
+                    } else {
+                        r.dx[q][0] = (short)tx;             r.dy[q][0] = (short)ty;
+                        r.dx[q][1] = (short)(tx - th);      r.dy[q][1] = (short)(ty + th);
+                        r.dx[q][2] = (short)(tx + tw);      r.dy[q][2] = (short)(ty + tw);
+                        r.dx[q][3] = (short)(tx + tw - th); r.dy[q][3] = (short)(ty + tw + th);
+                    }
+                    r.w[q] = (float)(n.weight[q] * correction_ratio);
+                    if (q == 0) area0 = tw * th;
+                    else {
+                        float tt = r.w[q] * tw;      // float * int -> float, evaluated left to right
+                        tt = tt * th;
+                        sum0 += tt;
+                    }
+                }
+                r.w[0] = (float)(-sum0 / area0);
+                r.thr = n.threshold;
+                // children: > 0 a node of this classifier, <= 0 a leaf whose value is alpha[first_alpha - v]
+                r.left = n.left > 0 ? n.left : -(hc.first_alpha + (-n.left));
+                r.right = n.right > 0 ? n.right : -(hc.first_alpha + (-n.right));
+                r.flags = n.nrect | (n.tilted ? 256 : 0);
+                t.ghost.push_back(r);
+            }
+        }
+        return;
+    }
     t.host.assign(c.cls.size(), TStumpRec());
     size_t k = 0;
     for (const HaarClassifier &hc : c.cls) {
@@ -203,7 +248,7 @@ nvca_rect DetectPlan::hit_rect(unsigned key) const
 
 int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&in, bool allow_tiles, std::string &err)
 {
-    if (!c.stump_based) { err = "tree weak classifiers are not supported by the device evaluator yet"; return NVCA_ERR_UNSUPPORTED; }
+    generic = c.generic(); needs_tilted = c.has_tilted; generic_stumps = c.stump_based;
     specs = std::move(in);
     nstumps = (int)c.cls.size();
     scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); release_tables();
@@ -211,6 +256,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     // stages 1 .. deep_stage-1 run on LDS lattice tiles (k_tile); NVCA_TILES=0 selects the older row strips (k_strip)
     bool use_tiles = true;
     if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
+    if (generic) use_tiles = false;              // the LDS tile kernels are built around upright stumps
     (void)allow_tiles;
     tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
     if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
@@ -234,6 +280,19 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
         sr.eq[0] = tabp->ey * pitch + tabp->ex;               sr.eq[1] = tabp->ey * pitch + tabp->ex + tabp->ew;
         sr.eq[2] = (tabp->ey + tabp->eh) * pitch + tabp->ex;  sr.eq[3] = (tabp->ey + tabp->eh) * pitch + tabp->ex + tabp->ew;
         sr.trecs = tabp->dev.as<TStumpRec>();
+        sr.grecs = tabp->d_grecs;
+        if (generic) {
+            // every corner of every node must stay inside the planes for every window of the grid (a faulting read takes the
+            // whole GPU down): columns 0 .. pitch-1, rows 0 .. plane_rows-1
+            int mnx = 0, mxx = 0, mny = 0, mxy = 0;
+            for (const GNodeRec &g : tabp->ghost)
+                for (int q = 0; q < (g.flags & 255); q++)
+                    for (int e = 0; e < 4; e++) { mnx = std::min<int>(mnx, g.dx[q][e]); mxx = std::max<int>(mxx, g.dx[q][e]); mny = std::min<int>(mny, g.dy[q][e]); mxy = std::max<int>(mxy, g.dy[q][e]); }
+            if (!sp.xs.empty() && !sp.ys.empty() &&
+                (sp.xs.front() + mnx < 0 || sp.xs.back() + mxx >= pitch || sp.ys.front() + mny < 0 || sp.ys.back() + mxy >= sp.plane_rows + 2)) {      // the planes are allocated with a few spare rows (api.cpp)
+                err = "a feature of the cascade leaves the image at this scale"; return NVCA_ERR_UNSUPPORTED;
+            }
+        }
         sr.plane_off = sp.plane_off; sr.pitch = pitch; sr.adaptive = sp.adaptive;
         sr.endX = (int)sp.xs.size(); sr.endY = (int)sp.ys.size();
         if (sr.endX > 8191 || sr.endY > 8191) { err = "image too large for the candidate key"; return NVCA_ERR_ARG; }
@@ -434,6 +493,19 @@ ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor)
     const size_t bytes = t->host.size() * sizeof(TStumpRec);
     if (t->dev.ensure(bytes ? bytes : 8)) { ctx->set_error("hipMalloc failed for a stump table"); return nullptr; }
     if (bytes && hipMemcpy(t->dev.p, t->host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy failed for a stump table"); return nullptr; }
+    if (!t->ghost.empty()) {             // general cascade: nodes | leaf values | first-node indices in one block
+        const size_t nb = (t->ghost.size() * sizeof(GNodeRec) + 255) & ~(size_t)255, ab = (t->galpha.size() * sizeof(float) + 255) & ~(size_t)255;
+        const size_t cb = t->gcls_first.size() * sizeof(int);
+        std::vector<unsigned char> blob(nb + ab + cb);
+        memcpy(blob.data(), t->ghost.data(), t->ghost.size() * sizeof(GNodeRec));
+        memcpy(blob.data() + nb, t->galpha.data(), t->galpha.size() * sizeof(float));
+        memcpy(blob.data() + nb + ab, t->gcls_first.data(), cb);
+        if (t->gdev.ensure(blob.size())) { ctx->set_error("hipMalloc failed for a node table"); return nullptr; }
+        if (hipMemcpy(t->gdev.p, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy failed for a node table"); return nullptr; }
+        t->d_grecs = (const GNodeRec *)t->gdev.p;
+        t->d_galpha = (const float *)((const unsigned char *)t->gdev.p + nb);
+        t->d_gcls_first = (const int *)((const unsigned char *)t->gdev.p + nb + ab);
+    }
     t->last_use = ++ctx->next_uid;
     ScaleTable *raw = t.release();
     ctx->scale_tables[key] = raw;

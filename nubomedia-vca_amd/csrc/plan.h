@@ -11,13 +11,20 @@ void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw
 struct ScaleTable {
     std::vector<TStumpRec> host;
     DevBuf dev;
+    // general cascades (tree weak classifiers / tilted features): every node at this factor, plus the cascade's leaf values and
+    // first-node indices (cascade-level, kept with the table so that a plan finds everything in one place)
+    std::vector<GNodeRec> ghost;
+    std::vector<float> galpha;
+    std::vector<int> gcls_first;
+    DevBuf gdev;
+    const GNodeRec *d_grecs = nullptr; const float *d_galpha = nullptr; const int *d_gcls_first = nullptr;
     int winw = 0, winh = 0, ex = 0, ey = 0, ew = 0, eh = 0;
     double inv_area = 0, factor = 0;
     int refs = 0; uint64_t last_use = 0;
     // distinct corner columns / rows of the stumps of stage ranges (cached per range: plans ask again and again)
     std::map<std::pair<int, int>, std::pair<std::vector<int>, std::vector<int>>> offsets;
     const std::pair<std::vector<int>, std::vector<int>> &corner_offsets(int k0, int k1, bool with_eq);
-    ~ScaleTable() { dev.release(); }
+    ~ScaleTable() { dev.release(); gdev.release(); }
 };
 void build_scale_table(const Cascade &c, double factor, ScaleTable &t);
 ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor);     // nullptr: allocation / copy failed (error set)
@@ -48,6 +55,9 @@ struct DetectPlan {
     std::vector<int> pos;
     std::vector<unsigned> tasks; // stage-0 wave tasks
     bool device_group_ok = false;     // candidate rects are plain (x, y, winw, winh): k_group can rebuild them
+    bool generic = false;             // tree weak classifiers / tilted features: evaluated by k_gen_stage0 + k_gen_rest
+    bool needs_tilted = false;        // the cascade reads the tilted integral
+    bool generic_stumps = false;      // general evaluator, but every weak classifier is a stump (the SSE2 pair policy applies)
     int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
     std::vector<TileRec> tiles;  // LDS lattice tiles (k_tile); empty: row strips (k_strip)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;

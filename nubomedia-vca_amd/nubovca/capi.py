@@ -68,6 +68,7 @@ SYMBOLS = [
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
+    "nvca_integral_tilted", "nvca_cascade_kind",
 ]
 
 _lib = None
@@ -130,6 +131,8 @@ def load():
     L.nvca_resize_linear.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.nvca_equalize_hist.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.nvca_integral.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.nvca_integral_tilted.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    L.nvca_cascade_kind.argtypes = [vp, ip, ip]
     L.nvca_detect_multiscale.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, ip]
     L.nvca_detect_raw.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
@@ -270,6 +273,13 @@ class Context:
                                         s.ctypes.data_as(C.POINTER(C.c_int32)), q.ctypes.data_as(C.POINTER(C.c_double))))
         return s, q
 
+    def integral_tilted(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        t = np.empty((h + 1, w + 1), np.int32)
+        self.check(self.L.nvca_integral_tilted(self.h, img.ctypes.data, w, h, img.strides[0], MEM_HOST, t.ctypes.data_as(C.POINTER(C.c_int32))))
+        return t
+
     def detect_multiscale(self, casc, gray, scale_factor=1.1, min_neighbors=3, flags=0, min_size=(0, 0),
                           max_size=(0, 0), cap=4096):
         gray = np.ascontiguousarray(gray, np.uint8)
@@ -374,6 +384,12 @@ class Cascade:
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(self.ctx.L.nvca_cascade_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
+
+    def kind(self):
+        """(has_tilted, has_trees)"""
+        t, r = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.L.nvca_cascade_kind(self.h, C.byref(t), C.byref(r)))
+        return bool(t.value), bool(r.value)
 
     def dump(self):
         ow, oh, ns, nw = self.info()

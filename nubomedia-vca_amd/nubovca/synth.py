@@ -240,27 +240,22 @@ def make_generic_cascade(ow=20, oh=20, seed=1, stage_sizes=(3, 8, 12, 16, 20, 24
         for _ in range(n):
             nn = int(rng.randint(2, max_nodes + 1)) if rng.rand() < tree_frac else 1
             nodes = []
+            next_free = 1                       # nodes are handed out to parents in index order: a proper binary tree, nn + 1 leaves
             for k in range(nn):
                 tilted = 1 if rng.rand() < tilt_frac else 0
                 feat = _rand_tilted_feature(rng, ow, oh) if tilted else _rand_upright_feature(rng, ow, oh)
                 a = float(rng.uniform(0.3, 1.0))
-
-                def child(later):
-                    if later and rng.rand() < 0.7:
-                        return ("node", later.pop(0))
-                    return ("val", a if rng.rand() < 0.5 else -a)
-                later = list(range(k + 1, nn))
-                # every later node must be reachable: node k points at k+1 on one side when there is one
-                if later:
-                    nxt = later.pop(0)
-                    sides = [("node", nxt), child(later)]
-                    if rng.rand() < 0.5:
-                        sides.reverse()
-                else:
-                    v = a if rng.rand() < 0.5 else -a
-                    sides = [("val", v), ("val", -v)]
+                avail = nn - next_free
+                lo = 1 if (next_free == k + 1 and avail > 0) else 0      # the next node must hang somewhere before its turn comes
+                take = int(rng.randint(lo, min(2, avail) + 1)) if avail > 0 else 0
+                sides = [("node", next_free + j) for j in range(take)]
+                next_free += take
+                v = a if rng.rand() < 0.5 else -a
+                while len(sides) < 2:
+                    sides.append(("val", v)); v = -v
+                if rng.rand() < 0.5:
+                    sides.reverse()
                 nodes.append(dict(feature=feat, tilted=tilted, threshold=float(rng.normal(0, 0.02)), left=sides[0], right=sides[1]))
-            # node indices must refer to existing later nodes only; unreachable extras are legal but pointless: trim to the chain
             trees.append(nodes)
         stages.append(dict(trees=trees, stage_threshold=float(rng.uniform(-0.3, 0.1))))
     return dict(name="generic_%dx%d" % (ow, oh), size=(ow, oh), stages=stages)
