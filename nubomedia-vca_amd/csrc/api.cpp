@@ -1090,33 +1090,77 @@ int nvca_integral_tilted(nvca_ctx *ctx, const void *src, int w, int h, int strid
 // =========================================================================
 // detectMultiScale
 // =========================================================================
+} // extern "C"
+
+// A detectMultiScale call in halves: enqueue() queues the next launch set of the call on the context's stream and returns;
+// advance(), after the stream has drained, consumes what the set produced and either finishes the call or asks for another
+// set (FIND_BIGGEST narrows its scan once).  Many calls can therefore share ONE wait per round: the part detectors queue the
+// face passes of every stream of a tick, then every ROI pass, with three synchronisations per tick instead of several per
+// stream (parts.cpp).  The image planes are shared working memory: jobs use them one after the other in stream order; what a
+// job leaves behind for the host (its candidate list) lives in its own result region (CascadeJob::r0).
+namespace nvca {
+
+struct FbStep { double factor, ystep; int winw, winh; };
+
+struct DetectJob {
+    // ---- request
+    int kind = 0;                                    // 0: scale-cascade scan, 1: CV_HAAR_SCALE_IMAGE, 2: CV_HAAR_FIND_BIGGEST_OBJECT
+    const nvca_cascade *casc = nullptr;
+    const void *img[2] = {nullptr, nullptr}; int nimg = 1;       // SCALE_IMAGE: up to two images of one geometry share the launches
+    int cols = 0, rows = 0, stride = 0, mem = 0;
+    double sf = 1.1; int min_neighbors = 0, flags = 0, minw = 0, minh = 0, maxw = 0, maxh = 0;
+    bool raw_only = false;
+    // ---- result
+    std::vector<nvca_rect> out[2];
+    // ---- progress
+    int phase = 0;                                   // 0: new, 1: first launch set queued, 2: narrowed set queued, 3: done
+    int slots() const { return nimg; }
+    GeomPlan *gp = nullptr;                          // cached plan of the queued set (kept from eviction while queued)
+    std::unique_ptr<DetectPlan> own;                 // FIND_BIGGEST: this call's narrowed plan
+    DetectPlan *dp = nullptr;                        // plan of the queued set (null: nothing was queued)
+    CascadeJob cj; int gthr = 0;
+    // FIND_BIGGEST: the serial loop's state between the two sets
+    std::vector<FbStep> ladder; std::vector<std::vector<nvca_rect>> hits; std::vector<char> have; std::vector<int> ladder_of;
+    std::vector<nvca_rect> all; nvca_rect scanROI{0, 0, 0, 0}; bool narrowed_done = false; size_t fb_i = 0; int cur_minw = 0, cur_minh = 0;
+};
+
+static bool fb_make_spec(const DetectJob &j, int spitch, const FbStep &st, int startX, int endX, int startY, int endY, ScaleSpec &sp)
+{   // scan grid of one ladder step; false: nothing to scan there
+    if (!(endX > startX && endY > startY)) return false;
+    sp = ScaleSpec();
+    sp.table_factor = st.factor; sp.plane_off = 0; sp.pitch = spitch; sp.plane_rows = j.rows + 1; sp.adaptive = 1;
+    sp.out_factor = 0; sp.out_w = st.winw; sp.out_h = st.winh;
+    for (int ix = startX; ix < endX; ix++) sp.xs.push_back(cv_round(ix * st.ystep));
+    for (int iy = startY; iy < endY; iy++) sp.ys.push_back(cv_round(iy * st.ystep));
+    // cvRunHaarClassifierCascadeSum returns -1 (no hit, step 1) outside the image: drop such grid points
+    while (!sp.xs.empty() && (sp.xs.back() + st.winw >= j.cols + 1)) sp.xs.pop_back();
+    while (!sp.ys.empty() && (sp.ys.back() + st.winh >= j.rows + 1)) sp.ys.pop_back();
+    const bool neg = (!sp.xs.empty() && sp.xs.front() < 0) || (!sp.ys.empty() && sp.ys.front() < 0);
+    return !sp.xs.empty() && !sp.ys.empty() && !neg;
+}
+
 // cvHaarDetectObjectsForROC, CV_HAAR_SCALE_IMAGE branch (EYE/kmseyedetect.cpp:991-993, NOSE/kmsnosedetect.cpp:843-846,
 // MOUTH/kmsmouthdetect.cpp:845-848, EAR/kmseardetect.cpp:656-659): per factor the image is resized, integrated and
-// scanned with the unscaled window on a fixed grid.  All pyramid levels are evaluated by one launch set.
-// `nimg` images of one geometry (the ear detector scans an image and its mirror, EAR/kmseardetect.cpp:796-803) share
-// every launch: pyramid levels, integrals and the scan run with the images as batch slots.
-static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const void *const *grays, int nimg, int cols, int rows, int stride,
-                              int mem, double sf, int min_neighbors, int minw, int minh, int maxw, int maxh, bool raw_only,
-                              std::vector<nvca_rect> *outs)
+// scanned with the unscaled window on a fixed grid.  All pyramid levels (of both images: the ear detector scans an image
+// and its mirror, EAR/kmseardetect.cpp:796-803) are evaluated by one launch set.
+static int si_plan(nvca_ctx *ctx, const DetectJob &j, GeomPlan **out)
 {
-    (void)hipSetDevice(ctx->device);
-    Workspace &ws = *ctx->ws;
-    const Cascade &c = casc->c;
-    for (int k = 0; k < nimg; k++) outs[k].clear();
+    const Cascade &c = j.casc->c;
+    const int cols = j.cols, rows = j.rows;
     int rc;
     // pyramid layout, resize tables and scan tables depend only on (cascade, image size, parameters): built once
     char key[256];
-    snprintf(key, sizeof(key), "SI|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, sf, minw, minh, maxw, maxh);
+    snprintf(key, sizeof(key), "SI|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, j.sf, j.minw, j.minh, j.maxw, j.maxh);
     GeomPlan *pp = find_plan(ctx, key);
     if (!pp) {
         std::unique_ptr<GeomPlan> np(new GeomPlan());
         np->P = (int)round_up(cols + 1, 8);
-        for (double factor = 1;; factor *= sf) {
+        for (double factor = 1;; factor *= j.sf) {
             const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
             const int szw = cv_round(cols / factor), szh = cv_round(rows / factor);
             if (szw - c.ow + 1 <= 0 || szh - c.oh + 1 <= 0) break;
-            if (winw > maxw || winh > maxh) break;
-            if (winw < minw || winh < minh) continue;
+            if (winw > j.maxw || winh > j.maxh) break;
+            if (winw < j.minw || winh < j.minh) continue;
             if (szw + 1 <= 1 + c.ow) continue;                   // HaarDetectObjects_ScaleImage_Invoker's early return
             PyrLevel L; L.f = factor; L.szw = szw; L.szh = szh; L.winw = winw; L.winh = winh;
             L.gpitch = (int)round_up(szw, 64); L.gray_off = np->gray_total; L.plane_off = (int)np->plane_total;
@@ -1159,10 +1203,23 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
         }
         pp = store_plan(ctx, key, std::move(np));
     }
+    *out = pp;
+    return NVCA_OK;
+}
+
+static int si_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
+{
+    Workspace &ws = *ctx->ws;
+    const Cascade &c = j.casc->c;
+    const int cols = j.cols, rows = j.rows, nimg = j.nimg;
+    GeomPlan *pp = nullptr;
+    int rc;
+    if ((rc = si_plan(ctx, j, &pp))) return rc;
+    j.phase = 1; j.dp = nullptr;
     if (pp->lv.empty()) return NVCA_OK;
     const int P = pp->P;
     const size_t gray_total = pp->gray_total, plane_total = pp->plane_total;
-    PreGeom g0; make_geom(g0, cols, rows, stride, 1, cols, rows);
+    PreGeom g0; make_geom(g0, cols, rows, j.stride, 1, cols, rows);
     if ((rc = ensure_ws(ctx, g0, nimg))) return rc;
     if (ws.aux.ensure(gray_total * nimg + 64) || ws.sum.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)) || ws.sqsum.ensure(plane_total * nimg * sizeof(unsigned long long)) ||
         (c.has_tilted && ws.tilted.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)))) {
@@ -1170,7 +1227,7 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
     }
     if (c.has_tilted && (size_t)2 * (pp->pyr_maxw + pp->pyr_maxh + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
     for (int k = 0; k < nimg; k++)
-        if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, grays[k], stride, cols, rows, mem))) return rc;
+        if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, j.img[k], j.stride, cols, rows, j.mem))) return rc;
     if (pp->pyr_ok) {            // all levels of all images: one resize launch, one integral launch
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
           launch_pyr_resize(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, g0.gray_slot, pp->d_pyr.as<PyrLevelDev>(),
@@ -1198,84 +1255,76 @@ static int detect_scale_image(nvca_ctx *ctx, const nvca_cascade *casc, const voi
                      (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
         if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, nimg, lg, ws.tilted.as<int>() + L.plane_off))) return rc;
     }
-    std::vector<std::vector<nvca_rect>> raw;
-    rc = run_cascade(ctx, pp->det, plane_total, P, nimg, raw);
-    if (rc) return rc;
-    if (!raw_only) group_all(raw, min_neighbors);
-    for (int k = 0; k < nimg; k++) outs[k].swap(raw[k]);
+    j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = nimg; j.cj.total = total;
+    if ((rc = cascade_enqueue(ctx, pp->det, plane_total, P, j.cj, nullptr, false))) return rc;
+    j.gp = pp; pp->inflight++; j.dp = &pp->det;
     return NVCA_OK;
 }
 
-} // extern "C"
-int nvca::detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
-                                  int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs)
+// plain scale-cascade scan (flags without SCALE_IMAGE / FIND_BIGGEST): FACE/kmsfacedetect.cpp:809-811, EYE/kmseyedetect.cpp:958-960
+static int plain_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
 {
-    NVCA_LOCK_OR_FAIL(ctx);
-    if (!casc || !(sf > 1.0) || check_img(ctx, img_a, w, h, stride, 1, mem) || check_img(ctx, img_b, w, h, stride, 1, mem)) return NVCA_ERR_ARG;
-    const void *imgs[2] = {img_a, img_b};
-    return detect_scale_image(ctx, casc, imgs, 2, w, h, stride, mem, sf, min_neighbors, minw, minh, w, h, false, outs);
+    GeomPlan *gp = nullptr;
+    int rc;
+    if ((rc = get_face_plan(ctx, j.casc, j.cols, j.rows, j.stride, 1, j.cols, j.rows, j.sf, j.minw, j.minh, j.maxw, j.maxh, &gp))) return rc;
+    if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
+    run_integral(ctx, gp->g, nullptr, 1);
+    if (j.casc->c.has_tilted && (rc = run_tilted(ctx, gp->g, nullptr, 1))) return rc;
+    j.gthr = (!j.raw_only && j.min_neighbors != 0) ? std::max(j.min_neighbors, 1) : 0;
+    j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = 1; j.cj.total = total;
+    if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, j.cj, j.gthr ? &j.gthr : nullptr, true))) return rc;
+    j.gp = gp; gp->inflight++; j.dp = &gp->det; j.phase = 1;
+    return NVCA_OK;
 }
-extern "C" {
 
 // cvHaarDetectObjectsForROC with CV_HAAR_FIND_BIGGEST_OBJECT (NOSE/kmsnosedetect.cpp:870-873, MOUTH/kmsmouthdetect.cpp:870-873,
 // EAR/kmseardetect.cpp:712-715): scale-cascade scan from the largest factor down; after the first grouped detection
-// the scan narrows to a region of interest and a minimum size.
-static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int cols, int rows, int stride,
-                               int mem, double scaleFactor, int minNeighbors, int flags, int minw, int minh, int maxw,
-                               int maxh, std::vector<nvca_rect> &out)
+// the scan narrows to a region of interest and a minimum size.  The serial loop changes its scan only once, so two launch
+// sets do: (1) every step on its full grid (a cached plan per geometry), (2) once the region is known, the remaining steps
+// on their narrowed grids.  fb_replay() replays the serial logic on those results, step by step.
+static int fb_stage_image(nvca_ctx *ctx, const DetectJob &j, PreGeom &g)
 {
-    (void)hipSetDevice(ctx->device);
-    const Cascade &c = casc->c;
-    const bool rough = (flags & NVCA_HAAR_DO_ROUGH_SEARCH) != 0;
-    PreGeom g; make_geom(g, cols, rows, stride, 1, cols, rows);
+    make_geom(g, j.cols, j.rows, j.stride, 1, j.cols, j.rows);
     int rc;
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, gray, stride, cols, rows, mem))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
     run_integral(ctx, g, nullptr, 1);
-    if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, 1))) return rc;
+    if (j.casc->c.has_tilted && (rc = run_tilted(ctx, g, nullptr, 1))) return rc;
+    return NVCA_OK;
+}
+
+static int fb_enqueue_first(nvca_ctx *ctx, DetectJob &j, int r0, int total)
+{
+    const Cascade &c = j.casc->c;
+    const int cols = j.cols, rows = j.rows;
+    PreGeom g; int rc;
+    if ((rc = fb_stage_image(ctx, j, g))) return rc;
     // the ladder of factors, largest first, exactly as the serial loop walks it
-    struct Step { double factor, ystep; int winw, winh; };
-    std::vector<Step> ladder;
+    j.ladder.clear();
     {
         int n_factors = 0; double factor;
-        for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= scaleFactor)
+        for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= j.sf)
             ;
-        const double inv = 1. / scaleFactor; factor *= inv;
-        for (; n_factors-- > 0; factor *= inv) ladder.push_back(Step{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
+        const double inv = 1. / j.sf; factor *= inv;
+        for (; n_factors-- > 0; factor *= inv) j.ladder.push_back(FbStep{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
     }
-    // scan grid of one ladder step; false: nothing to scan there
-    auto make_spec = [&](const Step &st, int startX, int endX, int startY, int endY, ScaleSpec &sp) {
-        if (!(endX > startX && endY > startY)) return false;
-        sp = ScaleSpec();
-        sp.table_factor = st.factor; sp.plane_off = 0; sp.pitch = g.spitch; sp.plane_rows = rows + 1; sp.adaptive = 1;
-        sp.out_factor = 0; sp.out_w = st.winw; sp.out_h = st.winh;
-        for (int ix = startX; ix < endX; ix++) sp.xs.push_back(cv_round(ix * st.ystep));
-        for (int iy = startY; iy < endY; iy++) sp.ys.push_back(cv_round(iy * st.ystep));
-        // cvRunHaarClassifierCascadeSum returns -1 (no hit, step 1) outside the image: drop such grid points
-        while (!sp.xs.empty() && (sp.xs.back() + st.winw >= cols + 1)) sp.xs.pop_back();
-        while (!sp.ys.empty() && (sp.ys.back() + st.winh >= rows + 1)) sp.ys.pop_back();
-        const bool neg = (!sp.xs.empty() && sp.xs.front() < 0) || (!sp.ys.empty() && sp.ys.front() < 0);
-        return !sp.xs.empty() && !sp.ys.empty() && !neg;
-    };
-    // The serial loop changes its scan only once: after the first grouped detection it narrows to a region of interest and
-    // raises the minimum size.  So two launch sets do: (1) every step on its full grid (a cached plan per geometry),
-    // (2) once the region is known, the remaining steps on their narrowed grids.  The loop below replays the serial
-    // logic on those results, step by step.
-    std::vector<std::vector<nvca_rect>> hits(ladder.size());             // per ladder step, scan order
+    if (j.ladder.size() > 63) { ctx->set_error("too many scales"); return NVCA_ERR_ARG; }
+    j.hits.assign(j.ladder.size(), {}); j.have.assign(j.ladder.size(), 0);
+    j.all.clear(); j.scanROI = nvca_rect{0, 0, 0, 0}; j.narrowed_done = false; j.fb_i = 0; j.cur_minw = j.minw; j.cur_minh = j.minh;
     char key[256];
-    snprintf(key, sizeof(key), "FB|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, scaleFactor, minw, minh, maxw, maxh);
+    snprintf(key, sizeof(key), "FB|%llu|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)c.uid, cols, rows, j.sf, j.minw, j.minh, j.maxw, j.maxh);
     GeomPlan *p1 = find_plan(ctx, key);
     if (!p1) {
         std::unique_ptr<GeomPlan> np(new GeomPlan());
         std::vector<ScaleSpec> specs;
-        for (size_t i = 0; i < ladder.size(); i++) {
-            const Step &st = ladder[i];
-            if (st.winw < minw || st.winh < minh) break;
-            if (st.winw > maxw || st.winh > maxh) continue;
+        for (size_t i = 0; i < j.ladder.size(); i++) {
+            const FbStep &st = j.ladder[i];
+            if (st.winw < j.minw || st.winh < j.minh) break;
+            if (st.winw > j.maxw || st.winh > j.maxh) continue;
             ScaleSpec sp;
-            if (make_spec(st, 0, cv_round((cols - st.winw) / st.ystep), 0, cv_round((rows - st.winh) / st.ystep), sp)) {
+            if (fb_make_spec(j, g.spitch, st, 0, cv_round((cols - st.winw) / st.ystep), 0, cv_round((rows - st.winh) / st.ystep), sp)) {
                 specs.push_back(std::move(sp)); np->fb_ladder.push_back((int)i);
-                if (specs.size() >= 63) break;               // (deeper ladders fall back to per-step evaluation below)
             }
         }
         if (!specs.empty()) {
@@ -1285,116 +1334,219 @@ static int detect_find_biggest(nvca_ctx *ctx, const nvca_cascade *casc, const vo
         }
         p1 = store_plan(ctx, key, std::move(np));
     }
-    std::vector<char> have(ladder.size(), 0);                            // steps whose scan result is in `hits`
-    auto run_set = [&](DetectPlan &dp, const std::vector<int> &ladder_of) {
-        std::vector<std::vector<nvca_rect>> raw;
-        std::vector<std::vector<int>> sc;
-        int r = run_cascade(ctx, dp, g.sum_slot, g.spitch, 1, raw, nullptr, nullptr, &sc);
-        if (r) return r;
-        for (size_t k = 0; k < raw[0].size(); k++) hits[ladder_of[sc[0][k]]].push_back(raw[0][k]);
-        for (int li : ladder_of) have[li] = 1;
-        return (int)NVCA_OK;
-    };
-    if (!p1->fb_ladder.empty() && (rc = run_set(p1->det, p1->fb_ladder))) return rc;
-    std::vector<nvca_rect> all;
-    nvca_rect scanROI{0, 0, 0, 0};
-    bool narrowed_done = false;
-    for (size_t i = 0; i < ladder.size(); i++) {
-        const Step &st = ladder[i];
-        if (st.winw < minw || st.winh < minh) break;
-        if (st.winw > maxw || st.winh > maxh) continue;
-        const bool narrowed = scanROI.w * scanROI.h > 0;
-        if (narrowed && !narrowed_done) {
-            // second launch set: this step and all later ones on the narrowed grids (nothing changes the scan any more)
-            narrowed_done = true;
-            std::vector<ScaleSpec> specs; std::vector<int> ladder_of;
-            for (size_t k = i; k < ladder.size() && specs.size() < 63; k++) {
-                const Step &sk = ladder[k];
-                hits[k].clear(); have[k] = 0;
-                if (sk.winw < minw || sk.winh < minh) break;
-                if (sk.winw > maxw || sk.winh > maxh) continue;
-                ScaleSpec sp;
-                if (make_spec(sk, cv_round(scanROI.x / sk.ystep), cv_round((scanROI.x + scanROI.w - sk.winw) / sk.ystep),
-                              cv_round(scanROI.y / sk.ystep), cv_round((scanROI.y + scanROI.h - sk.winh) / sk.ystep), sp)) {
-                    specs.push_back(std::move(sp)); ladder_of.push_back((int)k);
-                } else have[k] = 1;                          // nothing to scan at that step
-            }
-            if (!specs.empty()) {
-                DetectPlan dp; std::string err;
-                if ((rc = dp.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
-                if ((rc = dp.upload(ctx))) return rc;
-                if ((rc = run_set(dp, ladder_of))) return rc;
-            }
-        }
-        if (!have[i]) {                                      // not covered by a launch set (a ladder deeper than 63 steps): on its own
-            ScaleSpec sp;
-            const bool any = narrowed ? make_spec(st, cv_round(scanROI.x / st.ystep), cv_round((scanROI.x + scanROI.w - st.winw) / st.ystep),
-                                                  cv_round(scanROI.y / st.ystep), cv_round((scanROI.y + scanROI.h - st.winh) / st.ystep), sp)
-                                      : make_spec(st, 0, cv_round((cols - st.winw) / st.ystep), 0, cv_round((rows - st.winh) / st.ystep), sp);
-            if (any) {
-                std::vector<ScaleSpec> one; one.push_back(std::move(sp));
-                DetectPlan dp; std::string err;
-                if ((rc = dp.build_custom(ctx, c, std::move(one), false, err))) { ctx->set_error(err); return rc; }
-                if ((rc = dp.upload(ctx))) return rc;
-                if ((rc = run_set(dp, std::vector<int>{(int)i}))) return rc;
-            }
-        }
-        all.insert(all.end(), hits[i].begin(), hits[i].end());
-        if (!all.empty() && scanROI.w * scanROI.h == 0) {
-            std::vector<nvca_rect> tmp(all);
-            group_rectangles(tmp, std::max(minNeighbors, 1), 0.2);
-            if (!tmp.empty()) {
-                nvca_rect maxRect{0, 0, 0, 0};
-                for (const nvca_rect &r : tmp) if (r.w * r.h > maxRect.w * maxRect.h) maxRect = r;
-                all.push_back(maxRect);
-                scanROI = maxRect;
-                const int dx = cv_round(maxRect.w * 0.2), dy = cv_round(maxRect.h * 0.2);
-                scanROI.x = std::max(scanROI.x - dx, 0); scanROI.y = std::max(scanROI.y - dy, 0);
-                scanROI.w = std::min(scanROI.w + dx * 2, cols - 1 - scanROI.x);
-                scanROI.h = std::min(scanROI.h + dy * 2, rows - 1 - scanROI.y);
-                const double minScale = rough ? 0.6 : 0.4;
-                minw = cv_round(maxRect.w * minScale); minh = cv_round(maxRect.h * minScale);
-            }
-        }
-    }
-    group_rectangles(all, std::max(minNeighbors, 1), 0.2);
-    out.clear();
-    if (!all.empty()) {
-        nvca_rect best{0, 0, 0, 0};
-        for (const nvca_rect &r : all) if (r.w * r.h > best.w * best.h) best = r;
-        out.push_back(best);
+    j.phase = 1; j.dp = nullptr;
+    // steps the full-grid plan does not hold have nothing to scan
+    for (size_t i = 0; i < j.ladder.size(); i++) j.have[i] = 1;
+    if (!p1->fb_ladder.empty()) {
+        j.ladder_of = p1->fb_ladder;
+        j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = 1; j.cj.total = total;
+        if ((rc = cascade_enqueue(ctx, p1->det, g.sum_slot, g.spitch, j.cj, nullptr, false))) return rc;
+        j.gp = p1; p1->inflight++; j.dp = &p1->det;
     }
     return NVCA_OK;
 }
+
+// the narrowed launch set: this step and all later ones on their narrowed grids (nothing changes the scan any more)
+static int fb_enqueue_narrowed(nvca_ctx *ctx, DetectJob &j, int r0, int total)
+{
+    PreGeom g; int rc;
+    if ((rc = fb_stage_image(ctx, j, g))) return rc;         // the planes have served other jobs in between
+    j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = 1; j.cj.total = total;
+    if ((rc = cascade_enqueue(ctx, *j.own, g.sum_slot, g.spitch, j.cj, nullptr, false))) return rc;
+    j.dp = j.own.get();
+    return NVCA_OK;
+}
+
+// the serial loop of cvHaarDetectObjectsForROC on the scan results at hand; returns 1 when it needs the narrowed set first
+static int fb_replay(nvca_ctx *ctx, DetectJob &j)
+{
+    const Cascade &c = j.casc->c;
+    const bool rough = (j.flags & NVCA_HAAR_DO_ROUGH_SEARCH) != 0;
+    const int cols = j.cols, rows = j.rows;
+    const int spitch = (int)round_up(cols + 1, 8);
+    for (size_t i = j.fb_i; i < j.ladder.size(); i++) {
+        const FbStep &st = j.ladder[i];
+        if (st.winw < j.cur_minw || st.winh < j.cur_minh) break;
+        if (st.winw > j.maxw || st.winh > j.maxh) continue;
+        const bool narrowed = j.scanROI.w * j.scanROI.h > 0;
+        if (narrowed && !j.narrowed_done) {
+            j.narrowed_done = true;
+            std::vector<ScaleSpec> specs; j.ladder_of.clear();
+            for (size_t k = i; k < j.ladder.size(); k++) {
+                const FbStep &sk = j.ladder[k];
+                j.hits[k].clear(); j.have[k] = 1;
+                if (sk.winw < j.cur_minw || sk.winh < j.cur_minh) break;
+                if (sk.winw > j.maxw || sk.winh > j.maxh) continue;
+                ScaleSpec sp;
+                if (fb_make_spec(j, spitch, sk, cv_round(j.scanROI.x / sk.ystep), cv_round((j.scanROI.x + j.scanROI.w - sk.winw) / sk.ystep),
+                                 cv_round(j.scanROI.y / sk.ystep), cv_round((j.scanROI.y + j.scanROI.h - sk.winh) / sk.ystep), sp)) {
+                    specs.push_back(std::move(sp)); j.ladder_of.push_back((int)k); j.have[k] = 0;
+                }
+            }
+            if (!specs.empty()) {
+                j.own.reset(new DetectPlan()); std::string err;
+                int rc;
+                if ((rc = j.own->build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc < 0 ? rc : NVCA_ERR_ARG; }
+                if ((rc = j.own->upload(ctx))) return rc;
+                j.fb_i = i;
+                return 1;                                    // come back with the narrowed scans
+            }
+        }
+        j.all.insert(j.all.end(), j.hits[i].begin(), j.hits[i].end());
+        if (!j.all.empty() && j.scanROI.w * j.scanROI.h == 0) {
+            std::vector<nvca_rect> tmp(j.all);
+            group_rectangles(tmp, std::max(j.min_neighbors, 1), 0.2);
+            if (!tmp.empty()) {
+                nvca_rect maxRect{0, 0, 0, 0};
+                for (const nvca_rect &r : tmp) if (r.w * r.h > maxRect.w * maxRect.h) maxRect = r;
+                j.all.push_back(maxRect);
+                j.scanROI = maxRect;
+                const int dx = cv_round(maxRect.w * 0.2), dy = cv_round(maxRect.h * 0.2);
+                j.scanROI.x = std::max(j.scanROI.x - dx, 0); j.scanROI.y = std::max(j.scanROI.y - dy, 0);
+                j.scanROI.w = std::min(j.scanROI.w + dx * 2, cols - 1 - j.scanROI.x);
+                j.scanROI.h = std::min(j.scanROI.h + dy * 2, rows - 1 - j.scanROI.y);
+                const double minScale = rough ? 0.6 : 0.4;
+                j.cur_minw = cv_round(maxRect.w * minScale); j.cur_minh = cv_round(maxRect.h * minScale);
+            }
+        }
+    }
+    group_rectangles(j.all, std::max(j.min_neighbors, 1), 0.2);
+    j.out[0].clear();
+    if (!j.all.empty()) {
+        nvca_rect best{0, 0, 0, 0};
+        for (const nvca_rect &r : j.all) if (r.w * r.h > best.w * best.h) best = r;
+        j.out[0].push_back(best);
+    }
+    return 0;
+}
+
+// queue the job's next launch set; its candidates go to result slots [r0, r0 + slots()) of `total`
+static int detect_job_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
+{
+    (void)hipSetDevice(ctx->device);
+    if (j.phase == 0) {
+        for (int k = 0; k < 2; k++) j.out[k].clear();
+        if (j.kind == 2) return fb_enqueue_first(ctx, j, r0, total);
+        if (j.kind == 1) return si_enqueue(ctx, j, r0, total);
+        return plain_enqueue(ctx, j, r0, total);
+    }
+    if (j.phase == 2) return fb_enqueue_narrowed(ctx, j, r0, total);
+    return NVCA_OK;
+}
+
+// after the stream has drained: consume the queued set's results.  phase 3: the call is complete (out[] holds the objects);
+// phase 2: it needs another set (enqueue again)
+static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
+{
+    int rc = NVCA_OK;
+    std::vector<std::vector<nvca_rect>> raw;
+    std::vector<char> grouped;
+    std::vector<std::vector<int>> sc;
+    if (j.dp) rc = cascade_collect(ctx, *j.dp, j.cj, raw, j.kind == 0 ? &grouped : nullptr, j.kind == 2 ? &sc : nullptr);
+    if (j.gp) { j.gp->inflight--; j.gp = nullptr; }
+    if (rc) { j.phase = 3; return rc; }
+    if (j.kind == 0) {
+        if (j.dp) { if (j.gthr && !grouped[0]) group_all(raw, j.min_neighbors); j.out[0].swap(raw[0]); }
+        j.phase = 3;
+    } else if (j.kind == 1) {
+        if (j.dp) { if (!j.raw_only) group_all(raw, j.min_neighbors); for (int k = 0; k < j.nimg; k++) j.out[k].swap(raw[k]); }
+        j.phase = 3;
+    } else {
+        if (j.dp) {
+            for (size_t k = 0; k < raw[0].size(); k++) j.hits[j.ladder_of[sc[0][k]]].push_back(raw[0][k]);
+            for (int li : j.ladder_of) j.have[li] = 1;
+        }
+        j.dp = nullptr;
+        const int r = fb_replay(ctx, j);
+        if (r < 0) { j.phase = 3; return r; }
+        j.phase = r == 1 ? 2 : 3;
+    }
+    j.dp = nullptr;
+    return NVCA_OK;
+}
+
+// run a set of detectMultiScale calls to completion: one wait per round for all of them
+int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n)
+{
+    for (;;) {
+        int total = 0;
+        for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) total += jobs[i]->slots();
+        if (!total) return NVCA_OK;
+        int r0 = 0, rc = NVCA_OK;
+        for (int i = 0; i < n && !rc; i++) {
+            if (jobs[i]->phase == 3) continue;
+            rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
+            r0 += jobs[i]->slots();
+        }
+        const hipError_t he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess && !rc) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); rc = NVCA_ERR_HIP; }
+        drain_timer(ctx);
+        for (int i = 0; i < n; i++) {
+            if (jobs[i]->phase == 3) continue;
+            if (rc) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; continue; }
+            const int r = detect_job_advance(ctx, *jobs[i]);
+            if (r) rc = r;
+        }
+        if (rc) {
+            for (int i = 0; i < n; i++) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; }
+            return rc;
+        }
+    }
+}
+
+} // namespace nvca
+
+int nvca::detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
+                                  int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!casc || !(sf > 1.0) || check_img(ctx, img_a, w, h, stride, 1, mem) || check_img(ctx, img_b, w, h, stride, 1, mem)) return NVCA_ERR_ARG;
+    DetectJob j; j.kind = 1; j.casc = casc; j.img[0] = img_a; j.img[1] = img_b; j.nimg = 2; j.cols = w; j.rows = h; j.stride = stride; j.mem = mem;
+    j.sf = sf; j.min_neighbors = min_neighbors; j.minw = minw; j.minh = minh; j.maxw = w; j.maxh = h;
+    DetectJob *jp = &j;
+    const int rc = run_detect_jobs(ctx, &jp, 1);
+    if (rc) return rc;
+    outs[0].swap(j.out[0]); outs[1].swap(j.out[1]);
+    return NVCA_OK;
+}
+
+nvca::DetectJob *nvca::detect_job_new() { return new (std::nothrow) DetectJob(); }
+void nvca::detect_job_free(DetectJob *j) { delete j; }
+const std::vector<nvca_rect> &nvca::detect_job_out(const DetectJob *j, int k) { return j->out[k]; }
+void nvca::detect_job_pair(DetectJob *j, const void *second_image) { j->img[1] = second_image; j->nimg = 2; }
+
+// fill in a job from detectMultiScale's arguments (flags decide the kind); NVCA_ERR_ARG for bad arguments
+int nvca::make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
+                          double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only)
+{
+    if (check_img(ctx, gray, w, h, stride, 1, mem) || !casc || !(sf > 1.0)) return NVCA_ERR_ARG;
+    if (maxw == 0 || maxh == 0) { maxw = w; maxh = h; }
+    j = DetectJob();
+    j.casc = casc; j.img[0] = gray; j.nimg = 1; j.cols = w; j.rows = h; j.stride = stride; j.mem = mem;
+    j.sf = sf; j.min_neighbors = min_neighbors; j.minw = minw; j.minh = minh; j.maxw = maxw; j.maxh = maxh; j.raw_only = raw_only;
+    if (flags & NVCA_HAAR_FIND_BIGGEST_OBJECT) {
+        flags &= ~(NVCA_HAAR_SCALE_IMAGE | NVCA_HAAR_DO_CANNY_PRUNING);
+        if (raw_only) return NVCA_ERR_ARG;
+        j.kind = 2;
+    } else if (flags & NVCA_HAAR_SCALE_IMAGE) j.kind = 1;
+    else j.kind = 0;
+    j.flags = flags;
+    return NVCA_OK;
+}
+
+extern "C" {
 
 static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
                        double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only,
                        std::vector<nvca_rect> &out)
 {
     NVCA_LOCK_OR_FAIL(ctx);
-    int rc = check_img(ctx, gray, w, h, stride, 1, mem);
-    if (rc || !casc || !(sf > 1.0)) return NVCA_ERR_ARG;
-    if (maxw == 0 || maxh == 0) { maxw = w; maxh = h; }
-    if (flags & NVCA_HAAR_FIND_BIGGEST_OBJECT) {
-        flags &= ~(NVCA_HAAR_SCALE_IMAGE | NVCA_HAAR_DO_CANNY_PRUNING);
-        if (raw_only) return NVCA_ERR_ARG;
-        return detect_find_biggest(ctx, casc, gray, w, h, stride, mem, sf, min_neighbors, flags, minw, minh, maxw, maxh, out);
-    }
-    if (flags & NVCA_HAAR_SCALE_IMAGE)
-        { const void *one[1] = {gray}; return detect_scale_image(ctx, casc, one, 1, w, h, stride, mem, sf, min_neighbors, minw, minh, maxw, maxh, raw_only, &out); }
-    (void)hipSetDevice(ctx->device);
-    GeomPlan *gp = nullptr;
-    if ((rc = get_face_plan(ctx, casc, w, h, stride, 1, w, h, sf, minw, minh, maxw, maxh, &gp))) return rc;
-    if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, gray, stride, w, h, mem))) return rc;
-    run_integral(ctx, gp->g, nullptr, 1);
-    if (casc->c.has_tilted && (rc = run_tilted(ctx, gp->g, nullptr, 1))) return rc;
-    std::vector<std::vector<nvca_rect>> raw;
-    const int gthr = (!raw_only && min_neighbors != 0) ? std::max(min_neighbors, 1) : 0;
-    std::vector<char> grouped;
-    if ((rc = run_cascade(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, 1, raw, gthr ? &gthr : nullptr, &grouped))) return rc;
-    if (gthr && !grouped[0]) group_all(raw, min_neighbors);
-    out.swap(raw[0]);
+    DetectJob j;
+    int rc = make_detect_job(ctx, j, casc, gray, w, h, stride, mem, sf, min_neighbors, flags, minw, minh, maxw, maxh, raw_only);
+    if (rc) return rc;
+    DetectJob *jp = &j;
+    if ((rc = run_detect_jobs(ctx, &jp, 1))) return rc;
+    out.swap(j.out[0]);
     return NVCA_OK;
 }
 

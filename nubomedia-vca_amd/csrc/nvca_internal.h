@@ -354,6 +354,15 @@ struct CascadeArgs {
 // lds_grant: the calling context's record of the dynamic LDS already granted to k_tile ([0]) / k_band ([1]); returns a
 // hipError_t (as int) when the grant is refused, 0 otherwise
 int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant);
+// detectMultiScale calls in halves (api.cpp): many calls share one wait per round
+struct DetectJob;
+int make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
+                    double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only);
+int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n);
+DetectJob *detect_job_new();
+void detect_job_free(DetectJob *j);
+const std::vector<nvca_rect> &detect_job_out(const DetectJob *j, int k);
+void detect_job_pair(DetectJob *j, const void *second_image);     // SCALE_IMAGE on two images of one geometry (k = 0 / 1 in detect_job_out)
 // detectMultiScale(CV_HAAR_SCALE_IMAGE) on two images of one geometry with shared launches (api.cpp; used by parts.cpp)
 int detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
                             int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs /* [2] */);
