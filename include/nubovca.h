@@ -248,6 +248,12 @@ int  nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, 
 int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, nvca_rect *out_a, int cap_a,
                               int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
 
+/* Batched frontend for the part detectors (BASELINE config 3, the ROI chain): frame i belongs to streams[i] (a stream at most
+ * once per call; the streams may be of different kinds).  The device work of all streams is queued together: one wait for
+ * every face pass, one for every part search, instead of several per stream.  out_a is [n][cap_a], out_b [n][cap_b]. */
+int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames,
+                             nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
+
 /* ---- NuboTracker stream -------------------------------------------------
  * Replaces gst_nubo_tracker_img_conf + gst_nubo_tracker_process
  * (TRK/gstnubotracker.cpp:202-237, 339-421): BGRA -> gray, absdiff, threshold,

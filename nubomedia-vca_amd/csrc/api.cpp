@@ -936,9 +936,21 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     PreGeom g; make_geom(g, w, h, stride, channels, w, h);
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
     nvca_frame f{src, w, h, stride, mem, 0};
-    if ((rc = stage_frames(ctx, &f, nullptr, 1, channels))) return rc;
+    // The frame pointer reaches the kernel through a pointer table that is uploaded asynchronously from page-locked host
+    // memory.  Callers that chain primitives without draining the stream (the part detectors queue many frames back to back)
+    // must not reuse a table entry whose upload may still be pending: every call takes the next entry of a ring.
+    static constexpr int kPtrRing = 1024;
+    Workspace &ws = *ctx->ws;
+    ResultBufs &rb = ws.res[ws.cur_res];
+    if (rb.srcptrs.ensure(kPtrRing * sizeof(void *)) || rb.h_srcptrs.ensure(kPtrRing * sizeof(void *))) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if (ctx->defer_device_sync > 0 && ++ctx->ptr_ring_used >= kPtrRing) {       // a full turn without a drain: drain once
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ptr_ring_used = 0;
+    }
+    const int slot = ctx->defer_device_sync > 0 ? ctx->ptr_ring_used : 0;
+    if ((rc = stage_frames(ctx, &f, nullptr, 1, channels, slot))) return rc;
     { TimedLaunch t(ctx, NVCA_K_GRAY);
-      launch_gray(ctx->stream, ctx->ws->res[ctx->ws->cur_res].srcptrs.as<const uint8_t *>(), g, 0, nullptr, nullptr, nullptr, nullptr, w,
+      launch_gray(ctx->stream, rb.srcptrs.as<const uint8_t *>() + slot, g, 0, nullptr, nullptr, nullptr, nullptr, w,
                   ctx->ws->gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
     return unstage_2d(ctx, dst, dst_stride, ctx->ws->gray.p, g.gpitch, w, h, mem);
 }

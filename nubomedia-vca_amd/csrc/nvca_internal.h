@@ -212,6 +212,7 @@ struct nvca_ctx {
     std::vector<hipEvent_t> chunk_events;
     nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect
     uint64_t face_serial = 0;
+    int ptr_ring_used = 0;                    // nvca_bgr2gray: entries of the frame-pointer ring handed out since the last drain
     int defer_device_sync = 0;                // > 0: primitives that write device memory return without draining the stream
                                               // (internal callers chaining primitives on the context's stream, parts.cpp)
     std::string err;

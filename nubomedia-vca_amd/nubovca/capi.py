@@ -68,7 +68,7 @@ SYMBOLS = [
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
-    "nvca_integral_tilted", "nvca_cascade_kind",
+    "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process",
 ]
 
 _lib = None
@@ -167,6 +167,7 @@ def load():
     L.nvca_part_stream_set_params.argtypes = [vp, C.POINTER(PartParams)]
     L.nvca_part_stream_push_faces.argtypes = [vp, C.POINTER(Rect), C.c_int]
     L.nvca_part_stream_faces.argtypes = [vp, C.POINTER(Rect), C.c_int, ip]
+    L.nvca_part_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     L.nvca_part_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     _lib = L
     return L
@@ -518,6 +519,19 @@ def tracker_batch_process(ctx, trackers, frames, timestamps, cap=4096):
     ctx.check(ctx.L.nvca_tracker_batch_process(ctx.h, n, th, fr, ts, out, cap, cnt))
     boxes = np.frombuffer(out, dtype=np.int32).reshape(n, cap, 4)
     return [boxes[i, :min(cnt[i], cap)].copy() for i in range(n)]
+
+
+def part_batch_process(ctx, streams, frames, cap=64):
+    """nvca_part_batch_process: one frame of each stream; returns [(list A, list B)] per stream"""
+    n = len(streams)
+    sh = (C.c_void_p * n)(*[s.h for s in streams])
+    fr = (Frame * n)(*[f if isinstance(f, Frame) else make_frame(np.ascontiguousarray(f, np.uint8)) for f in frames])
+    a, b = (Rect * (n * cap))(), (Rect * (n * cap))()
+    na, nb = (C.c_int * n)(), (C.c_int * n)()
+    ctx.check(ctx.L.nvca_part_batch_process(ctx.h, n, sh, fr, a, cap, na, b, cap, nb))
+    A = np.frombuffer(a, dtype=np.int32).reshape(n, cap, 4)
+    B = np.frombuffer(b, dtype=np.int32).reshape(n, cap, 4)
+    return [(A[i, :min(na[i], cap)].copy(), B[i, :min(nb[i], cap)].copy()) for i in range(n)]
 
 
 class PartStream:

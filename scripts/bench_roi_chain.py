@@ -55,3 +55,51 @@ ctx.synchronize()
 dt = time.perf_counter() - t0
 print(("roi chain 1080p, face sizes changing every frame: " if JITTER else "roi chain 1080p: ") + "%.1f frames/s (%.3f ms/frame); faces/frame %.2f, parts/frame %.2f; per element ms: %s" %
       (K / dt, dt / K * 1e3, tot[0] / K, tot[1] / K, {k: round(v / K * 1e3, 3) for k, v in acc.items()}))
+
+
+# ---- the same chain batched: V video streams x (face detector + the four part detectors, own face pass each) per tick,
+# one nvca_face_batch_process + one nvca_part_batch_process call per tick (BASELINE config 3 on several concurrent streams)
+V = 8
+for a in sys.argv:
+    if a.startswith("--streams="):
+        V = int(a.split("=")[1])
+faces_v = [capi.FaceStream(ctx, face_c, width_to_process=W, multi_scale_factor=10) for _ in range(V)]
+kinds = [(0, "righteye", "lefteye"), (1, "nose", None), (2, "mouth", None), (3, "leftear", "rightear")]
+parts_v = [[capi.PartStream(ctx, k, face_c, pc[a], pc[b] if b else None) for k, a, b in kinds] for _ in range(V)]
+flat = [p for row in parts_v for p in row]
+
+
+def tick(i):
+    fb = [fr[(i + 3 * v) % N] for v in range(V)]
+    ctx.face_batch_process(faces_v, fb)
+    res = capi.part_batch_process(ctx, flat, [fb[v] for v in range(V) for _ in range(4)])
+    return sum(len(a) + len(b) for a, b in res)
+
+
+for i in range(3):
+    tick(i)
+K2 = 24
+t0 = time.perf_counter()
+found = 0
+for i in range(K2):
+    found += tick(i)
+ctx.synchronize()
+dt2 = time.perf_counter() - t0
+# a second, separate pass with an event pair around every launch (they serialise the launches: not part of the rate above)
+ctx.enable_kernel_timing(1)
+for i in range(K2):
+    tick(i)
+ctx.synchronize()
+kt = ctx.kernel_timing()
+ctx.enable_kernel_timing(0)
+busy_ms = sum(v[0] for v in kt.values())
+import json
+# algorithmic bytes of the chain per video frame (SURVEY.md 8d formula applied to each working image): the face detector's
+# 60.21 MB plus, per part detector, BGR in + gray out/in + the small working images' integrals
+alg = 60.21e6 + 4 * (3 * W * H + 2 * W * H) + 4 * 25 * (320 * 180 + 160 * 90)
+print(json.dumps({"roi_chain_batched": {"video_streams": V, "frames_per_s": V * K2 / dt2, "ms_per_tick": dt2 / K2 * 1e3, "parts_per_frame": found / (V * K2),
+      "gpu_kernel_ms_per_tick": busy_ms / K2, "gpu_busy_frac": busy_ms / (dt2 * 1e3),
+      "kernel_ms_per_tick": {k: round(v[0] / K2, 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1]},
+      "launch_sets_per_tick": {k: round(v[1] / K2, 1) for k, v in kt.items() if v[1]},
+      "roofline": {"bound": "hbm", "achieved": alg * V * K2 / dt2 / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg * V * K2 / dt2 / 1e9 / 8000.0,
+                   "note": "launch-bound small-image work: %d kernel launches per tick" % int(sum(v[1] for v in kt.values()) / K2)}}}))

@@ -106,6 +106,59 @@ def test_roi_chain_1080p(env):
         assert tot > 0, kind
 
 
+def test_roi_chain_1080p_batched(env):
+    """the same chain through nvca_part_batch_process: four 1080p video streams x the four part detectors = 16 part
+    streams in ONE call per tick (own face pass each), device-resident frames; every stream's lists as if it ran alone"""
+    import torch
+    from nubovca import capi, synth
+    ctx = env[0]
+    V, T = 4, 3
+    kinds = ("eye", "nose", "mouth", "ear")
+    pairs = [[_streams(env, k) for k in kinds] for _ in range(V)]
+    tot = 0
+    for t in range(T):
+        frames = [synth.make_bgr(1920, 1080, 60 + 10 * v + t, "natural", [(300 + 100 * v + 10 * t, 150 + 20 * v, 500 + 30 * v)] if (v + t) % 5 else [])
+                  for v in range(V)]
+        keep = [torch.from_numpy(f).cuda() for f in frames]
+        torch.cuda.synchronize()
+        fr = [capi.make_frame(k.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for k in keep]
+        res = capi.part_batch_process(ctx, [pairs[v][j][0] for v in range(V) for j in range(4)], [fr[v] for v in range(V) for j in range(4)])
+        for v in range(V):
+            for j in range(4):
+                ea, eb = pairs[v][j][1].process(frames[v])
+                ga, gb = res[v * 4 + j]
+                assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (t, v, kinds[j], ga, ea, gb, eb)
+                tot += len(ea) + len(eb)
+    assert tot > 0
+
+
+def test_part_batch_mixed_sizes_and_event_mode(env):
+    """one batched call with streams of different kinds, frame sizes and modes (own face pass / faces pushed by an upstream
+    face detector / gated by process-x-every-4), host frames; five ticks so the merging state takes part"""
+    from nubovca import capi
+    ctx, dev, cpu = env
+    specs = [("eye", 640, 480, {}), ("nose", 800, 600, {}), ("mouth", 640, 480, {"detect_event": 1}), ("ear", 1280, 720, {}),
+             ("eye", 640, 480, {"detect_event": 1}), ("nose", 640, 480, {"process_x_every_4_frames": 2}), ("mouth", 800, 600, {"width_to_process": 400})]
+    pairs = [_streams(env, k, **p) for k, _, _, p in specs]
+    scenes = [_scene(W, H, 5, 1200 + 31 * i, two_faces=(i % 2 == 0)) for i, (_, W, H, _) in enumerate(specs)]
+    fs = [capi.FaceStream(ctx, dev["face"]) for _ in specs]
+    tot = 0
+    for t in range(5):
+        for i, (k, W, H, p) in enumerate(specs):
+            if p.get("detect_event"):
+                boxes, _ = fs[i].process(scenes[i][t])
+                if t % 3 != 2 and len(boxes):
+                    pairs[i][0].push_faces(boxes); pairs[i][1].push_faces(boxes)
+        res = capi.part_batch_process(ctx, [g for g, _ in pairs], [scenes[i][t] for i in range(len(specs))])
+        for i in range(len(specs)):
+            ea, eb = pairs[i][1].process(scenes[i][t])
+            assert np.array_equal(res[i][0], ea) and np.array_equal(res[i][1], eb), (t, i, specs[i][0])
+            tot += len(ea) + len(eb)
+    assert tot > 0
+    with pytest.raises(capi.NvcaError):          # a stream twice in one call
+        capi.part_batch_process(ctx, [pairs[0][0], pairs[0][0]], [scenes[0][0], scenes[0][0]])
+
+
 def test_flip_primitive(env):
     import ctypes as C
     import orc
