@@ -107,16 +107,30 @@ struct ResultBufs {
     std::vector<int> gthr_last;       // thresholds currently resident in gthr
     void release() { hits.release(); grp.release(); gthr.release(); staging.release(); srcptrs.release(); h_hits.release(); h_grp.release(); h_gthr.release(); h_srcptrs.release(); gthr_last.clear(); }
 };
-struct Workspace {
+// Working memory of the kernels, per LANE.  A lane is a HIP stream with its own planes and cascade scratch: whatever runs on a
+// lane is ordered by its stream, different lanes run side by side.  Everything uses lane 0 (the context's stream) except
+// the batched part detectors, which spread their streams' small, launch-bound jobs over all lanes (parts.cpp): the GPU then
+// holds several of those tiny kernels at a time instead of one.  What a job leaves for the host lives in ResultBufs regions
+// of its own, shared by all lanes.
+struct Lane {
     DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, tilted, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
-    ResultBufs res[3];
-    int cur_res = 0;
     int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
         sqsum.release(); tilted.release(); staging.release(); aux.release();
         failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
+    }
+};
+struct Workspace {
+    Lane lanes[kLanes];
+    int *cur_lane = nullptr;          // the context's current lane index
+    Lane &ln() { return lanes[*cur_lane]; }
+    ResultBufs res[3];
+    int cur_res = 0;
+    void release_all()
+    {
+        for (Lane &l : lanes) l.release_all();
         for (ResultBufs &r : res) r.release();
     }
 };
@@ -224,13 +238,13 @@ static int ensure_ws(nvca_ctx *ctx, const PreGeom &g, int batch)
 {
     Workspace &ws = *ctx->ws;
     int e = 0;
-    e |= ws.gray.ensure(g.gray_slot * batch + 64);
-    { void *old = ws.hist.p; e |= ws.hist.ensure((size_t)batch * 256 * sizeof(unsigned)); if (ws.hist.p != old) ws.hist_clean = 0; }
-    e |= ws.lut.ensure((size_t)batch * 256);
-    e |= ws.bandsum.ensure(g.band_slot * batch * sizeof(unsigned));
-    e |= ws.bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
-    e |= ws.sum.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int));      // a few spare rows: a scaled feature corner may round past the window by a pixel or two
-    e |= ws.sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
+    e |= ws.ln().gray.ensure(g.gray_slot * batch + 64);
+    { void *old = ws.ln().hist.p; e |= ws.ln().hist.ensure((size_t)batch * 256 * sizeof(unsigned)); if (ws.ln().hist.p != old) ws.ln().hist_clean = 0; }
+    e |= ws.ln().lut.ensure((size_t)batch * 256);
+    e |= ws.ln().bandsum.ensure(g.band_slot * batch * sizeof(unsigned));
+    e |= ws.ln().bandsq.ensure(g.band_slot * batch * sizeof(unsigned));
+    e |= ws.ln().sum.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int));      // a few spare rows: a scaled feature corner may round past the window by a pixel or two
+    e |= ws.ln().sqsum.ensure(g.sum_slot * batch * sizeof(unsigned long long));
     e |= ws.res[ws.cur_res].srcptrs.ensure((size_t)batch * sizeof(void *));
     e |= ws.res[ws.cur_res].h_srcptrs.ensure((size_t)batch * sizeof(void *));
     if (e) { ctx->set_error("device/pinned allocation failed for the workspace"); return NVCA_ERR_NOMEM; }
@@ -280,15 +294,15 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
                          int *sum = nullptr, unsigned long long *sq = nullptr)
 {
     Workspace &ws = *ctx->ws;
-    if (!gray) gray = ws.gray.as<uint8_t>();
-    if (!sum) sum = ws.sum.as<int>();
-    if (!sq) sq = ws.sqsum.as<unsigned long long>();
+    if (!gray) gray = ws.ln().gray.as<uint8_t>();
+    if (!sum) sum = ws.ln().sum.as<int>();
+    if (!sq) sq = ws.ln().sqsum.as<unsigned long long>();
     { TimedLaunch t(ctx, NVCA_K_COLSUM);
-      launch_colsum(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
+      launch_colsum(ctx->cs(), gray, lut, 256, g, ws.ln().bandsum.as<unsigned>(), ws.ln().bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_BANDSCAN);
-      launch_bandscan(ctx->stream, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), batch); }
+      launch_bandscan(ctx->cs(), g, ws.ln().bandsum.as<unsigned>(), ws.ln().bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
-      launch_integral(ctx->stream, gray, lut, 256, g, ws.bandsum.as<unsigned>(), ws.bandsq.as<unsigned>(), sum, sq, batch); }
+      launch_integral(ctx->cs(), gray, lut, 256, g, ws.ln().bandsum.as<unsigned>(), ws.ln().bandsq.as<unsigned>(), sum, sq, batch); }
 }
 
 // tilted integral planes for `batch` slots (cascades with tilted features only); same geometry and equalisation LUT as run_integral
@@ -297,12 +311,12 @@ static int run_tilted(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int b
     Workspace &ws = *ctx->ws;
     if (g.w + 1 > 8 * 1024 || (size_t)2 * (g.w + g.h + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
     if (!tilted) {
-        if (ws.tilted.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int))) { ctx->set_error("device allocation failed (tilted integral)"); return NVCA_ERR_NOMEM; }
-        tilted = ws.tilted.as<int>();
+        if (ws.ln().tilted.ensure((g.sum_slot * batch + 4 * (size_t)g.spitch) * sizeof(int))) { ctx->set_error("device allocation failed (tilted integral)"); return NVCA_ERR_NOMEM; }
+        tilted = ws.ln().tilted.as<int>();
     }
-    if (!gray) gray = ws.gray.as<uint8_t>();
+    if (!gray) gray = ws.ln().gray.as<uint8_t>();
     TimedLaunch t(ctx, NVCA_K_INTEGRAL);
-    launch_tilted(ctx->stream, gray, lut, 256, g, tilted, batch);
+    launch_tilted(ctx->cs(), gray, lut, 256, g, tilted, batch);
     return NVCA_OK;
 }
 
@@ -330,12 +344,12 @@ static int cascade_counters(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job
     const int total = std::max(job.total, job.r0 + job.n);
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * job.n + 64, 1u << 28);
-    if (ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
+    if (ws.ln().deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
         rb.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || rb.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
         ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
     }
     *hits = rb.hits.as<unsigned long long>() + hits_stride * job.r0;
-    *deep = ws.deep.as<unsigned long long>();
+    *deep = ws.ln().deep.as<unsigned long long>();
     return NVCA_OK;
 }
 
@@ -348,9 +362,9 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;                 // u64 words per result slot
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
     const unsigned deep_cap = (unsigned)std::min<size_t>((size_t)dp.tasks.size() * 64 * batch + 64, 1u << 28);   // every window may survive
-    if (ws.failbits.ensure(dp.tasks.size() * sizeof(unsigned long long) * batch + 8) ||
-        ws.vnf.ensure(dp.tasks.size() * 64 * sizeof(double) * batch + 8) ||
-        ws.deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
+    if (ws.ln().failbits.ensure(dp.tasks.size() * sizeof(unsigned long long) * batch + 8) ||
+        ws.ln().vnf.ensure(dp.tasks.size() * 64 * sizeof(double) * batch + 8) ||
+        ws.ln().deep.ensure(((size_t)deep_cap + 1) * sizeof(unsigned long long)) ||
         rb.hits.ensure(hits_stride * total * sizeof(unsigned long long)) || rb.h_hits.ensure(hits_stride * total * sizeof(unsigned long long))) {
         ctx->set_error("device allocation failed for the cascade workspace"); return NVCA_ERR_NOMEM;
     }
@@ -358,8 +372,8 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
     job.d_hits = rb.hits.as<unsigned long long>() + hits_stride * job.r0;
     job.h_hits = rb.h_hits.as<unsigned long long>() + hits_stride * job.r0;
     if (!job.counters_zeroed) {
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.deep.p, 0, sizeof(unsigned long long), ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().deep.p, 0, sizeof(unsigned long long), ctx->cs()));
     }
     static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
     static const bool host_group = getenv("NVCA_HOST_GROUP") != nullptr;         // keep cv::groupRectangles on the host (A/B testing)
@@ -377,23 +391,23 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         job.d_grp = rb.grp.as<int>() + grp_stride * job.r0; job.h_grp = rb.h_grp.as<int>() + grp_stride * job.r0;
         if (rb.gthr_last.size() < (size_t)total) rb.gthr_last.resize(total, -1);
         if (memcmp(rb.gthr_last.data() + job.r0, group_thr, batch * sizeof(int)) != 0) {
-            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));             // h_gthr may still feed an earlier copy
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));             // h_gthr may still feed an earlier copy
             memcpy(rb.h_gthr.as<int>() + job.r0, group_thr, batch * sizeof(int));
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(rb.gthr.as<int>() + job.r0, rb.h_gthr.as<int>() + job.r0, batch * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(rb.gthr.as<int>() + job.r0, rb.h_gthr.as<int>() + job.r0, batch * sizeof(int), hipMemcpyHostToDevice, ctx->cs()));
             std::copy(group_thr, group_thr + batch, rb.gthr_last.begin() + job.r0);
         }
     }
     if (!dp.tasks.empty() && !skip_cascade) {
         CascadeArgs a;
-        a.sum = ws.sum.as<int>(); a.sqsum = ws.sqsum.as<unsigned long long>();
+        a.sum = ws.ln().sum.as<int>(); a.sqsum = ws.ln().sqsum.as<unsigned long long>();
         a.sum_slot = sum_slot; a.spitch = spitch;
         a.scales = dp.d_scales.as<ScaleRec>();
         a.stages = dp.d_stages.as<StageRec>(); a.strips = dp.d_strips.as<StripRec>(); a.pos = dp.d_pos.as<int>();
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
-        a.failbits = ws.failbits.as<unsigned long long>(); a.vnf = ws.vnf.as<double>();
+        a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
         a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
-        a.deep_stage = dp.deep_stage; a.deep = ws.deep.as<unsigned long long>(); a.deep_cap = deep_cap;
+        a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame;
@@ -403,21 +417,21 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
-        a.tilted = dp.needs_tilted ? ws.tilted.as<int>() : nullptr;
+        a.tilted = dp.needs_tilted ? ws.ln().tilted.as<int>() : nullptr;
         a.galpha = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_galpha; a.gcls_first = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_gcls_first;
         a.stump_based = dp.generic_stumps ? 1 : 0;
         if (dp.generic) {
             // tree weak classifiers / tilted features: stage-0 pre-pass for every window, then the remaining stages on the
             // visited survivors, window per lane (kernels_cascade.hip, "general cascades")
             if (dp.needs_tilted && !a.tilted) { ctx->set_error("internal: tilted integral missing"); return NVCA_ERR_ARG; }
-            { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_generic(ctx->stream, a, batch, 0); }
-            { TimedLaunch t(ctx, NVCA_K_STRIP); launch_generic(ctx->stream, a, batch, 1); }
+            { TimedLaunch t(ctx, NVCA_K_STAGE0); launch_generic(ctx->cs(), a, batch, 0); }
+            { TimedLaunch t(ctx, NVCA_K_STRIP); launch_generic(ctx->cs(), a, batch, 1); }
         } else {
 #ifdef NVCA_STAMPS
         {   // diagnostic build: the stamps of the last band launch are written to $NVCA_STAMPS_OUT when the context synchronises
             static DevBuf dbgbuf;
             a.dbg = nullptr;
-            if (getenv("NVCA_STAMPS_OUT") && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->stream); ctx->stamps = a.dbg; }
+            if (getenv("NVCA_STAMPS_OUT") && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->cs()); ctx->stamps = a.dbg; }
         }
 #endif
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
@@ -425,7 +439,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         const int band_env = band_e ? atoi(band_e) : -1;
         const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 640);     // measured crossover at 1080p: 8 frames (544 bands) equal, 16 frames +20 %
         auto launch = [&](int which) {
-            const int e = launch_cascade_sc(ctx->stream, a, batch, which, ctx->lds_grant);
+            const int e = launch_cascade_sc(ctx->cs(), a, batch, which, ctx->lds_grant);
             if (e) ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e));
             return e;
         };
@@ -439,15 +453,15 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
                 std::vector<unsigned> off(dp.scales.size());
                 for (size_t i = 0; i < off.size(); i++) off[i] = dp.list_off[i] * (unsigned)batch;
                 if (dp.d_list_off.ensure(sizeof(unsigned) * 64)) { ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM; }
-                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
                 NVCA_HIP_CHECK(ctx, hipMemcpy(dp.d_list_off.p, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
                 dp.list_off_batch = batch;
             }
-            if (ws.list_cnt.ensure(sizeof(unsigned) * 64 * (dp.stages.size() + 1)) || ws.list_ent.ensure(sizeof(unsigned) * 2 * cap_l + 64)) {
+            if (ws.ln().list_cnt.ensure(sizeof(unsigned) * 64 * (dp.stages.size() + 1)) || ws.ln().list_ent.ensure(sizeof(unsigned) * 2 * cap_l + 64)) {
                 ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM;
             }
-            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.list_cnt.p, 0, sizeof(unsigned) * 64 * (dp.stages.size() + 1), ctx->stream));
-            a.list_cnt = ws.list_cnt.as<unsigned>(); a.list_ent = ws.list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
+            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().list_cnt.p, 0, sizeof(unsigned) * 64 * (dp.stages.size() + 1), ctx->cs()));
+            a.list_cnt = ws.ln().list_cnt.as<unsigned>(); a.list_ent = ws.ln().list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
             a.list_cap = (unsigned)cap_l; a.list_from = dp.list_from;
             TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(4)) return NVCA_ERR_HIP;
         } else if (use_band) {
@@ -460,16 +474,16 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         }
         // the box tables are small (a few KB per frame): the grouping kernel stores them straight into the page-locked host
         // buffer (plain stores, visible to the host once the stream has drained) -- no copy operation behind the last kernel
-        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->stream, a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
+        if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->cs(), a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
     }
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     if (dev_group && grp_zero_copy) {
         // nothing to copy: k_group wrote the host buffer
     } else if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, (rec * batch + 2) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_grp, job.d_grp, (rec * batch + 2) * sizeof(int), hipMemcpyDeviceToHost, ctx->cs()));
     } else {              // one D2H covers the count and (almost always) every candidate
         job.first = std::min<size_t>(cap, 2048);
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, (job.first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(job.h_hits, job.d_hits, (job.first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->cs()));
     }
     return NVCA_OK;
 }
@@ -491,7 +505,7 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
     const unsigned long long total = hh[0];
     if (hostprof) {
         unsigned long long dc = 0;
-        (void)hipMemcpy(&dc, ctx->ws->deep.p, sizeof(dc), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&dc, ctx->ws->ln().deep.p, sizeof(dc), hipMemcpyDeviceToHost);
         fprintf(stderr, "[nvca host] deep windows (last job) %llu, raw candidates %llu (job of %d)\n", dc, total, batch);
     }
     if (total > job.cap) {
@@ -514,8 +528,8 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
     }
     if (total > have) {
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + have, job.d_hits + 1 + have, (total - have) * sizeof(unsigned long long),
-                                           hipMemcpyDeviceToHost, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                           hipMemcpyDeviceToHost, ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     }
     std::sort(hh + 1, hh + 1 + total);
     for (unsigned long long i = 0; i < total; i++) {
@@ -535,7 +549,7 @@ static int run_cascade(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitc
     CascadeJob job; job.n = batch; job.total = batch;
     int rc = cascade_enqueue(ctx, dp, sum_slot, spitch, job, group_thr, grouped != nullptr);
     if (rc) return rc;
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer(ctx);
     return cascade_collect(ctx, dp, job, raw, grouped, scale_of);
 }
@@ -553,7 +567,7 @@ static int stage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, si
 {
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                                         ctx->stream));
+                                         ctx->cs()));
     return NVCA_OK;
 }
 static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
@@ -561,9 +575,9 @@ static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, 
 {
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                                         ctx->stream));
+                                         ctx->cs()));
     if (mem == NVCA_MEM_DEVICE && ctx->defer_device_sync > 0) return NVCA_OK;   // consumer is queued on the same stream
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer(ctx);
     return NVCA_OK;
 }
@@ -573,7 +587,7 @@ static int finish_device_op(nvca_ctx *ctx)
 {
     NVCA_HIP_CHECK(ctx, hipGetLastError());
     if (ctx->defer_device_sync > 0) return NVCA_OK;
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer(ctx);
     return NVCA_OK;
 }
@@ -588,15 +602,17 @@ static GeomPlan *find_plan(nvca_ctx *ctx, const std::string &key)
 
 // Plans are cached per (cascade, geometry).  ROI-driven callers (the part detectors) ask for ever new geometries, so the
 // cache is bounded: beyond kMaxPlans the least recently used plan goes (its device tables are idle: the stream is drained).
-static constexpr size_t kMaxPlans = 96;
+static constexpr size_t kMaxPlans = 1024;
 static GeomPlan *store_plan(nvca_ctx *ctx, const std::string &key, std::unique_ptr<GeomPlan> gp)
 {
     if (ctx->plans.size() >= kMaxPlans) {
-        (void)hipStreamSynchronize(ctx->stream);
-        auto victim = ctx->plans.end();
-        for (auto it = ctx->plans.begin(); it != ctx->plans.end(); ++it)
-            if (it->second->inflight == 0 && (victim == ctx->plans.end() || it->second->last_use < victim->second->last_use)) victim = it;
-        if (victim != ctx->plans.end()) ctx->plans.erase(victim);
+        // kernels that read a victim's tables may still be queued on any lane: drain the device once, then drop the least
+        // recently used quarter in one go (ROI-driven callers would otherwise pay the drain for every new geometry)
+        (void)hipDeviceSynchronize();
+        std::vector<std::pair<uint64_t, std::string>> order;
+        for (auto &kv : ctx->plans) if (kv.second->inflight == 0) order.emplace_back(kv.second->last_use, kv.first);
+        std::sort(order.begin(), order.end());
+        for (size_t i = 0; i < order.size() && i < kMaxPlans / 4; i++) ctx->plans.erase(order[i].second);
     }
     gp->last_use = ++ctx->next_uid;
     GeomPlan *p = gp.get();
@@ -647,6 +663,7 @@ nvca_ctx::~nvca_ctx()
     for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
     for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    for (int l = 1; l < nvca::kLanes; l++) if (lane_streams[l]) (void)hipStreamDestroy(lane_streams[l]);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -666,8 +683,12 @@ int nvca_ctx_create(int device_id, nvca_ctx **out)
     if (!ctx) return NVCA_ERR_NOMEM;
     ctx->device = device_id;
     ctx->ws.reset(new Workspace());
+    ctx->ws->cur_lane = &ctx->cur_lane;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NVCA_ERR_HIP; }
+    ctx->lane_streams[0] = ctx->stream;
+    for (int l = 1; l < kLanes; l++)
+        if (hipStreamCreateWithFlags(&ctx->lane_streams[l], hipStreamNonBlocking) != hipSuccess) { delete ctx; return NVCA_ERR_HIP; }
     *out = ctx;
     return NVCA_OK;
 }
@@ -676,7 +697,7 @@ void nvca_ctx_destroy(nvca_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     delete ctx;
 }
 
@@ -698,7 +719,7 @@ int nvca_ctx_synchronize(nvca_ctx *ctx)
 {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
 #ifdef NVCA_STAMPS
     if (ctx->stamps && getenv("NVCA_STAMPS_OUT")) {
         std::vector<unsigned long long> h(64 * 16 * 64);
@@ -723,7 +744,7 @@ int nvca_host_unregister(nvca_ctx *ctx, void *ptr)
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ptr) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     NVCA_HIP_CHECK(ctx, hipHostUnregister(ptr));
     return NVCA_OK;
 }
@@ -732,7 +753,7 @@ int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
 {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->cs());
     drain_timer(ctx);
     ctx->timer.on = on != 0;
     ctx->timer.stride = on > 1 ? on : 1; ctx->timer.seq[0] = ctx->timer.seq[1] = 0; ctx->timer.sample = true;
@@ -743,7 +764,7 @@ int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
 {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer_now(ctx);
     for (int k = 0; k < NVCA_K_COUNT; k++) {
         if (total_ms) total_ms[k] = ctx->timer.total_ms[k];
@@ -876,7 +897,7 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
     static const bool sparse_off = getenv("NVCA_SPARSE_INGEST") && atoi(getenv("NVCA_SPARSE_INGEST")) == 0;
     if (sparse_off || (rows && !rows->on)) rows = nullptr;
     Workspace &ws = *ctx->ws;
-    if (!st) st = ctx->stream;
+    if (!st) st = ctx->cs();
     if (!off_io) {           // stand-alone call: size the buffers here
         if (ws.res[ws.cur_res].srcptrs.ensure((size_t)(r0 + n) * sizeof(void *)) || ws.res[ws.cur_res].h_srcptrs.ensure((size_t)(r0 + n) * sizeof(void *))) {
             ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM;
@@ -944,15 +965,15 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     ResultBufs &rb = ws.res[ws.cur_res];
     if (rb.srcptrs.ensure(kPtrRing * sizeof(void *)) || rb.h_srcptrs.ensure(kPtrRing * sizeof(void *))) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
     if (ctx->defer_device_sync > 0 && ++ctx->ptr_ring_used >= kPtrRing) {       // a full turn without a drain: drain once
-        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipDeviceSynchronize());
         ctx->ptr_ring_used = 0;
     }
     const int slot = ctx->defer_device_sync > 0 ? ctx->ptr_ring_used : 0;
     if ((rc = stage_frames(ctx, &f, nullptr, 1, channels, slot))) return rc;
     { TimedLaunch t(ctx, NVCA_K_GRAY);
-      launch_gray(ctx->stream, rb.srcptrs.as<const uint8_t *>() + slot, g, 0, nullptr, nullptr, nullptr, nullptr, w,
-                  ctx->ws->gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
-    return unstage_2d(ctx, dst, dst_stride, ctx->ws->gray.p, g.gpitch, w, h, mem);
+      launch_gray(ctx->cs(), rb.srcptrs.as<const uint8_t *>() + slot, g, 0, nullptr, nullptr, nullptr, nullptr, w,
+                  ctx->ws->ln().gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
+    return unstage_2d(ctx, dst, dst_stride, ctx->ws->ln().gray.p, g.gpitch, w, h, mem);
 }
 
 // resize coefficient tables for (source size -> destination size), cached with the other plans
@@ -979,14 +1000,14 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
         (void)hipSetDevice(ctx->device);
         Workspace &w3 = *ctx->ws;
         const size_t sp = round_up((size_t)sw * 3, 64), dp3 = round_up((size_t)dw * 3, 64);
-        if (w3.staging.ensure(sp * sh + 64) || w3.aux.ensure(dp3 * dh + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
-        if ((rc3 = stage_2d(ctx, w3.staging.p, sp, src, sstride, (size_t)sw * 3, sh, mem))) return rc3;
+        if (w3.ln().staging.ensure(sp * sh + 64) || w3.ln().aux.ensure(dp3 * dh + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+        if ((rc3 = stage_2d(ctx, w3.ln().staging.p, sp, src, sstride, (size_t)sw * 3, sh, mem))) return rc3;
         GeomPlan *gp3 = nullptr;
         if ((rc3 = get_resize_plan(ctx, sw, sh, dw, dh, &gp3))) return rc3;
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-          launch_resize3(ctx->stream, w3.staging.as<uint8_t>(), sw, sh, (int)sp, gp3->tab.mode, gp3->d_xofs.as<int>(), gp3->d_ialpha.as<short>(),
-                         gp3->d_yofs.as<int>(), gp3->d_ibeta.as<short>(), gp3->tab.xmax, w3.aux.as<uint8_t>(), dw, dh, (int)dp3); }
-        return unstage_2d(ctx, dst, dstride, w3.aux.p, dp3, (size_t)dw * 3, dh, mem);
+          launch_resize3(ctx->cs(), w3.ln().staging.as<uint8_t>(), sw, sh, (int)sp, gp3->tab.mode, gp3->d_xofs.as<int>(), gp3->d_ialpha.as<short>(),
+                         gp3->d_yofs.as<int>(), gp3->d_ibeta.as<short>(), gp3->tab.xmax, w3.ln().aux.as<uint8_t>(), dw, dh, (int)dp3); }
+        return unstage_2d(ctx, dst, dstride, w3.ln().aux.p, dp3, (size_t)dw * 3, dh, mem);
     }
     if (channels != 1) return NVCA_ERR_ARG;
     int rc = check_img(ctx, src, sw, sh, sstride, 1, mem);
@@ -999,19 +1020,19 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
     if ((rc = get_resize_plan(ctx, sw, sh, dw, dh, &gp))) return rc;
     if (mem == NVCA_MEM_DEVICE) {          // device images are read and written in place (ordered on the context's stream)
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-          launch_resize1(ctx->stream, (const uint8_t *)src, sw, sh, sstride, gp->tab.mode, gp->d_xofs.as<int>(),
+          launch_resize1(ctx->cs(), (const uint8_t *)src, sw, sh, sstride, gp->tab.mode, gp->d_xofs.as<int>(),
                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
                          (uint8_t *)dst, dw, dh, dstride, nullptr); }
         return finish_device_op(ctx);
     }
     if ((rc = ensure_ws(ctx, gs, 1)) || (rc = ensure_ws(ctx, gd, 1))) return rc;
-    if (ws.aux.ensure(gd.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
-    if ((rc = stage_2d(ctx, ws.gray.p, gs.gpitch, src, sstride, sw, sh, mem))) return rc;
+    if (ws.ln().aux.ensure(gd.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.ln().gray.p, gs.gpitch, src, sstride, sw, sh, mem))) return rc;
     { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-      launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), sw, sh, gs.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
+      launch_resize1(ctx->cs(), ws.ln().gray.as<uint8_t>(), sw, sh, gs.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
                      gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
-                     ws.aux.as<uint8_t>(), dw, dh, gd.gpitch, nullptr); }
-    return unstage_2d(ctx, dst, dstride, ws.aux.p, gd.gpitch, dw, dh, mem);
+                     ws.ln().aux.as<uint8_t>(), dw, dh, gd.gpitch, nullptr); }
+    return unstage_2d(ctx, dst, dstride, ws.ln().aux.p, gd.gpitch, dw, dh, mem);
 }
 
 int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
@@ -1024,19 +1045,19 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
     if (mem == NVCA_MEM_DEVICE) {          // histogram of the caller's image, LUT applied straight into the destination (in place allowed)
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
-        { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->stream, (const uint8_t *)src, w, h, stride, ws.hist.as<unsigned>()); }
-        { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1, 1); }
-        launch_apply_lut(ctx->stream, (const uint8_t *)src, w, h, stride, ws.lut.as<uint8_t>(), (uint8_t *)dst, dst_stride);
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().hist.p, 0, 256 * sizeof(unsigned), ctx->cs()));
+        { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->cs(), (const uint8_t *)src, w, h, stride, ws.ln().hist.as<unsigned>()); }
+        { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), ws.ln().hist.as<unsigned>(), w * h, ws.ln().lut.as<uint8_t>(), 1, 1); }
+        launch_apply_lut(ctx->cs(), (const uint8_t *)src, w, h, stride, ws.ln().lut.as<uint8_t>(), (uint8_t *)dst, dst_stride);
         return finish_device_op(ctx);
     }
-    if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
-    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
-    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, 256 * sizeof(unsigned), ctx->stream));
-    { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.hist.as<unsigned>()); }
-    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->stream, ws.hist.as<unsigned>(), w * h, ws.lut.as<uint8_t>(), 1, 1); }   // slot 0 left zeroed again
-    launch_apply_lut(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.lut.as<uint8_t>(), ws.aux.as<uint8_t>(), g.gpitch);
-    return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
+    if (ws.ln().aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.ln().gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().hist.p, 0, 256 * sizeof(unsigned), ctx->cs()));
+    { TimedLaunch t(ctx, NVCA_K_GRAY); launch_hist(ctx->cs(), ws.ln().gray.as<uint8_t>(), w, h, g.gpitch, ws.ln().hist.as<unsigned>()); }
+    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), ws.ln().hist.as<unsigned>(), w * h, ws.ln().lut.as<uint8_t>(), 1, 1); }   // slot 0 left zeroed again
+    launch_apply_lut(ctx->cs(), ws.ln().gray.as<uint8_t>(), w, h, g.gpitch, ws.ln().lut.as<uint8_t>(), ws.ln().aux.as<uint8_t>(), g.gpitch);
+    return unstage_2d(ctx, dst, dst_stride, ws.ln().aux.p, g.gpitch, w, h, mem);
 }
 
 int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
@@ -1048,14 +1069,14 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int strid
     Workspace &ws = *ctx->ws;
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
     if (mem == NVCA_MEM_DEVICE && src != dst) {
-        launch_flip_h(ctx->stream, (const uint8_t *)src, w, h, stride, (uint8_t *)dst, dst_stride);
+        launch_flip_h(ctx->cs(), (const uint8_t *)src, w, h, stride, (uint8_t *)dst, dst_stride);
         return finish_device_op(ctx);
     }
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
-    if (ws.aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
-    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
-    launch_flip_h(ctx->stream, ws.gray.as<uint8_t>(), w, h, g.gpitch, ws.aux.as<uint8_t>(), g.gpitch);
-    return unstage_2d(ctx, dst, dst_stride, ws.aux.p, g.gpitch, w, h, mem);
+    if (ws.ln().aux.ensure(g.gray_slot + 64)) { ctx->set_error("allocation failed"); return NVCA_ERR_NOMEM; }
+    if ((rc = stage_2d(ctx, ws.ln().gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    launch_flip_h(ctx->cs(), ws.ln().gray.as<uint8_t>(), w, h, g.gpitch, ws.ln().aux.as<uint8_t>(), g.gpitch);
+    return unstage_2d(ctx, dst, dst_stride, ws.ln().aux.p, g.gpitch, w, h, mem);
 }
 
 int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *sum, double *sqsum)
@@ -1068,16 +1089,16 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     Workspace &ws = *ctx->ws;
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    if ((rc = stage_2d(ctx, ws.ln().gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
     run_integral(ctx, g, nullptr, 1);
-    rc = unstage_2d(ctx, sum, (size_t)(w + 1) * 4, ws.sum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+    rc = unstage_2d(ctx, sum, (size_t)(w + 1) * 4, ws.ln().sum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
     if (rc) return rc;
     if (sqsum) {                                       // device layout: u32 low-word plane, then u8 high-byte plane
         const size_t n = (size_t)(w + 1) * (h + 1);
         std::vector<unsigned> lo(n); std::vector<uint8_t> hi(n);
-        rc = unstage_2d(ctx, lo.data(), (size_t)(w + 1) * 4, ws.sqsum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+        rc = unstage_2d(ctx, lo.data(), (size_t)(w + 1) * 4, ws.ln().sqsum.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
         if (rc) return rc;
-        rc = unstage_2d(ctx, hi.data(), (size_t)(w + 1), ws.sqsum.as<unsigned>() + g.sum_slot, (size_t)g.spitch, (size_t)(w + 1), h + 1, NVCA_MEM_HOST);
+        rc = unstage_2d(ctx, hi.data(), (size_t)(w + 1), ws.ln().sqsum.as<unsigned>() + g.sum_slot, (size_t)g.spitch, (size_t)(w + 1), h + 1, NVCA_MEM_HOST);
         if (rc) return rc;
         for (size_t i = 0; i < n; i++) sqsum[i] = (double)(((unsigned long long)hi[i] << 32) | lo[i]);
     }
@@ -1094,9 +1115,9 @@ int nvca_integral_tilted(nvca_ctx *ctx, const void *src, int w, int h, int strid
     Workspace &ws = *ctx->ws;
     PreGeom g; make_geom(g, w, h, stride, 1, w, h);
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ws.gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
+    if ((rc = stage_2d(ctx, ws.ln().gray.p, g.gpitch, src, stride, w, h, mem))) return rc;
     if ((rc = run_tilted(ctx, g, nullptr, 1))) return rc;
-    return unstage_2d(ctx, tilted, (size_t)(w + 1) * 4, ws.tilted.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
+    return unstage_2d(ctx, tilted, (size_t)(w + 1) * 4, ws.ln().tilted.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
 }
 
 // =========================================================================
@@ -1233,39 +1254,39 @@ static int si_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
     const size_t gray_total = pp->gray_total, plane_total = pp->plane_total;
     PreGeom g0; make_geom(g0, cols, rows, j.stride, 1, cols, rows);
     if ((rc = ensure_ws(ctx, g0, nimg))) return rc;
-    if (ws.aux.ensure(gray_total * nimg + 64) || ws.sum.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)) || ws.sqsum.ensure(plane_total * nimg * sizeof(unsigned long long)) ||
-        (c.has_tilted && ws.tilted.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)))) {
+    if (ws.ln().aux.ensure(gray_total * nimg + 64) || ws.ln().sum.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)) || ws.ln().sqsum.ensure(plane_total * nimg * sizeof(unsigned long long)) ||
+        (c.has_tilted && ws.ln().tilted.ensure((plane_total * nimg + 4 * (size_t)P) * sizeof(int)))) {
         ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
     }
     if (c.has_tilted && (size_t)2 * (pp->pyr_maxw + pp->pyr_maxh + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
     for (int k = 0; k < nimg; k++)
-        if ((rc = stage_2d(ctx, ws.gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, j.img[k], j.stride, cols, rows, j.mem))) return rc;
+        if ((rc = stage_2d(ctx, ws.ln().gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, j.img[k], j.stride, cols, rows, j.mem))) return rc;
     if (pp->pyr_ok) {            // all levels of all images: one resize launch, one integral launch
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-          launch_pyr_resize(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, g0.gray_slot, pp->d_pyr.as<PyrLevelDev>(),
-                            (int)pp->lv.size(), nimg, pp->pyr_maxw, pp->pyr_maxh, ws.aux.as<uint8_t>(), gray_total); }
+          launch_pyr_resize(ctx->cs(), ws.ln().gray.as<uint8_t>(), cols, rows, g0.gpitch, g0.gray_slot, pp->d_pyr.as<PyrLevelDev>(),
+                            (int)pp->lv.size(), nimg, pp->pyr_maxw, pp->pyr_maxh, ws.ln().aux.as<uint8_t>(), gray_total); }
         { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
-          launch_pyr_integral(ctx->stream, ws.aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
-                              ws.sum.as<int>(), ws.sqsum.as<unsigned>(), plane_total, P); }
+          launch_pyr_integral(ctx->cs(), ws.ln().aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
+                              ws.ln().sum.as<int>(), ws.ln().sqsum.as<unsigned>(), plane_total, P); }
         if (c.has_tilted) {          // cvIntegral(&img1, &sum1, &sqsum1, _tilted) per level
             TimedLaunch t(ctx, NVCA_K_INTEGRAL);
-            launch_pyr_tilted(ctx->stream, ws.aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
-                              ws.tilted.as<int>(), plane_total, P, pp->pyr_maxw, pp->pyr_maxh);
+            launch_pyr_tilted(ctx->cs(), ws.ln().aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
+                              ws.ln().tilted.as<int>(), plane_total, P, pp->pyr_maxw, pp->pyr_maxh);
         }
     } else
     for (size_t li = 0; li < pp->lv.size(); li++) {
         const PyrLevel &L = pp->lv[li];
         GeomPlan *gp = pp->level_tabs[li].get();
-        uint8_t *lg = ws.aux.as<uint8_t>() + L.gray_off;
+        uint8_t *lg = ws.ln().aux.as<uint8_t>() + L.gray_off;
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);               // cvResize(img, &img1, CV_INTER_LINEAR)
-          launch_resize1(ctx->stream, ws.gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
+          launch_resize1(ctx->cs(), ws.ln().gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax, lg, L.szw,
                          L.szh, L.gpitch, nullptr, nimg, g0.gray_slot, gray_total); }
         PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
-        run_integral(ctx, g, nullptr, nimg, lg, ws.sum.as<int>() + L.plane_off,
-                     (unsigned long long *)(ws.sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
-        if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, nimg, lg, ws.tilted.as<int>() + L.plane_off))) return rc;
+        run_integral(ctx, g, nullptr, nimg, lg, ws.ln().sum.as<int>() + L.plane_off,
+                     (unsigned long long *)(ws.ln().sqsum.as<unsigned>() + L.plane_off));     // lo plane of the level; hi plane at + plane_total
+        if (c.has_tilted && (rc = run_tilted(ctx, g, nullptr, nimg, lg, ws.ln().tilted.as<int>() + L.plane_off))) return rc;
     }
     j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = nimg; j.cj.total = total;
     if ((rc = cascade_enqueue(ctx, pp->det, plane_total, P, j.cj, nullptr, false))) return rc;
@@ -1280,7 +1301,7 @@ static int plain_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
     int rc;
     if ((rc = get_face_plan(ctx, j.casc, j.cols, j.rows, j.stride, 1, j.cols, j.rows, j.sf, j.minw, j.minh, j.maxw, j.maxh, &gp))) return rc;
     if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ctx->ws->gray.p, gp->g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->ln().gray.p, gp->g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
     run_integral(ctx, gp->g, nullptr, 1);
     if (j.casc->c.has_tilted && (rc = run_tilted(ctx, gp->g, nullptr, 1))) return rc;
     j.gthr = (!j.raw_only && j.min_neighbors != 0) ? std::max(j.min_neighbors, 1) : 0;
@@ -1300,7 +1321,7 @@ static int fb_stage_image(nvca_ctx *ctx, const DetectJob &j, PreGeom &g)
     make_geom(g, j.cols, j.rows, j.stride, 1, j.cols, j.rows);
     int rc;
     if ((rc = ensure_ws(ctx, g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ctx->ws->gray.p, g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
+    if ((rc = stage_2d(ctx, ctx->ws->ln().gray.p, g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
     run_integral(ctx, g, nullptr, 1);
     if (j.casc->c.has_tilted && (rc = run_tilted(ctx, g, nullptr, 1))) return rc;
     return NVCA_OK;
@@ -1477,28 +1498,40 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     return NVCA_OK;
 }
 
-// run a set of detectMultiScale calls to completion: one wait per round for all of them
-int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n)
+// run a set of detectMultiScale calls to completion: one wait per round for all of them.  lanes (optional, [n]): the lane
+// each job runs on -- jobs of one lane execute in order, lanes side by side
+int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
 {
+    const int lane0 = ctx->cur_lane;
+    struct Restore { nvca_ctx *c; int l; ~Restore() { c->cur_lane = l; } } restore{ctx, lane0};
     for (;;) {
         int total = 0;
         for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) total += jobs[i]->slots();
         if (!total) return NVCA_OK;
         int r0 = 0, rc = NVCA_OK;
+        bool used[kLanes] = {false};
         for (int i = 0; i < n && !rc; i++) {
             if (jobs[i]->phase == 3) continue;
+            ctx->cur_lane = lanes ? lanes[i] : lane0;
+            used[ctx->cur_lane] = true;
             rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
             r0 += jobs[i]->slots();
         }
-        const hipError_t he = hipStreamSynchronize(ctx->stream);
-        if (he != hipSuccess && !rc) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); rc = NVCA_ERR_HIP; }
+        for (int l = 0; l < kLanes; l++) {
+            if (!used[l]) continue;
+            const hipError_t he = hipStreamSynchronize(ctx->lane_streams[l]);
+            if (he != hipSuccess && !rc) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); rc = NVCA_ERR_HIP; }
+        }
+        ctx->cur_lane = lane0;
         drain_timer(ctx);
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
             if (rc) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; continue; }
+            ctx->cur_lane = lanes ? lanes[i] : lane0;
             const int r = detect_job_advance(ctx, *jobs[i]);
             if (r) rc = r;
         }
+        ctx->cur_lane = lane0;
         if (rc) {
             for (int i = 0; i < n; i++) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; }
             return rc;
@@ -1516,7 +1549,7 @@ int nvca::detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const
     DetectJob j; j.kind = 1; j.casc = casc; j.img[0] = img_a; j.img[1] = img_b; j.nimg = 2; j.cols = w; j.rows = h; j.stride = stride; j.mem = mem;
     j.sf = sf; j.min_neighbors = min_neighbors; j.minw = minw; j.minh = minh; j.maxw = w; j.maxh = h;
     DetectJob *jp = &j;
-    const int rc = run_detect_jobs(ctx, &jp, 1);
+    const int rc = run_detect_jobs(ctx, &jp, 1, nullptr);
     if (rc) return rc;
     outs[0].swap(j.out[0]); outs[1].swap(j.out[1]);
     return NVCA_OK;
@@ -1557,7 +1590,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
     int rc = make_detect_job(ctx, j, casc, gray, w, h, stride, mem, sf, min_neighbors, flags, minw, minh, maxw, maxh, raw_only);
     if (rc) return rc;
     DetectJob *jp = &j;
-    if ((rc = run_detect_jobs(ctx, &jp, 1))) return rc;
+    if ((rc = run_detect_jobs(ctx, &jp, 1, nullptr))) return rc;
     out.swap(j.out[0]);
     return NVCA_OK;
 }
@@ -1788,41 +1821,41 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         std::vector<CascadeJob> &jobs = grp.jobs;
         for (int s0 = 0; s0 < batch; s0 += chunk) {
             const int nc = std::min(chunk, batch - s0);
-            if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->stream, &stage_off, &gp->rowcopy))) return rc;
+            if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->cs(), &stage_off, &gp->rowcopy))) return rc;
             if (piped) {
                 while (ctx->chunk_events.size() <= jobs.size()) {
                     hipEvent_t ev; NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                     ctx->chunk_events.push_back(ev);
                 }
                 NVCA_HIP_CHECK(ctx, hipEventRecord(ctx->chunk_events[jobs.size()], ctx->copy_stream));
-                NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->chunk_events[jobs.size()], 0));
+                NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->cs(), ctx->chunk_events[jobs.size()], 0));
             }
-            int hist_clean = ws.hist_clean;                                // k_lut leaves the histograms it read zeroed again
+            int hist_clean = ws.ln().hist_clean;                                // k_lut leaves the histograms it read zeroed again
             if (hist_clean < nc) {
-                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.hist.p, 0, (size_t)nc * 256 * sizeof(unsigned), ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().hist.p, 0, (size_t)nc * 256 * sizeof(unsigned), ctx->cs()));
                 hist_clean = nc;
             }
-            ws.hist_clean = 0;                                             // dirty until the LUT kernel is queued
+            ws.ln().hist_clean = 0;                                             // dirty until the LUT kernel is queued
             CascadeJob job; job.r0 = gbase + s0; job.n = nc; job.total = n;
             unsigned long long *z_hits = nullptr, *z_deep = nullptr;
             if ((rc = cascade_counters(ctx, gp->det, job, &z_hits, &z_deep))) return rc;
             { TimedLaunch t(ctx, NVCA_K_GRAY);                             // cv::resize + cvtColor :805-806 (+ histogram)
-              launch_gray(ctx->stream, ws.res[ws.cur_res].srcptrs.as<const uint8_t *>() + gbase + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
+              launch_gray(ctx->cs(), ws.res[ws.cur_res].srcptrs.as<const uint8_t *>() + gbase + s0, gp->g, gp->tab.mode, gp->d_xofs.as<int>(),
                           gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax,
-                          ws.gray.as<uint8_t>(), ws.hist.as<unsigned>(), nc, frames_aligned4(frames, idx.data() + s0, nc)); }
+                          ws.ln().gray.as<uint8_t>(), ws.ln().hist.as<unsigned>(), nc, frames_aligned4(frames, idx.data() + s0, nc)); }
             { TimedLaunch t(ctx, NVCA_K_LUT);                              // equalizeHist :807 (applied inside the integral pass)
-              launch_lut(ctx->stream, ws.hist.as<unsigned>(), cols * rows, ws.lut.as<uint8_t>(), nc, 1, z_hits, z_deep); }
+              launch_lut(ctx->cs(), ws.ln().hist.as<unsigned>(), cols * rows, ws.ln().lut.as<uint8_t>(), nc, 1, z_hits, z_deep); }
             job.counters_zeroed = true;
-            ws.hist_clean = hist_clean;
-            run_integral(ctx, gp->g, ws.lut.as<uint8_t>(), nc);
-            if (streams[idx[0]]->cascade->c.has_tilted && (rc = run_tilted(ctx, gp->g, ws.lut.as<uint8_t>(), nc))) return rc;
+            ws.ln().hist_clean = hist_clean;
+            run_integral(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc);
+            if (streams[idx[0]]->cascade->c.has_tilted && (rc = run_tilted(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc))) return rc;
             if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
             jobs.push_back(job);
         }
         gbase += batch;
     }
     if (!tk.done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
-    NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->stream));
+    NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->cs()));
     tk.pending = true;
     gates.armed = false;
     return NVCA_OK;
@@ -1909,7 +1942,7 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
                     if (s == streams[i]) { ctx->set_error("a stream of this batch has a submitted batch in flight: collect it first"); return NVCA_ERR_ARG; }
     FaceTicket &tk = ticket_slot(ctx, 0);
     int rc = face_submit(ctx, n, streams, frames, 0, tk);
-    if (rc) { (void)hipStreamSynchronize(ctx->stream); face_release(tk); return rc; }
+    if (rc) { (void)hipStreamSynchronize(ctx->cs()); face_release(tk); return rc; }
     return face_collect(ctx, 0, tk, out, ids, cap, n_out);
 }
 
@@ -1926,7 +1959,7 @@ int nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *stream
     FaceTicket &tk = ticket_slot(ctx, k);
     tk.serial = ++ctx->face_serial;
     int rc = face_submit(ctx, n, streams, frames, k, tk);
-    if (rc) { (void)hipStreamSynchronize(ctx->stream); face_release(tk); return rc; }
+    if (rc) { (void)hipStreamSynchronize(ctx->cs()); face_release(tk); return rc; }
     *ticket = k;
     return NVCA_OK;
 }

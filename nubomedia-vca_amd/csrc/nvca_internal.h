@@ -205,9 +205,14 @@ struct KernelTimer {
 
 struct nvca_cascade { nvca::Cascade c; nvca_ctx *ctx; };
 
+namespace nvca { static constexpr int kLanes = 8; }
+
 struct nvca_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // lane 0
+    hipStream_t lane_streams[nvca::kLanes] = {nullptr};   // [0] == stream; the others carry the batched part detectors' jobs (api.cpp, Lane)
+    int cur_lane = 0;
+    hipStream_t cs() const { return lane_streams[cur_lane]; }       // the stream of the lane that is being queued on
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
     nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect
@@ -359,7 +364,7 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
 struct DetectJob;
 int make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
                     double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only);
-int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n);
+int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes);      // lanes: per job, or null (current lane)
 DetectJob *detect_job_new();
 void detect_job_free(DetectJob *j);
 const std::vector<nvca_rect> &detect_job_out(const DetectJob *j, int k);

@@ -257,12 +257,16 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     struct Defer { nvca_ctx *c; Defer(nvca_ctx *x) : c(x) { c->defer_device_sync++; } ~Defer() { c->defer_device_sync--; } } defer(ctx);
     std::vector<PartWork> work(n);
     std::vector<DetectJob *> jobs;
+    std::vector<int> job_lane;
+    // stream i's image chain and searches run on lane i mod kLanes: in order on that lane, side by side with the other lanes
+    struct LaneGuard { nvca_ctx *c; ~LaneGuard() { c->cur_lane = 0; } } lane_guard{ctx};
     int rc = NVCA_OK;
     const int D = NVCA_MEM_DEVICE;
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
     // ---- phase 1: gating, image chains and face passes of every stream, in stream order
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
+        ctx->cur_lane = n > 1 ? i % kLanes : 0;
         nvca_part_stream *s = w.s = streams[i]; const nvca_frame *f = w.f = &frames[i];
         const int kind = s->p.kind, W = w.W = f->width, H = w.H = f->height;
         // conf_images: float arithmetic (EYE/kmseyedetect.cpp:331-339 and siblings)
@@ -296,7 +300,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         const void *src = f->data; const int sstride = f->stride;
         if (f->mem == NVCA_MEM_HOST) {
             if (s->d_frame.ensure((size_t)f->stride * H + 64)) { ctx->set_error("part stream: allocation failed"); return NVCA_ERR_NOMEM; }
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(s->d_frame.p, f->data, (size_t)f->stride * (H - 1) + (size_t)W * 3, hipMemcpyHostToDevice, ctx->stream));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(s->d_frame.p, f->data, (size_t)f->stride * (H - 1) + (size_t)W * 3, hipMemcpyHostToDevice, ctx->cs()));
             src = s->d_frame.p;
         }
         uint8_t *gray = s->d_gray.as<uint8_t>(), *small = s->d_small.as<uint8_t>(), *part = s->d_part.as<uint8_t>();
@@ -327,11 +331,12 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
             CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, part, pw, ph, pw));
             CK(nvca_equalize_hist(ctx, part, pw, ph, pw, D, part, pw));
         }
-        if (w.face_job) jobs.push_back(w.face_job);
+        if (w.face_job) { jobs.push_back(w.face_job); job_lane.push_back(ctx->cur_lane); }
     }
-    CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size()));          // wait 1: every face pass
+    ctx->cur_lane = 0;
+    CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 1: every face pass
     // ---- phase 2: the part searches of every face of every stream
-    jobs.clear();
+    jobs.clear(); job_lane.clear();
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
         if (!w.run) continue;
@@ -376,9 +381,9 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
                 }
             }
         }
-        for (RoiJob &r : w.rois) if (r.job) jobs.push_back(r.job);
+        for (RoiJob &r : w.rois) if (r.job) { jobs.push_back(r.job); job_lane.push_back(n > 1 ? i % kLanes : 0); }
     }
-    CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size()));          // wait 2 (+ one more for searches that narrowed)
+    CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 2 (+ one more for searches that narrowed)
 #undef CK
     // ---- phase 3: merging heuristics, hysteresis, emission -- in stream order
     for (int i = 0; i < n; i++) {

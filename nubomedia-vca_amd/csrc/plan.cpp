@@ -486,7 +486,7 @@ ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor)
         auto victim = ctx->scale_tables.end();
         for (auto jt = ctx->scale_tables.begin(); jt != ctx->scale_tables.end(); ++jt)
             if (jt->second->refs == 0 && (victim == ctx->scale_tables.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
-        if (victim != ctx->scale_tables.end()) { (void)hipStreamSynchronize(ctx->stream); delete victim->second; ctx->scale_tables.erase(victim); }
+        if (victim != ctx->scale_tables.end()) { (void)hipDeviceSynchronize(); delete victim->second; ctx->scale_tables.erase(victim); }      // any lane may still hold kernels that read it
     }
     std::unique_ptr<ScaleTable> t(new ScaleTable());
     build_scale_table(c, factor, *t);

@@ -103,3 +103,43 @@ print(json.dumps({"roi_chain_batched": {"video_streams": V, "frames_per_s": V * 
       "launch_sets_per_tick": {k: round(v[1] / K2, 1) for k, v in kt.items() if v[1]},
       "roofline": {"bound": "hbm", "achieved": alg * V * K2 / dt2 / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg * V * K2 / dt2 / 1e9 / 8000.0,
                    "note": "launch-bound small-image work: %d kernel launches per tick" % int(sum(v[1] for v in kt.values()) / K2)}}}))
+
+
+# ---- the same V video streams spread over C contexts on the one GPU, one host thread per context (what the GStreamer shim's
+# per-GPU frontend does with NVCA_VIRTUAL_GPUS): the launch-bound chains of different contexts are queued in parallel
+import threading
+for C in (2, 4):
+    if V % C:
+        continue
+    ctxs = [capi.Context(0) for _ in range(C)]
+    per = V // C
+    setups = []
+    for cx in ctxs:
+        fc = cx.load_cascade_xml(synth.synthetic_cascade_xml())
+        pcs = {n: cx.load_cascade_xml(synth.synthetic_part_cascade_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+        fv = [capi.FaceStream(cx, fc, width_to_process=W, multi_scale_factor=10) for _ in range(per)]
+        pv = [capi.PartStream(cx, k, fc, pcs[a], pcs[b] if b else None) for _ in range(per) for k, a, b in kinds]
+        setups.append((cx, fv, pv))
+
+    def work(ci, ticks):
+        cx, fv, pv = setups[ci]
+        for i in range(ticks):
+            fb = [fr[(i + 3 * (ci * per + v)) % N] for v in range(per)]
+            cx.face_batch_process(fv, fb)
+            capi.part_batch_process(cx, pv, [fb[v] for v in range(per) for _ in range(4)])
+
+    def run(ticks):
+        th = [threading.Thread(target=work, args=(ci, ticks)) for ci in range(C)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    run(3)
+    t0 = time.perf_counter()
+    run(K2)
+    for cx, _, _ in setups:
+        cx.synchronize()
+    dt3 = time.perf_counter() - t0
+    print(json.dumps({"roi_chain_batched_contexts": {"contexts": C, "video_streams": V, "frames_per_s": V * K2 / dt3, "ms_per_tick": dt3 / K2 * 1e3}}))
+    for cx, _, _ in setups:
+        cx.close()
