@@ -66,6 +66,8 @@ typedef struct nvca_frame {
 } nvca_frame;
 
 /* ---- context ----------------------------------------------------------- */
+/* HIP devices visible to the process (the GStreamer shim spreads its elements over them, one context per GPU) */
+int  nvca_device_count(int *n);
 int  nvca_ctx_create(int device_id, nvca_ctx **out);
 void nvca_ctx_destroy(nvca_ctx *ctx);
 /* text of the last error on this context (never NULL) */

@@ -671,6 +671,15 @@ extern "C" {
 
 const char *nvca_version(void) { return "nubovca-hip 0.1 (gfx950)"; }
 
+int nvca_device_count(int *n)
+{
+    if (!n) return NVCA_ERR_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) { *n = 0; return NVCA_ERR_NO_DEVICE; }
+    *n = c;
+    return NVCA_OK;
+}
+
 int nvca_ctx_create(int device_id, nvca_ctx **out)
 {
     if (!out) return NVCA_ERR_ARG;

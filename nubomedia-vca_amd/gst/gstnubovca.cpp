@@ -34,43 +34,20 @@ GST_DEBUG_CATEGORY_STATIC(nubovca_debug);
 
 #define OPENCV_CASCADE_DIR "/usr/share/opencv/haarcascades"     /* FACE/kmsfacedetect.cpp:40 */
 
-// ---------------------------------------------------------------- shared context (one per process / GPU)
-static std::mutex g_ctx_mutex;
-static nvca_ctx *g_ctx = nullptr;
-static nvca_ctx *shared_ctx()
-{
-    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    if (!g_ctx) {
-        const char *dev = getenv("NVCA_DEVICE");
-        int rc = nvca_ctx_create(dev ? atoi(dev) : 0, &g_ctx);
-        if (rc != NVCA_OK) { GST_ERROR("nvca_ctx_create failed (%d): no HIP device; frames pass through untouched", rc); g_ctx = nullptr; }
-    }
-    return g_ctx;
-}
-// Elements that name the same cascade file share one handle: their plans and scale tables are then shared in the
-// context, and their frames can ride in one batch (streams batch only when cascade, geometry and parameters agree).
+// ---------------------------------------------------------------- per-GPU frontend
+// A media stream (= one element instance, one streaming thread: FACE/kmsfacedetect.cpp:857-898) is the independent unit: it
+// lives on ONE GPU for its whole life, because its temporal state (Faces, the tracker's MHI and previous frame) is device
+// resident.  The process holds one slot per visible GPU -- context, cascade handles, frame combiners -- created on first
+// use; an element takes slot (instance counter mod slots) at its first frame and never migrates.  No data crosses GPUs.
+//   NVCA_DEVICE=d        pin the whole process to GPU d (one slot)
+//   NVCA_VIRTUAL_GPUS=n  n slots on one device (NVCA_DEVICE or 0): the multi-GPU code path on a one-GPU box, and a way to
+//                        let several launch-bound pipelines queue their work in parallel
 struct SharedCascade { nvca_cascade *h; int refs; };
-static std::map<std::string, SharedCascade> g_cascades;
-static nvca_cascade *acquire_cascade(nvca_ctx *ctx, const std::string &path)
-{
-    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    auto it = g_cascades.find(path);
-    if (it != g_cascades.end()) { it->second.refs++; return it->second.h; }
-    nvca_cascade *h = nullptr;
-    if (nvca_cascade_load_xml(ctx, path.c_str(), &h) != NVCA_OK) return nullptr;
-    g_cascades[path] = SharedCascade{h, 1};
-    return h;
-}
-static void release_cascade(nvca_cascade *h)
-{
-    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    for (auto it = g_cascades.begin(); it != g_cascades.end(); ++it)
-        if (it->second.h == h) {
-            if (--it->second.refs == 0) { nvca_cascade_free(h); g_cascades.erase(it); }
-            return;
-        }
-}
-
+struct GpuSlot;
+static std::mutex g_ctx_mutex;
+static std::vector<GpuSlot *> g_slots;          // filled once, entries live for the process
+static bool g_slots_ready = false;
+static int g_instances = 0;                     // elements that have taken a slot so far
 // Frames of different elements of one kind that arrive while the GPU is busy are combined into one batched call.  The
 // first streaming thread to arrive leads: it takes whatever has queued up (its own frame included), runs the batched
 // entry point on the lot and wakes the owners; threads that arrive meanwhile queue up for the next round, so the batch
@@ -109,8 +86,64 @@ template <class Req> struct Combiner {
 static const int kFaceCap = 256, kTrkCap = 4096;
 struct FaceReq { nvca_face_stream *stream; nvca_frame frame; nvca_rect *out; int n, rc; bool done; };
 struct TrkReq { nvca_tracker *trk; nvca_frame frame; double ts; nvca_rect *out; int n, rc; bool done; };
-static Combiner<FaceReq> g_face_q;
-static Combiner<TrkReq> g_trk_q;
+struct GpuSlot {
+    int index = 0, device = 0;
+    nvca_ctx *ctx = nullptr;
+    // Elements that name the same cascade file share one handle per GPU: their plans and scale tables are then shared in the
+    // context, and their frames can ride in one batch (streams batch only when cascade, geometry and parameters agree).
+    std::map<std::string, SharedCascade> cascades;
+    Combiner<FaceReq> face_q;
+    Combiner<TrkReq> trk_q;
+};
+
+static void make_slots_locked()
+{
+    if (g_slots_ready) return;
+    g_slots_ready = true;
+    const char *dev = getenv("NVCA_DEVICE"), *virt = getenv("NVCA_VIRTUAL_GPUS");
+    std::vector<int> devices;
+    if (virt && atoi(virt) > 0) devices.assign((size_t)std::min(atoi(virt), 64), dev ? atoi(dev) : 0);
+    else if (dev) devices.push_back(atoi(dev));
+    else {
+        int n = 0;
+        if (nvca_device_count(&n) != NVCA_OK || n <= 0) n = 1;      // ctx creation reports the missing device
+        for (int d = 0; d < n; d++) devices.push_back(d);
+    }
+    for (size_t i = 0; i < devices.size(); i++) { GpuSlot *g = new GpuSlot(); g->index = (int)i; g->device = devices[i]; g_slots.push_back(g); }
+}
+// the slot an element lives on: assigned round-robin at its first frame, then fixed
+static GpuSlot *take_slot()
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    make_slots_locked();
+    GpuSlot *g = g_slots[(size_t)(g_instances++) % g_slots.size()];
+    if (!g->ctx) {
+        const int rc = nvca_ctx_create(g->device, &g->ctx);
+        if (rc != NVCA_OK) { GST_ERROR("nvca_ctx_create(%d) failed (%d): no HIP device; frames pass through untouched", g->device, rc); g->ctx = nullptr; }
+    }
+    if (getenv("NVCA_GST_STATS")) fprintf(stderr, "nubovca: element %d -> slot %d (device %d)\n", g_instances - 1, g->index, g->device);
+    return g;
+}
+static nvca_cascade *acquire_cascade(GpuSlot *g, const std::string &path)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    auto it = g->cascades.find(path);
+    if (it != g->cascades.end()) { it->second.refs++; return it->second.h; }
+    nvca_cascade *h = nullptr;
+    if (nvca_cascade_load_xml(g->ctx, path.c_str(), &h) != NVCA_OK) return nullptr;
+    g->cascades[path] = SharedCascade{h, 1};
+    return h;
+}
+static void release_cascade(GpuSlot *g, nvca_cascade *h)
+{
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    for (auto it = g->cascades.begin(); it != g->cascades.end(); ++it)
+        if (it->second.h == h) {
+            if (--it->second.refs == 0) { nvca_cascade_free(h); g->cascades.erase(it); }
+            return;
+        }
+}
 
 static void face_run_round(nvca_ctx *ctx, std::vector<FaceReq *> &round)
 {
@@ -228,6 +261,7 @@ static Canvas canvas_of(GstVideoFrame *frame)
 struct NvcaFace {
     GstVideoFilter base;
     GRecMutex mutex;
+    GpuSlot *slot;                  /* the GPU this stream lives on (taken at the first frame) */
     nvca_cascade *cascade; nvca_face_stream *stream;
     nvca_face_params p;
     int view_faces, send_meta_data, server_events, events_ms;
@@ -315,11 +349,12 @@ static gboolean nvca_face_sink_event(GstBaseTransform *trans, GstEvent *event)
 static void face_lazy_init(NvcaFace *f)
 {
     if (f->stream) return;
-    nvca_ctx *ctx = shared_ctx();
+    if (!f->slot) f->slot = take_slot();
+    nvca_ctx *ctx = f->slot->ctx;
     if (!ctx) return;
     if (!f->cascade) {
         const std::string path = cascade_path("haarcascade_frontalface_alt.xml");
-        f->cascade = acquire_cascade(ctx, path);
+        f->cascade = acquire_cascade(f->slot, path);
         if (!f->cascade) {
             GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));   /* :167-176: logged, not fatal */
             return;
@@ -348,8 +383,8 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
         nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
         nvca_rect boxes[256]; int n = 0;
         FaceReq req{f->stream, nf, boxes, 0, NVCA_OK, false};
-        nvca_ctx *ctx = shared_ctx();
-        const int rc = g_face_q.process(&req, [ctx](std::vector<FaceReq *> &round) { face_run_round(ctx, round); });
+        nvca_ctx *ctx = f->slot->ctx;
+        const int rc = f->slot->face_q.process(&req, [ctx](std::vector<FaceReq *> &round) { face_run_round(ctx, round); });
         n = req.n;
         if (rc != NVCA_OK) GST_ERROR("nvca_face_stream_process: %d", rc);
         else {
@@ -396,12 +431,12 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
 static void nvca_face_finalize(GObject *o)
 {
     NvcaFace *f = (NvcaFace *)o;
-    if (getenv("NVCA_GST_STATS")) {
-        std::lock_guard<std::mutex> lk(g_face_q.m);
-        fprintf(stderr, "nubovca: largest combined face batch %d\n", g_face_q.max_batch);
+    if (getenv("NVCA_GST_STATS") && f->slot) {
+        std::lock_guard<std::mutex> lk(f->slot->face_q.m);
+        fprintf(stderr, "nubovca: largest combined face batch %d (slot %d)\n", f->slot->face_q.max_batch, f->slot->index);
     }
     if (f->stream) nvca_face_stream_destroy(f->stream);
-    if (f->cascade) release_cascade(f->cascade);
+    if (f->cascade) release_cascade(f->slot, f->cascade);
     if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
     g_queue_free_full(f->events_queue, (GDestroyNotify)gst_structure_free);
     g_rec_mutex_clear(&f->mutex);
@@ -457,6 +492,7 @@ static void nvca_face_class_init(NvcaFaceClass *klass)
 struct NvcaTrk {
     GstVideoFilter base;
     GRecMutex mutex;
+    GpuSlot *slot;
     nvca_tracker *trk;
     nvca_tracker_params p;
     int visual_mode, server_events, events_ms;
@@ -505,7 +541,7 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
 {
     NvcaTrk *t = (NvcaTrk *)filter;
     g_rec_mutex_lock(&t->mutex);
-    if (!t->trk) { nvca_ctx *ctx = shared_ctx(); if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
+    if (!t->trk) { if (!t->slot) t->slot = take_slot(); nvca_ctx *ctx = t->slot->ctx; if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
     if (t->trk) {
         nvca_frame nf;
         nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
@@ -516,8 +552,8 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
         int n = 0;
         nvca_rect *bx = (nvca_rect *)g_malloc(sizeof(nvca_rect) * kTrkCap);
         TrkReq req{t->trk, nf, timestamp, bx, 0, NVCA_OK, false};
-        nvca_ctx *ctx = shared_ctx();
-        const int rc = g_trk_q.process(&req, [ctx](std::vector<TrkReq *> &round) { trk_run_round(ctx, round); });
+        nvca_ctx *ctx = t->slot->ctx;
+        const int rc = t->slot->trk_q.process(&req, [ctx](std::vector<TrkReq *> &round) { trk_run_round(ctx, round); });
         n = req.n;
         if (rc != NVCA_OK) GST_ERROR("nvca_tracker_process: %d", rc);
         else if (n > 0) {
@@ -547,9 +583,9 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
 static void nvca_trk_finalize(GObject *o)
 {
     NvcaTrk *t = (NvcaTrk *)o;
-    if (getenv("NVCA_GST_STATS")) {
-        std::lock_guard<std::mutex> lk(g_trk_q.m);
-        fprintf(stderr, "nubovca: largest combined tracker batch %d\n", g_trk_q.max_batch);
+    if (getenv("NVCA_GST_STATS") && t->slot) {
+        std::lock_guard<std::mutex> lk(t->slot->trk_q.m);
+        fprintf(stderr, "nubovca: largest combined tracker batch %d (slot %d)\n", t->slot->trk_q.max_batch, t->slot->index);
     }
     if (t->trk) nvca_tracker_destroy(t->trk);
     g_rec_mutex_clear(&t->mutex);
@@ -607,6 +643,7 @@ struct NvcaPart {
     GstVideoFilter base;
     GRecMutex mutex;
     PartDesc *desc;
+    GpuSlot *slot;
     nvca_cascade *cf, *ca, *cb; nvca_part_stream *stream;
     nvca_part_params p;
     int view, meta_data, server_events, events_ms;
@@ -660,13 +697,14 @@ static void nvca_part_get_property(GObject *o, guint id, GValue *v, GParamSpec *
 static void part_lazy_init(NvcaPart *f)
 {
     if (f->stream) return;
-    nvca_ctx *ctx = shared_ctx();
+    if (!f->slot) f->slot = take_slot();
+    nvca_ctx *ctx = f->slot->ctx;
     if (!ctx) return;
     struct { nvca_cascade **c; const char *file; } need[3] = {{&f->cf, f->desc->face_file}, {&f->ca, f->desc->a_file}, {&f->cb, f->desc->b_file}};
     for (auto &n : need) {
         if (!n.file || *n.c) continue;
         const std::string path = cascade_path(n.file);
-        *n.c = acquire_cascade(ctx, path);
+        *n.c = acquire_cascade(f->slot, path);
         if (!*n.c) {
             GST_ERROR("Error charging cascade %s: %s", path.c_str(), nvca_last_error(ctx));
             return;
@@ -806,9 +844,9 @@ static void nvca_part_finalize(GObject *o)
 {
     NvcaPart *f = (NvcaPart *)o;
     if (f->stream) nvca_part_stream_destroy(f->stream);
-    if (f->cf) release_cascade(f->cf);
-    if (f->ca) release_cascade(f->ca);
-    if (f->cb) release_cascade(f->cb);
+    if (f->cf) release_cascade(f->slot, f->cf);
+    if (f->ca) release_cascade(f->slot, f->ca);
+    if (f->cb) release_cascade(f->slot, f->cb);
     if (f->image_to_overlay) gst_structure_free(f->image_to_overlay);
     g_rec_mutex_clear(&f->mutex);
     G_OBJECT_CLASS(f->desc->parent_class)->finalize(o);

@@ -68,7 +68,7 @@ SYMBOLS = [
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
-    "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process",
+    "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count",
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def load():
     L.nvca_last_error.argtypes = [vp]
     L.nvca_kernel_name.restype = C.c_char_p
     L.nvca_kernel_name.argtypes = [C.c_int]
+    L.nvca_device_count.argtypes = [ip]
     L.nvca_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.nvca_ctx_destroy.argtypes = [vp]
     L.nvca_ctx_destroy.restype = None

@@ -223,6 +223,51 @@ def test_face_branches_share_batches_and_keep_per_stream_results(shim, synth_xml
 
 
 @pytest.mark.gpu
+def test_face_and_tracker_branches_over_virtual_gpus(shim, synth_xml, orc_cascade):
+    """the multi-GPU frontend on a one-GPU box (NVCA_VIRTUAL_GPUS=2: two contexts on device 0): elements are dealt to the
+    slots round-robin at their first frame and stay there; every stream's events are those of a single-context run"""
+    import re
+    import orc
+    from nubovca import synth
+    W, H, N, B = 640, 480, 6, 4
+    branches = []
+    for b in range(B):
+        branches.append([synth.make_bgr(W, H, 6100 + 50 * b + i, "natural", [(60 + 40 * b + 8 * i, 70 + 10 * b, 210 + 20 * b)] if (i + b) % 5 != 2 else [])
+                         for i in range(N)])
+    r = _run_harness("nubofacedetector", "BGR", W, H, branches, cascade_xml=synth_xml, extra_env={"NVCA_GST_STATS": "1", "NVCA_VIRTUAL_GPUS": "2"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    placed = sorted((int(m.group(1)), int(m.group(2))) for m in re.finditer(r"element (\d+) -> slot (\d+)", r.stderr))
+    assert placed == [(0, 0), (1, 1), (2, 0), (3, 1)], r.stderr[-1500:]
+    seen = 0
+    for b in range(B):
+        tag = "event" if b == 0 else "event#%d" % b
+        got = []
+        for ln in r.stdout.splitlines():
+            if ln.startswith(tag + " "):
+                parts = ln.split(" ", 2)
+                got.append([tuple(int(v) for v in box.split(":")[1].split(",")) for box in (parts[2].split(";") if len(parts) > 2 else []) if box])
+        ofs = orc.FaceStream(orc_cascade)
+        exp = [[tuple(int(v) for v in bx) for bx in ofs.process(f)[0]] for f in branches[b]]
+        assert got == exp, (b, got, exp)
+        seen += sum(len(e) for e in exp)
+    assert seen > 0
+    # trackers over two slots: independent streams, each with its own device-resident MHI / previous frame
+    seq = []
+    for b in range(2):
+        bg = synth.make_gray(W, H, 77 + b, "natural")
+        fr = []
+        for i in range(5):
+            g = bg.copy()
+            g[100 + 30 * b:160 + 30 * b, 50 + 40 * i:110 + 40 * i] = 255
+            fr.append(synth.gray_to_bgr(g, 5, 4))
+        seq.append(fr)
+    t = _run_harness("nubotracker", "BGRA", W, H, seq, props=["activate-events=1", "events-ms=0"], extra_env={"NVCA_GST_STATS": "1", "NVCA_VIRTUAL_GPUS": "2"})
+    assert t.returncode == 0, t.stderr[-2000:]
+    assert sorted(int(m.group(2)) for m in re.finditer(r"element (\d+) -> slot (\d+)", t.stderr)) == [0, 1], t.stderr[-1500:]
+    assert "signal " in t.stdout and "signal#1 " in t.stdout
+
+
+@pytest.mark.gpu
 def test_tracker_pipeline_runs(shim):
     W, H = 320, 240
     frames = []
