@@ -297,6 +297,11 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
     if (!gray) gray = ws.ln().gray.as<uint8_t>();
     if (!sum) sum = ws.ln().sum.as<int>();
     if (!sq) sq = ws.ln().sqsum.as<unsigned long long>();
+    if (batch <= 4 && small_integral_fits(g)) {          // a few small images (ROI searches of the part detectors): one launch
+        TimedLaunch t(ctx, NVCA_K_INTEGRAL);
+        launch_small_integral(ctx->cs(), gray, lut, 256, g, sum, sq, batch);
+        return;
+    }
     { TimedLaunch t(ctx, NVCA_K_COLSUM);
       launch_colsum(ctx->cs(), gray, lut, 256, g, ws.ln().bandsum.as<unsigned>(), ws.ln().bandsq.as<unsigned>(), batch); }
     { TimedLaunch t(ctx, NVCA_K_BANDSCAN);

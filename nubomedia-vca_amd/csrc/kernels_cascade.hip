@@ -1304,7 +1304,12 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
         if (a.blocks_per_frame > 0)
             NVCA_LAUNCH(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
     } else if (a.deep_stage < a.nstages) {
-        NVCA_LAUNCH(k_deep, dim3(8192), dim3(256), 0, st, a);    // grid-stride over the list, one window per workgroup at a time
+        // grid-stride over the list, one window per workgroup at a time; small jobs (the part detectors' ROI searches) do not
+        // need eight thousand workgroups to find a handful of windows
+        long long wg = (long long)a.ntasks * batch / 2;
+        if (wg < 128) wg = 128;
+        if (wg > 8192) wg = 8192;
+        NVCA_LAUNCH(k_deep, dim3((unsigned)wg), dim3(256), 0, st, a);
     }
     return 0;
 }

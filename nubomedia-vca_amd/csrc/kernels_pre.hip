@@ -590,10 +590,56 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const uint8_t *__restrict__ 
     }
 }
 
+// Integral pair of a SMALL image (rows x (cols | 1) <= kSmallIntWords words of LDS) by one workgroup, without a barrier per
+// row: (1) every wave scans whole rows -- 64 pixels per step, DPP wave scan, carry from chunk to chunk -- and leaves the row
+// prefix sums in LDS; (2) after one barrier every thread owns a column and adds the rows up out of LDS, writing the
+// integral rows to global memory fully coalesced.  Once for the pixel sums, once for their squares (row prefixes of squares
+// stay below 2^32; the column sums are 64-bit and leave as the u32 low-word plane + u8 high-byte plane of k_integral).
+// 160 x 90 (the part detectors' face-pass image): ~3 us instead of ~36 us for the row-by-row walk below.
+static constexpr int kSmallIntWords = 16 * 1024 - 256;     // dynamic LDS: with the static scan words still inside the 64 KiB a kernel gets without asking
+__device__ __forceinline__ void small_integral(const uint8_t *__restrict__ g, int gpitch, const uint8_t *__restrict__ lut, int w, int h,
+                                               int *__restrict__ s, unsigned *__restrict__ lo, uint8_t *__restrict__ hi, int P, unsigned *sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int pitch = w | 1;
+    for (int X = tid; X <= w; X += nthreads) { s[X] = 0; lo[X] = 0; hi[X] = 0; }            // integral row 0
+    for (int pass = 0; pass < 2; pass++) {
+        for (int y = wave; y < h; y += nwaves) {
+            const uint8_t *row = g + (size_t)y * gpitch;
+            unsigned carry = 0;
+            for (int x0 = 0; x0 < w; x0 += 64) {
+                const int x = x0 + lane;
+                unsigned v = 0;
+                if (x < w) { v = row[x]; if (lut) v = lut[v]; if (pass) v *= v; }
+                const unsigned inc = wave_incl_scan_u32(v, lane) + carry;
+                if (x < w) sm[y * pitch + x] = inc;
+                carry = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < w; x += nthreads) {
+            if (pass == 0) {
+                unsigned acc = 0;
+                for (int y = 0; y < h; y++) { acc += sm[y * pitch + x]; s[(size_t)(y + 1) * P + x + 1] = (int)acc; }
+            } else {
+                unsigned long long acc = 0;
+                for (int y = 0; y < h; y++) {
+                    acc += sm[y * pitch + x];
+                    const size_t o = (size_t)(y + 1) * P + x + 1;
+                    lo[o] = (unsigned)acc; hi[o] = (uint8_t)(acc >> 32);
+                }
+            }
+        }
+        if (pass == 0) for (int y = tid; y < h; y += nthreads) { const size_t o = (size_t)(y + 1) * P; s[o] = 0; lo[o] = 0; hi[o] = 0; }   // column 0
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict__ aux, size_t aux_slot,
                                                        const PyrLevelDev *__restrict__ levels, int nimg,
                                                        int *__restrict__ sum, unsigned *__restrict__ sq32, size_t sum_slot, int P)
 {
+    extern __shared__ unsigned pyr_sm[];
     __shared__ unsigned wt_s[2][16], wt_l[2][16], wt_h[2][16];
     const int lev = blockIdx.x / nimg, img = blockIdx.x - lev * nimg;
     const PyrLevelDev L = levels[lev];
@@ -602,6 +648,7 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
     int *s = sum + (size_t)img * sum_slot + L.plane_off;
     unsigned *lo = sq32 + (size_t)img * 2 * sum_slot + L.plane_off;
     uint8_t *hi = (uint8_t *)(sq32 + (size_t)img * 2 * sum_slot + sum_slot) + L.plane_off;   // high-byte plane
+    if (h * (w | 1) <= kSmallIntWords) { small_integral(g, L.gpitch, nullptr, w, h, s, lo, hi, P, pyr_sm); return; }
     if (tid <= w) { s[tid] = 0; lo[tid] = 0; hi[tid] = 0; }            // integral row 0
     // running sums of this thread's column; the squared one stays below 2^32 (rows x 255^2), so its row prefix can be
     // scanned as two 32-bit halves (low 16 bits / the rest) on the VALU and recombined in 64 bits
@@ -623,6 +670,24 @@ __global__ __launch_bounds__(1024) void k_pyr_integral(const uint8_t *__restrict
         if (tid < w) { s[row + tid + 1] = (int)is; lo[row + tid + 1] = (unsigned)iq; hi[row + tid + 1] = (uint8_t)(iq >> 32); }
         if (tid == 0) { s[row] = 0; lo[row] = 0; hi[row] = 0; }
     }
+}
+
+// one small image per workgroup (batch slots), the planes laid out like k_integral's: the ROI-sized images of the part
+// detectors' FIND_BIGGEST searches take one launch instead of column sums + band scan + row pass
+__global__ __launch_bounds__(1024) void k_small_integral(const uint8_t *__restrict__ gray, const uint8_t *__restrict__ lut, int lut_stride, PreGeom g,
+                                                         int *__restrict__ sum, unsigned *__restrict__ sq32)
+{
+    extern __shared__ unsigned pyr_sm[];
+    const int slot = blockIdx.x;
+    unsigned *lo = sq32 + (size_t)slot * 2 * g.sum_slot;
+    small_integral(gray + (size_t)slot * g.gray_slot, g.gpitch, lut ? lut + (size_t)slot * lut_stride : nullptr, g.w, g.h,
+                   sum + (size_t)slot * g.sum_slot, lo, (uint8_t *)(lo + g.sum_slot), g.spitch, pyr_sm);
+}
+bool small_integral_fits(const PreGeom &g) { return g.h * (g.w | 1) <= kSmallIntWords; }
+void launch_small_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g, int *sum,
+                           unsigned long long *sqsum, int batch)
+{
+    NVCA_LAUNCH(k_small_integral, dim3(batch), dim3(1024), (size_t)g.h * (g.w | 1) * sizeof(unsigned), st, gray, lut, lut_stride, g, sum, (unsigned *)sqsum);
 }
 
 // ---- tilted integral: cv::integral's third plane, read by tilted Haar features ------------------------------------------
@@ -705,7 +770,8 @@ void launch_pyr_resize(hipStream_t st, const uint8_t *src, int sw, int sh, int s
 void launch_pyr_integral(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
                          int *sum, unsigned *sq32, size_t sum_slot, int P)
 {
-    NVCA_LAUNCH(k_pyr_integral, dim3(nlev * nimg), dim3(1024), 0, st, aux, aux_slot, levels, nimg, sum, sq32, sum_slot, P);
+    // dynamic LDS: the row prefix sums of the largest level that takes the LDS-resident path (64 KiB at most)
+    NVCA_LAUNCH(k_pyr_integral, dim3(nlev * nimg), dim3(1024), (size_t)kSmallIntWords * sizeof(unsigned), st, aux, aux_slot, levels, nimg, sum, sq32, sum_slot, P);
 }
 
 } // namespace nvca

@@ -303,6 +303,11 @@ void launch_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, in
                      const unsigned *bandsum, const unsigned *bandsq, int *sum, unsigned long long *sqsum,
                      int batch);
 
+// integral pair of small images (rows x cols fit 64 KiB of LDS) in one launch, one workgroup per image
+bool small_integral_fits(const PreGeom &g);
+void launch_small_integral(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g, int *sum,
+                           unsigned long long *sqsum, int batch);
+
 // ---- tracker (kernels_tracker.hip) ----
 struct TrkSlot {                // per tracker in the batch
     const uint8_t *src;         // BGRA frame

@@ -93,7 +93,8 @@ def test_equalize_lut_division_sweep(ctx):
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (64, 16), (65, 17), (640, 480), (1920, 1080), (2047, 20), (2048, 20),
-                                 (2500, 37), (4100, 33)])
+                                 (2500, 37), (4100, 33),
+                                 (125, 128), (126, 127), (255, 63), (1000, 16), (63, 200), (160, 90), (3, 1000)])     # around the LDS-resident small-image path
 def test_integral(ctx, w, h):
     import orc
     img = np.random.default_rng(w + h).integers(0, 256, size=(h, w), dtype=np.uint8)
