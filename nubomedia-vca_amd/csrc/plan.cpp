@@ -268,6 +268,15 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     stages.resize(c.stage_rec_cache.size() / sizeof(StageRec));
     if (!stages.empty()) memcpy(stages.data(), c.stage_rec_cache.data(), c.stage_rec_cache.size());
     std::vector<long long> strip_w, tile_w;
+    // A scan with few windows (the part detectors' working images and ROIs) cannot fill the GPU with 32 x 32-window tiles: a
+    // handful of workgroups would each walk a long chain of stages.  Smaller tiles give more workgroups and, with the same 1024
+    // threads per tile, more stump partitions per window -- a shorter chain.  (Results do not depend on the tiling.)
+    int max_tile = kTileWin;
+    {
+        long long tiles32 = 0;
+        for (const ScaleSpec &sp : specs) tiles32 += (long long)((sp.xs.size() + kTileWin - 1) / kTileWin) * (long long)((sp.ys.size() + kTileWin - 1) / kTileWin);
+        if (tiles32 < 128) max_tile = 16;
+    }
     for (size_t s = 0; s < specs.size(); s++) {
         const ScaleSpec &sp = specs[s];
         const int pitch = sp.pitch;
@@ -323,7 +332,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                 std::sort(out.begin(), out.end()); out.erase(std::unique(out.begin(), out.end()), out.end());
             };
             std::vector<int> cx, cy;
-            for (tw = kTileWin; tw >= 1; tw--) {         // largest tile side whose every tile fits the LDS budget
+            for (tw = max_tile; tw >= 1; tw--) {         // largest tile side whose every tile fits the LDS budget
                 bool ok = true;
                 int worst_c = 0, worst_r = 0, worst_sx = 0, worst_sy = 0;
                 for (int i0 = 0; i0 < sr.endX; i0 += tw) {
