@@ -62,7 +62,7 @@ static void on_signal(GstElement *, const gchar *payload, gpointer user)
     fflush(stdout);
 }
 
-struct FrameData { std::vector<unsigned char> bytes; };
+struct FrameData { std::vector<unsigned char> bytes; size_t next = 0; };   // frames of the file, handed out in a cycle
 static GstPadProbeReturn on_fill(GstPad *, GstPadProbeInfo *info, gpointer user)
 {
     FrameData *fd = (FrameData *)user;
@@ -70,7 +70,8 @@ static GstPadProbeReturn on_fill(GstPad *, GstPadProbeInfo *info, gpointer user)
     GST_PAD_PROBE_INFO_DATA(info) = buf;
     GstMapInfo map;
     if (gst_buffer_map(buf, &map, GST_MAP_WRITE)) {
-        memcpy(map.data, fd->bytes.data(), std::min((size_t)map.size, fd->bytes.size()));
+        const size_t nfr = std::max<size_t>(fd->bytes.size() / std::max<size_t>(map.size, 1), 1), at = (fd->next++ % nfr) * map.size;
+        if (at < fd->bytes.size()) memcpy(map.data, fd->bytes.data() + at, std::min((size_t)map.size, fd->bytes.size() - at));
         gst_buffer_unmap(buf, &map);
     }
     return GST_PAD_PROBE_OK;

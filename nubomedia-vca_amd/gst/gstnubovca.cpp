@@ -22,6 +22,7 @@
 #include <string.h>
 #include <string>
 #include <mutex>
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <vector>
@@ -94,6 +95,7 @@ struct GpuSlot {
     std::map<std::string, SharedCascade> cascades;
     Combiner<FaceReq> face_q;
     Combiner<TrkReq> trk_q;
+    std::atomic<int> registered{0};             // pool memories page-locked so far (NVCA_GST_STATS)
 };
 
 static void make_slots_locked()
@@ -110,6 +112,32 @@ static void make_slots_locked()
         for (int d = 0; d < n; d++) devices.push_back(d);
     }
     for (size_t i = 0; i < devices.size(); i++) { GpuSlot *g = new GpuSlot(); g->index = (int)i; g->device = devices[i]; g_slots.push_back(g); }
+}
+// Pool memory that keeps coming back (decoders and converters recycle their GstBufferPool memories) is page-locked once
+// with nvca_host_register, so its H2D copies are DMA from the buffer instead of going through the runtime's staging
+// copy; the registration ends with the GstMemory (weak reference).  One-shot memories are left alone: a registration
+// costs more than the copy it saves.
+struct RegNote { nvca_ctx *ctx; void *ptr; };
+static void on_memory_gone(gpointer data, GstMiniObject *)
+{
+    RegNote *r = (RegNote *)data;
+    nvca_host_unregister(r->ctx, r->ptr);
+    delete r;
+}
+static void note_frame_memory(GpuSlot *g, GstVideoFrame *frame)
+{
+    static const bool off = getenv("NVCA_GST_NO_REGISTER") != NULL;
+    static const GQuark seen_q = g_quark_from_static_string("nubovca-seen");
+    GstMemory *mem = frame->map[0].memory;
+    if (off || !g || !g->ctx || !mem || !frame->map[0].data || !frame->map[0].size) return;
+    GstMiniObject *mo = GST_MINI_OBJECT_CAST(mem);
+    const int seen = GPOINTER_TO_INT(gst_mini_object_get_qdata(mo, seen_q));
+    if (seen < 0) return;                                   // registered, or registration refused once
+    if (seen + 1 < 3) { gst_mini_object_set_qdata(mo, seen_q, GINT_TO_POINTER(seen + 1), NULL); return; }
+    gst_mini_object_set_qdata(mo, seen_q, GINT_TO_POINTER(-1), NULL);
+    if (nvca_host_register(g->ctx, frame->map[0].data, frame->map[0].size) != NVCA_OK) return;
+    gst_mini_object_weak_ref(mo, on_memory_gone, new RegNote{g->ctx, frame->map[0].data});
+    g->registered++;
 }
 // the slot an element lives on: assigned round-robin at its first frame, then fixed
 static GpuSlot *take_slot()
@@ -376,6 +404,7 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
             gst_structure_free(m);
         }
         GST_OBJECT_UNLOCK(f);
+        note_frame_memory(f->slot, frame);
         nvca_frame nf;
         nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
         nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);
@@ -434,6 +463,7 @@ static void nvca_face_finalize(GObject *o)
     if (getenv("NVCA_GST_STATS") && f->slot) {
         std::lock_guard<std::mutex> lk(f->slot->face_q.m);
         fprintf(stderr, "nubovca: largest combined face batch %d (slot %d)\n", f->slot->face_q.max_batch, f->slot->index);
+        fprintf(stderr, "nubovca: page-locked pool memories %d (slot %d)\n", f->slot->registered.load(), f->slot->index);
     }
     if (f->stream) nvca_face_stream_destroy(f->stream);
     if (f->cascade) release_cascade(f->slot, f->cascade);
@@ -543,6 +573,7 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
     g_rec_mutex_lock(&t->mutex);
     if (!t->trk) { if (!t->slot) t->slot = take_slot(); nvca_ctx *ctx = t->slot->ctx; if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
     if (t->trk) {
+        note_frame_memory(t->slot, frame);
         nvca_frame nf;
         nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
         nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);
@@ -764,6 +795,7 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
     g_rec_mutex_lock(&f->mutex);
     part_lazy_init(f);
     if (f->stream && f->p.width_to_process > 0) {
+        note_frame_memory(f->slot, frame);
         nvca_frame nf;
         nf.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
         nf.width = GST_VIDEO_FRAME_WIDTH(frame); nf.height = GST_VIDEO_FRAME_HEIGHT(frame);

@@ -223,6 +223,30 @@ def test_face_branches_share_batches_and_keep_per_stream_results(shim, synth_xml
 
 
 @pytest.mark.gpu
+def test_pool_memory_is_page_locked_once_it_recurs(shim, synth_xml, orc_cascade):
+    """buffers from a GstBufferPool (videotestsrc here, decoders in a media server) come back with the same GstMemory:
+    from its third appearance a memory is registered with nvca_host_register; results are unchanged by it"""
+    import re
+    import orc
+    from nubovca import synth
+    W, H, NF, LOOP = 640, 480, 3, 14
+    seq = [synth.make_bgr(W, H, 7300 + i, "natural", [(80 + 30 * i, 60, 220)]) for i in range(NF)]
+    out = {}
+    for tag, extra in (("on", {}), ("off", {"NVCA_GST_NO_REGISTER": "1"})):
+        env = {"NVCA_GST_STATS": "1", "NVCA_HARNESS_LOOP": str(LOOP)}
+        env.update(extra)
+        r = _run_harness("nubofacedetector", "BGR", W, H, seq, cascade_xml=synth_xml, extra_env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = ([l.split(" ", 2)[2] if len(l.split(" ", 2)) > 2 else "" for l in r.stdout.splitlines() if l.startswith("event ")],
+                    int(re.search(r"page-locked pool memories (\d+)", r.stderr).group(1)))
+    ofs = orc.FaceStream(orc_cascade)
+    exp = ["".join("face/face:%d,%d,%d,%d;" % tuple(bx) for bx in ofs.process(seq[i % NF])[0]) for i in range(LOOP)]
+    assert out["on"][0] == exp and out["off"][0] == exp
+    assert any(exp)
+    assert out["on"][1] >= 1 and out["off"][1] == 0, (out["on"][1], out["off"][1])
+
+
+@pytest.mark.gpu
 def test_face_and_tracker_branches_over_virtual_gpus(shim, synth_xml, orc_cascade):
     """the multi-GPU frontend on a one-GPU box (NVCA_VIRTUAL_GPUS=2: two contexts on device 0): elements are dealt to the
     slots round-robin at their first frame and stay there; every stream's events are those of a single-context run"""
