@@ -297,7 +297,7 @@ static void run_integral(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, in
     if (!gray) gray = ws.ln().gray.as<uint8_t>();
     if (!sum) sum = ws.ln().sum.as<int>();
     if (!sq) sq = ws.ln().sqsum.as<unsigned long long>();
-    if (batch <= 4 && small_integral_fits(g)) {          // a few small images (ROI searches of the part detectors): one launch
+    if (batch <= 64 && small_integral_fits(g)) {         // small images (ROI searches and working images of the part detectors): one launch, a workgroup per image
         TimedLaunch t(ctx, NVCA_K_INTEGRAL);
         launch_small_integral(ctx->cs(), gray, lut, 256, g, sum, sq, batch);
         return;
@@ -662,6 +662,7 @@ nvca_ctx::~nvca_ctx()
     nvca::free_scale_tables(this);
     if (ws) ws->release_all();
     trk.release_all();
+    part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1153,12 +1154,12 @@ struct DetectJob {
     // ---- request
     int kind = 0;                                    // 0: scale-cascade scan, 1: CV_HAAR_SCALE_IMAGE, 2: CV_HAAR_FIND_BIGGEST_OBJECT
     const nvca_cascade *casc = nullptr;
-    const void *img[2] = {nullptr, nullptr}; int nimg = 1;       // SCALE_IMAGE: up to two images of one geometry share the launches
+    const void *img[kJobImages] = {nullptr}; int nimg = 1;       // plain scan / SCALE_IMAGE: images of one geometry share the launches
     int cols = 0, rows = 0, stride = 0, mem = 0;
     double sf = 1.1; int min_neighbors = 0, flags = 0, minw = 0, minh = 0, maxw = 0, maxh = 0;
     bool raw_only = false;
     // ---- result
-    std::vector<nvca_rect> out[2];
+    std::vector<nvca_rect> out[kJobImages];
     // ---- progress
     int phase = 0;                                   // 0: new, 1: first launch set queued, 2: narrowed set queued, 3: done
     int slots() const { return nimg; }
@@ -1254,6 +1255,22 @@ static int si_plan(nvca_ctx *ctx, const DetectJob &j, GeomPlan **out)
     return NVCA_OK;
 }
 
+// Device images of a job that sit at equal distances (the working images of a batched part call are carved that way) are read
+// where they are; anything else is copied into the lane's gray slots first.
+static bool job_images_in_place(const DetectJob &j, size_t *slot)
+{
+    if (j.mem != NVCA_MEM_DEVICE) return false;
+    *slot = 0;
+    if (j.nimg == 1) return true;
+    const uint8_t *a = (const uint8_t *)j.img[0], *b = (const uint8_t *)j.img[1];
+    if (b <= a) return false;
+    const size_t d = (size_t)(b - a);
+    if (d < (size_t)j.stride * (j.rows - 1) + j.cols) return false;
+    for (int k = 2; k < j.nimg; k++) if ((const uint8_t *)j.img[k] != a + d * k) return false;
+    *slot = d;
+    return true;
+}
+
 static int si_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
 {
     Workspace &ws = *ctx->ws;
@@ -1273,11 +1290,15 @@ static int si_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
         ctx->set_error("allocation failed (pyramid)"); return NVCA_ERR_NOMEM;
     }
     if (c.has_tilted && (size_t)2 * (pp->pyr_maxw + pp->pyr_maxh + 2) * sizeof(int) > 64 * 1024) { ctx->set_error("image too large for the tilted integral"); return NVCA_ERR_ARG; }
-    for (int k = 0; k < nimg; k++)
-        if ((rc = stage_2d(ctx, ws.ln().gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, j.img[k], j.stride, cols, rows, j.mem))) return rc;
+    const uint8_t *src0 = ws.ln().gray.as<uint8_t>(); int spitch0 = g0.gpitch; size_t sslot0 = g0.gray_slot;
+    size_t in_place_slot = 0;
+    if (job_images_in_place(j, &in_place_slot)) { src0 = (const uint8_t *)j.img[0]; spitch0 = j.stride; sslot0 = in_place_slot; }
+    else
+        for (int k = 0; k < nimg; k++)
+            if ((rc = stage_2d(ctx, ws.ln().gray.as<uint8_t>() + g0.gray_slot * k, g0.gpitch, j.img[k], j.stride, cols, rows, j.mem))) return rc;
     if (pp->pyr_ok) {            // all levels of all images: one resize launch, one integral launch
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);
-          launch_pyr_resize(ctx->cs(), ws.ln().gray.as<uint8_t>(), cols, rows, g0.gpitch, g0.gray_slot, pp->d_pyr.as<PyrLevelDev>(),
+          launch_pyr_resize(ctx->cs(), src0, cols, rows, spitch0, sslot0, pp->d_pyr.as<PyrLevelDev>(),
                             (int)pp->lv.size(), nimg, pp->pyr_maxw, pp->pyr_maxh, ws.ln().aux.as<uint8_t>(), gray_total); }
         { TimedLaunch t(ctx, NVCA_K_INTEGRAL);
           launch_pyr_integral(ctx->cs(), ws.ln().aux.as<uint8_t>(), gray_total, pp->d_pyr.as<PyrLevelDev>(), (int)pp->lv.size(), nimg,
@@ -1293,9 +1314,9 @@ static int si_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
         GeomPlan *gp = pp->level_tabs[li].get();
         uint8_t *lg = ws.ln().aux.as<uint8_t>() + L.gray_off;
         { TimedLaunch t(ctx, NVCA_K_RESIZE1);               // cvResize(img, &img1, CV_INTER_LINEAR)
-          launch_resize1(ctx->cs(), ws.ln().gray.as<uint8_t>(), cols, rows, g0.gpitch, gp->tab.mode, gp->d_xofs.as<int>(),
+          launch_resize1(ctx->cs(), src0, cols, rows, spitch0, gp->tab.mode, gp->d_xofs.as<int>(),
                          gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax, lg, L.szw,
-                         L.szh, L.gpitch, nullptr, nimg, g0.gray_slot, gray_total); }
+                         L.szh, L.gpitch, nullptr, nimg, sslot0, gray_total); }
         PreGeom g; make_geom(g, L.szw, L.szh, L.gpitch, 1, L.szw, L.szh);
         g.gpitch = L.gpitch; g.spitch = P; g.sum_slot = plane_total; g.gray_slot = gray_total;
         run_integral(ctx, g, nullptr, nimg, lg, ws.ln().sum.as<int>() + L.plane_off,
@@ -1314,13 +1335,22 @@ static int plain_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
     GeomPlan *gp = nullptr;
     int rc;
     if ((rc = get_face_plan(ctx, j.casc, j.cols, j.rows, j.stride, 1, j.cols, j.rows, j.sf, j.minw, j.minh, j.maxw, j.maxh, &gp))) return rc;
-    if ((rc = ensure_ws(ctx, gp->g, 1))) return rc;
-    if ((rc = stage_2d(ctx, ctx->ws->ln().gray.p, gp->g.gpitch, j.img[0], j.stride, j.cols, j.rows, j.mem))) return rc;
-    run_integral(ctx, gp->g, nullptr, 1);
-    if (j.casc->c.has_tilted && (rc = run_tilted(ctx, gp->g, nullptr, 1))) return rc;
+    const int nimg = j.nimg;
+    if ((rc = ensure_ws(ctx, gp->g, nimg))) return rc;
+    PreGeom g = gp->g;
+    const uint8_t *src = nullptr;
+    size_t in_place_slot = 0;
+    if (job_images_in_place(j, &in_place_slot) && j.stride % 4 == 0 && ((uintptr_t)j.img[0] & 3) == 0 && in_place_slot % 4 == 0) {
+        src = (const uint8_t *)j.img[0]; g.gpitch = j.stride; g.gray_slot = in_place_slot;      // the integral kernels read rows in 4-byte words
+    } else
+        for (int k = 0; k < nimg; k++)
+            if ((rc = stage_2d(ctx, ctx->ws->ln().gray.as<uint8_t>() + gp->g.gray_slot * k, gp->g.gpitch, j.img[k], j.stride, j.cols, j.rows, j.mem))) return rc;
+    run_integral(ctx, g, nullptr, nimg, src);
+    if (j.casc->c.has_tilted && (rc = run_tilted(ctx, g, nullptr, nimg, src))) return rc;
     j.gthr = (!j.raw_only && j.min_neighbors != 0) ? std::max(j.min_neighbors, 1) : 0;
-    j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = 1; j.cj.total = total;
-    if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, j.cj, j.gthr ? &j.gthr : nullptr, true))) return rc;
+    j.cj = CascadeJob(); j.cj.r0 = r0; j.cj.n = nimg; j.cj.total = total;
+    const std::vector<int> gthrv(nimg, j.gthr);
+    if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, j.cj, j.gthr ? gthrv.data() : nullptr, true))) return rc;
     j.gp = gp; gp->inflight++; j.dp = &gp->det; j.phase = 1;
     return NVCA_OK;
 }
@@ -1472,7 +1502,7 @@ static int detect_job_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
 {
     (void)hipSetDevice(ctx->device);
     if (j.phase == 0) {
-        for (int k = 0; k < 2; k++) j.out[k].clear();
+        for (int k = 0; k < kJobImages; k++) j.out[k].clear();
         if (j.kind == 2) return fb_enqueue_first(ctx, j, r0, total);
         if (j.kind == 1) return si_enqueue(ctx, j, r0, total);
         return plain_enqueue(ctx, j, r0, total);
@@ -1493,7 +1523,11 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     if (j.gp) { j.gp->inflight--; j.gp = nullptr; }
     if (rc) { j.phase = 3; return rc; }
     if (j.kind == 0) {
-        if (j.dp) { if (j.gthr && !grouped[0]) group_all(raw, j.min_neighbors); j.out[0].swap(raw[0]); }
+        if (j.dp)
+            for (int k = 0; k < j.nimg; k++) {
+                if (j.gthr && !grouped[k]) group_rectangles(raw[k], j.gthr, 0.2);
+                j.out[k].swap(raw[k]);
+            }
         j.phase = 3;
     } else if (j.kind == 1) {
         if (j.dp) { if (!j.raw_only) group_all(raw, j.min_neighbors); for (int k = 0; k < j.nimg; k++) j.out[k].swap(raw[k]); }
@@ -1512,8 +1546,104 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     return NVCA_OK;
 }
 
+// ---- working images of a batched part call ---------------------------------------------------------------------------
+int part_arena(nvca_ctx *ctx, size_t bytes, uint8_t **base)
+{
+    if (ctx->part.arena.ensure(bytes + 256)) { ctx->set_error("allocation failed (part detectors' images)"); return NVCA_ERR_NOMEM; }
+    *base = ctx->part.arena.as<uint8_t>();
+    return NVCA_OK;
+}
+int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep)
+{
+    PartWorkspace &pw = ctx->part;
+    const size_t need_l = (size_t)(n_keep + n_scratch + 1) * 256, need_h = (size_t)(std::max(n_keep, n_scratch) + 1) * 256 * sizeof(unsigned);
+    if (pw.luts.ensure(need_l)) { ctx->set_error("allocation failed (part detectors' LUTs)"); return NVCA_ERR_NOMEM; }
+    const void *old = pw.hist.p;
+    if (pw.hist.ensure(need_h)) { ctx->set_error("allocation failed (part detectors' histograms)"); return NVCA_ERR_NOMEM; }
+    if (pw.hist.p != old) NVCA_HIP_CHECK(ctx, hipMemset(pw.hist.p, 0, pw.hist.bytes));       // k_lut leaves what it read zeroed again
+    *keep = pw.luts.as<uint8_t>();
+    return NVCA_OK;
+}
+// a small table for the next launch: page-locked staging ring -> device ring, copied on the current lane
+static int part_table(nvca_ctx *ctx, const void *host, size_t bytes, void **dev)
+{
+    PartWorkspace &pw = ctx->part;
+    static constexpr size_t kRing = 256 * 1024;
+    if (pw.tables.ensure(kRing) || pw.h_tables.ensure(kRing)) { ctx->set_error("allocation failed (part detectors' tables)"); return NVCA_ERR_NOMEM; }
+    const size_t room = round_up(bytes, 64);
+    if (room > kRing) { ctx->set_error("part detectors: table too large"); return NVCA_ERR_ARG; }
+    if (pw.tab_used + room > kRing) { NVCA_HIP_CHECK(ctx, hipDeviceSynchronize()); pw.tab_used = 0; }      // a full turn: earlier uploads must have been consumed
+    uint8_t *h = pw.h_tables.as<uint8_t>() + pw.tab_used, *d = pw.tables.as<uint8_t>() + pw.tab_used;
+    memcpy(h, host, bytes);
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->cs()));
+    pw.tab_used += room;
+    *dev = d;
+    return NVCA_OK;
+}
+int part_gray_eq(nvca_ctx *ctx, const void *const *bgr, int n, int w, int h, int stride, uint8_t *gray, size_t slot, uint8_t *luts)
+{
+    int rc;
+    void *d_ptrs = nullptr;
+    if ((rc = part_table(ctx, bgr, (size_t)n * sizeof(void *), &d_ptrs))) return rc;
+    PreGeom g; make_geom(g, w, h, stride, 3, w, h);
+    g.gpitch = w; g.gray_slot = slot;
+    bool aligned = stride % 4 == 0 && w % 4 == 0 && slot % 4 == 0 && ((uintptr_t)gray & 3) == 0;
+    for (int k = 0; k < n; k++) aligned = aligned && ((uintptr_t)bgr[k] & 3) == 0;
+    unsigned *hist = ctx->part.hist.as<unsigned>();
+    { TimedLaunch t(ctx, NVCA_K_GRAY);
+      launch_gray(ctx->cs(), (const uint8_t *const *)d_ptrs, g, 0, nullptr, nullptr, nullptr, nullptr, w, gray, hist, n, aligned); }
+    { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), hist, w * h, luts, n, 1); }
+    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    return NVCA_OK;
+}
+int part_image_batch(nvca_ctx *ctx, const PartImageBatch &b, const uint8_t *luts)
+{
+    int rc;
+    const int n = (int)b.src.size();
+    if (!n) return NVCA_OK;
+    GeomPlan *gp = nullptr;
+    if ((rc = get_resize_plan(ctx, b.sw, b.sh, b.dw, b.dh, &gp))) return rc;
+    // one table: n source pointers, then (gray sources with a LUT) n LUT indices
+    std::vector<unsigned char> tab((size_t)n * sizeof(void *) + (size_t)n * sizeof(int));
+    memcpy(tab.data(), b.src.data(), (size_t)n * sizeof(void *));
+    const bool with_lut = !b.bgr && (int)b.lut_idx.size() == n;
+    if (with_lut) memcpy(tab.data() + (size_t)n * sizeof(void *), b.lut_idx.data(), (size_t)n * sizeof(int));
+    void *d_tab = nullptr;
+    if ((rc = part_table(ctx, tab.data(), tab.size(), &d_tab))) return rc;
+    unsigned *hist = b.post_eq ? ctx->part.hist.as<unsigned>() : nullptr;
+    uint8_t *scratch = ctx->part.luts.as<uint8_t>() + ctx->part.luts.bytes - (size_t)(n + 1) * 256;       // the scratch LUTs sit at the end
+    if (b.post_eq && (size_t)(n + 1) * 256 > ctx->part.luts.bytes) { ctx->set_error("internal: LUT storage"); return NVCA_ERR_ARG; }
+    { TimedLaunch t(ctx, NVCA_K_RESIZE1);
+      launch_work_resize(ctx->cs(), b.bgr, (const uint8_t *const *)d_tab, with_lut ? (const int *)((uint8_t *)d_tab + (size_t)n * sizeof(void *)) : nullptr, luts,
+                         b.sh, b.sstride, gp->tab.mode, gp->d_xofs.as<int>(), gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(),
+                         gp->tab.xmax, b.dst, b.dw, b.dh, b.dw, b.slot, hist, n); }
+    if (b.post_eq) {
+        { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), hist, b.dw * b.dh, scratch, n, 1); }
+        launch_apply_lut(ctx->cs(), b.dst, b.dw, b.dh, b.dw, scratch, b.dst, b.dw, n, b.slot, b.slot);
+    }
+    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    return NVCA_OK;
+}
+int part_flip_batch(nvca_ctx *ctx, const uint8_t *src, uint8_t *dst, int w, int h, int n, size_t slot)
+{
+    launch_flip_h(ctx->cs(), src, w, h, w, dst, w, n, slot, slot);
+    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    return NVCA_OK;
+}
+int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
+{
+    PartWorkspace &pw = ctx->part;
+    if (!pw.images_done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&pw.images_done, hipEventDisableTiming));
+    NVCA_HIP_CHECK(ctx, hipEventRecord(pw.images_done, ctx->cs()));
+    for (int i = 0; i < n; i++)
+        if (lanes[i] != ctx->cur_lane) NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->lane_streams[lanes[i]], pw.images_done, 0));
+    return NVCA_OK;
+}
+
 // run a set of detectMultiScale calls to completion: one wait per round for all of them.  lanes (optional, [n]): the lane
 // each job runs on -- jobs of one lane execute in order, lanes side by side
+double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS: where run_detect_jobs spends the host's time
+static inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
 {
     const int lane0 = ctx->cur_lane;
@@ -1524,6 +1654,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         if (!total) return NVCA_OK;
         int r0 = 0, rc = NVCA_OK;
         bool used[kLanes] = {false};
+        const double t0 = mono_s();
         for (int i = 0; i < n && !rc; i++) {
             if (jobs[i]->phase == 3) continue;
             ctx->cur_lane = lanes ? lanes[i] : lane0;
@@ -1531,12 +1662,17 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
             r0 += jobs[i]->slots();
         }
+        const double t1 = mono_s();
+        g_jobs_enqueue_s += t1 - t0;
         for (int l = 0; l < kLanes; l++) {
             if (!used[l]) continue;
             const hipError_t he = hipStreamSynchronize(ctx->lane_streams[l]);
             if (he != hipSuccess && !rc) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); rc = NVCA_ERR_HIP; }
         }
         ctx->cur_lane = lane0;
+        const double t2 = mono_s();
+        g_jobs_wait_s += t2 - t1;
+        struct Adv { double t; ~Adv() { g_jobs_advance_s += mono_s() - t; } } adv{t2};
         drain_timer(ctx);
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
@@ -1572,7 +1708,12 @@ int nvca::detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const
 nvca::DetectJob *nvca::detect_job_new() { return new (std::nothrow) DetectJob(); }
 void nvca::detect_job_free(DetectJob *j) { delete j; }
 const std::vector<nvca_rect> &nvca::detect_job_out(const DetectJob *j, int k) { return j->out[k]; }
-void nvca::detect_job_pair(DetectJob *j, const void *second_image) { j->img[1] = second_image; j->nimg = 2; }
+int nvca::detect_job_add_image(DetectJob *j, const void *image)
+{
+    if (j->kind == 2 || j->phase != 0 || j->nimg >= kJobImages) return -1;
+    j->img[j->nimg] = image;
+    return j->nimg++;
+}
 
 // fill in a job from detectMultiScale's arguments (flags decide the kind); NVCA_ERR_ARG for bad arguments
 int nvca::make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,

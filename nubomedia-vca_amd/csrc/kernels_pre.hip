@@ -158,27 +158,31 @@ void launch_gray(hipStream_t st, const uint8_t *const *d_src, const PreGeom &g, 
 
 // ---- 8UC1 resize (gray-then-resize order of the part detectors, pyramid levels)
 // one destination sample of cv::resize(INTER_LINEAR) 8UC1 (mode 0: copy, 2: exact 2x area-fast, 1: fixed-point bilinear)
-__device__ __forceinline__ int resize1_value(const uint8_t *__restrict__ src, int sh, int sstride, int mode,
-                                             const int *__restrict__ xofs, const short *__restrict__ ialpha,
-                                             const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax, int x, int y)
+// `px(row, col)`: the source sample (a gray byte, a gray byte through a LUT, or the gray value of a BGR pixel)
+template <class Px>
+__device__ __forceinline__ int resize1_sample(Px px, int sh, int mode,
+                                              const int *__restrict__ xofs, const short *__restrict__ ialpha,
+                                              const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax, int x, int y)
 {
-    if (mode == 0) return src[(size_t)y * sstride + x];
-    if (mode == 2) {
-        const uint8_t *s0 = src + (size_t)(2 * y) * sstride + 2 * x, *s1 = s0 + sstride;
-        return (s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2;
-    }
+    if (mode == 0) return px(y, x);
+    if (mode == 2) return (px(2 * y, 2 * x) + px(2 * y, 2 * x + 1) + px(2 * y + 1, 2 * x) + px(2 * y + 1, 2 * x + 1) + 2) >> 2;
     int sy0 = yofs[y], sy1 = sy0 + 1;
     sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
     sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
     const int sx = xofs[x];
-    const uint8_t *s0 = src + (size_t)sy0 * sstride + sx, *s1 = src + (size_t)sy1 * sstride + sx;
     const int b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
     int h0, h1;
     if (x < xmax) {
         const int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1];
-        h0 = s0[0] * a0 + s0[1] * a1; h1 = s1[0] * a0 + s1[1] * a1;
-    } else { h0 = s0[0] * 2048; h1 = s1[0] * 2048; }
+        h0 = px(sy0, sx) * a0 + px(sy0, sx + 1) * a1; h1 = px(sy1, sx) * a0 + px(sy1, sx + 1) * a1;
+    } else { h0 = px(sy0, sx) * 2048; h1 = px(sy1, sx) * 2048; }
     return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
+}
+__device__ __forceinline__ int resize1_value(const uint8_t *__restrict__ src, int sh, int sstride, int mode,
+                                             const int *__restrict__ xofs, const short *__restrict__ ialpha,
+                                             const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax, int x, int y)
+{
+    return resize1_sample([&](int r, int c) { return (int)src[(size_t)r * sstride + c]; }, sh, mode, xofs, ialpha, yofs, ibeta, xmax, x, y);
 }
 
 __global__ __launch_bounds__(256) void k_resize1(
@@ -261,6 +265,53 @@ void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
                        d_ibeta, xmax, dst, dw, dh, dstride, hist, src_slot, dst_slot);
 }
 
+// ---- working images of the part detectors, all frames of a batched call in one launch: image z of the launch is
+// resize(gray(frame z)) (BGR = true: the gray value of a source pixel is computed where the resize reads it -- cvtColor then
+// resize, EYE/kmseyedetect.cpp:948-956, NOSE/kmsnosedetect.cpp:836-841 -- without writing the full-size gray image) or
+// resize(lut[gray z]) (the eye detector equalizes the full-size gray image first, EYE :950), plus its histogram.
+template <bool BGR>
+__global__ __launch_bounds__(256) void k_work_resize(
+    const uint8_t *const *__restrict__ srcs, const int *__restrict__ lut_idx, const uint8_t *__restrict__ luts,
+    int sh, int sstride, int mode, const int *__restrict__ xofs, const short *__restrict__ ialpha,
+    const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax,
+    uint8_t *__restrict__ dst, int dw, int dh, int dstride, size_t dst_slot, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4][256];
+    __shared__ uint8_t sl[256];
+    const int tid = threadIdx.x, wave = tid >> 6, z = blockIdx.z;
+    for (int i = tid; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+    const uint8_t *__restrict__ src = srcs[z];
+    const bool use_lut = !BGR && lut_idx != nullptr;
+    if (use_lut) sl[tid] = luts[(size_t)lut_idx[z] * 256 + tid];
+    __syncthreads();
+    dst += (size_t)z * dst_slot;
+    const int x = blockIdx.x * 256 + tid;
+    for (int ry = 0; ry < kGrayRows; ry++) {
+        const int y = blockIdx.y * kGrayRows + ry;
+        if (y >= dh) break;
+        if (x < dw) {
+            int v;
+            if (BGR) v = resize1_sample([&](int r, int c) { const uint8_t *p = src + (size_t)r * sstride + (size_t)c * 3; return gray_of(p[0], p[1], p[2]); },
+                                        sh, mode, xofs, ialpha, yofs, ibeta, xmax, x, y);
+            else if (use_lut) v = resize1_sample([&](int r, int c) { return (int)sl[src[(size_t)r * sstride + c]]; }, sh, mode, xofs, ialpha, yofs, ibeta, xmax, x, y);
+            else v = resize1_value(src, sh, sstride, mode, xofs, ialpha, yofs, ibeta, xmax, x, y);
+            dst[(size_t)y * dstride + x] = (uint8_t)v;
+            if (hist) atomicAdd(&lh[wave][v], 1u);
+        }
+    }
+    if (hist) hist_flush(lh, hist + (size_t)z * 256, tid);
+}
+void launch_work_resize(hipStream_t st, bool bgr, const uint8_t *const *d_srcs, const int *d_lut_idx, const uint8_t *d_luts, int sh, int sstride,
+                        int mode, const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta, int xmax,
+                        uint8_t *dst, int dw, int dh, int dstride, size_t dst_slot, unsigned *hist, int batch)
+{
+    dim3 grid((dw + 255) / 256, (dh + kGrayRows - 1) / kGrayRows, batch);
+    if (bgr) NVCA_LAUNCH(k_work_resize<true>, grid, dim3(256), 0, st, d_srcs, d_lut_idx, d_luts, sh, sstride, mode, d_xofs, d_ialpha, d_yofs, d_ibeta, xmax,
+                         dst, dw, dh, dstride, dst_slot, hist);
+    else NVCA_LAUNCH(k_work_resize<false>, grid, dim3(256), 0, st, d_srcs, d_lut_idx, d_luts, sh, sstride, mode, d_xofs, d_ialpha, d_yofs, d_ibeta, xmax,
+                     dst, dw, dh, dstride, dst_slot, hist);
+}
+
 // ---- K2: equalizeHist LUT from the histogram (one block per slot)
 // `rezero`: the histogram is cleared again once read (the next frame's gray kernel accumulates into it) and the two
 // list counters of the cascade that follows are reset -- three fill launches less per batch.
@@ -327,10 +378,12 @@ void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, u
 }
 
 __global__ __launch_bounds__(256) void k_apply_lut(const uint8_t *__restrict__ src, int w, int h, int spitch,
-                                                   const uint8_t *__restrict__ lut, uint8_t *__restrict__ dst, int dpitch)
+                                                   const uint8_t *__restrict__ lut, uint8_t *__restrict__ dst, int dpitch,
+                                                   size_t src_slot, size_t dst_slot)
 {
     __shared__ uint8_t sl[256];
-    sl[threadIdx.x] = lut[threadIdx.x];
+    sl[threadIdx.x] = lut[(size_t)blockIdx.z * 256 + threadIdx.x];          // image z of the launch: its own LUT and slot
+    src += (size_t)blockIdx.z * src_slot; dst += (size_t)blockIdx.z * dst_slot;
     __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x;
     for (int ry = 0; ry < kGrayRows; ry++) {
@@ -339,26 +392,28 @@ __global__ __launch_bounds__(256) void k_apply_lut(const uint8_t *__restrict__ s
     }
 }
 void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spitch, const uint8_t *lut,
-                      uint8_t *dst, int dpitch)
+                      uint8_t *dst, int dpitch, int batch, size_t src_slot, size_t dst_slot)
 {
-    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
-    NVCA_LAUNCH(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch);
+    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, batch);
+    NVCA_LAUNCH(k_apply_lut, grid, dim3(256), 0, st, src, w, h, spitch, lut, dst, dpitch, src_slot, dst_slot);
 }
 
 // ---- cv::flip(src, dst, 1) (EAR/kmseardetect.cpp:800)
 __global__ __launch_bounds__(256) void k_flip_h(const uint8_t *__restrict__ src, int w, int h, int spitch,
-                                                uint8_t *__restrict__ dst, int dpitch)
+                                                uint8_t *__restrict__ dst, int dpitch, size_t src_slot, size_t dst_slot)
 {
+    src += (size_t)blockIdx.z * src_slot; dst += (size_t)blockIdx.z * dst_slot;
     const int x = blockIdx.x * 256 + threadIdx.x;
     for (int ry = 0; ry < kGrayRows; ry++) {
         const int y = blockIdx.y * kGrayRows + ry;
         if (y < h && x < w) dst[(size_t)y * dpitch + x] = src[(size_t)y * spitch + (w - 1 - x)];
     }
 }
-void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch)
+void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch, int batch, size_t src_slot,
+                   size_t dst_slot)
 {
-    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, 1);
-    NVCA_LAUNCH(k_flip_h, grid, dim3(256), 0, st, src, w, h, spitch, dst, dpitch);
+    dim3 grid((w + 255) / 256, (h + kGrayRows - 1) / kGrayRows, batch);
+    NVCA_LAUNCH(k_flip_h, grid, dim3(256), 0, st, src, w, h, spitch, dst, dpitch, src_slot, dst_slot);
 }
 
 // ---- K3a: per-band column sums of lut[gray] and its square

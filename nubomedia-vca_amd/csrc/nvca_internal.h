@@ -181,6 +181,14 @@ struct TrkWorkspace {
     void release_all() { slots.release(); labels.release(); acc.release(); out.release(); staging.release(); h_slots.release(); h_out.release(); }
 };
 
+// batched part detectors (parts.cpp): working images of a call carved from one arena, the small tables its launches read
+struct PartWorkspace {
+    DevBuf arena, tables, hist, luts; PinnedBuf h_tables;
+    size_t tab_used = 0;
+    hipEvent_t images_done = nullptr;
+    void release_all() { arena.release(); tables.release(); hist.release(); luts.release(); h_tables.release(); if (images_done) { (void)hipEventDestroy(images_done); images_done = nullptr; } }
+};
+
 struct DetectPlan;   // plan.cpp
 struct ScaleTable;   // plan.cpp: one cascade at one scale factor (geometry-independent stump records), cached in the context
 struct FaceTicket;   // api.cpp
@@ -229,6 +237,7 @@ struct nvca_ctx {
     std::map<std::pair<uint64_t, uint64_t>, nvca::ScaleTable *> scale_tables;   // (cascade uid, factor bits)
     std::unique_ptr<nvca::Workspace> ws;
     nvca::TrkWorkspace trk;           // tracker buffers live and die with the context
+    nvca::PartWorkspace part;
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
 #ifdef NVCA_STAMPS
@@ -290,12 +299,16 @@ void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
 void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride);
-void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch);
+void launch_flip_h(hipStream_t st, const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch, int batch = 1, size_t src_slot = 0,
+                   size_t dst_slot = 0);
 void launch_hist(hipStream_t st, const uint8_t *gray, int w, int h, int pitch, unsigned *hist);
 void launch_lut(hipStream_t st, unsigned *hist, int total, uint8_t *lut, int batch, int rezero = 0,
                 unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr);
 void launch_apply_lut(hipStream_t st, const uint8_t *src, int w, int h, int spitch, const uint8_t *lut,
-                      uint8_t *dst, int dpitch);
+                      uint8_t *dst, int dpitch, int batch = 1, size_t src_slot = 0, size_t dst_slot = 0);
+void launch_work_resize(hipStream_t st, bool bgr, const uint8_t *const *d_srcs, const int *d_lut_idx, const uint8_t *d_luts, int sh, int sstride,
+                        int mode, const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta, int xmax,
+                        uint8_t *dst, int dw, int dh, int dstride, size_t dst_slot, unsigned *hist, int batch);
 void launch_colsum(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g,
                    unsigned *bandsum, unsigned *bandsq, int batch);
 void launch_bandscan(hipStream_t st, const PreGeom &g, unsigned *bandsum, unsigned *bandsq, int batch);
@@ -366,6 +379,21 @@ struct CascadeArgs {
 // hipError_t (as int) when the grant is refused, 0 otherwise
 int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant);
 // detectMultiScale calls in halves (api.cpp): many calls share one wait per round
+// ---- working images of a batched part call (api.cpp), all on the current lane
+// N images of one launch set: image k = [equalizeHist](resize(source k)) at dst + k * slot, pitch dw.  BGR sources: gray of the frame
+// computed on the fly (cvtColor then resize); gray sources go through LUT lut_idx[k] of `luts` first when lut_idx is given
+struct PartImageBatch {
+    bool bgr = true, post_eq = true;
+    int sw = 0, sh = 0, sstride = 0, dw = 0, dh = 0;
+    std::vector<const void *> src; std::vector<int> lut_idx;
+    uint8_t *dst = nullptr; size_t slot = 0;
+};
+int part_arena(nvca_ctx *ctx, size_t bytes, uint8_t **base);                 // grows the arena (before anything of the call is queued)
+int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep);     // LUT storage: n_keep that live through the call + scratch
+int part_gray_eq(nvca_ctx *ctx, const void *const *bgr, int n, int w, int h, int stride, uint8_t *gray, size_t slot, uint8_t *luts);   // gray images + their equalisation LUTs
+int part_image_batch(nvca_ctx *ctx, const PartImageBatch &b, const uint8_t *luts);
+int part_flip_batch(nvca_ctx *ctx, const uint8_t *src, uint8_t *dst, int w, int h, int n, size_t slot);
+int part_images_done(nvca_ctx *ctx, const int *lanes, int n);                // the lanes in `lanes` wait for what the current lane has queued so far
 struct DetectJob;
 int make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
                     double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only);
@@ -373,7 +401,8 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
 DetectJob *detect_job_new();
 void detect_job_free(DetectJob *j);
 const std::vector<nvca_rect> &detect_job_out(const DetectJob *j, int k);
-void detect_job_pair(DetectJob *j, const void *second_image);     // SCALE_IMAGE on two images of one geometry (k = 0 / 1 in detect_job_out)
+constexpr int kJobImages = 32;                                    // images of one geometry that a plain / SCALE_IMAGE job can carry
+int detect_job_add_image(DetectJob *j, const void *image);       // one more image for the job's launch set; returns its index k (detect_job_out), -1: full / not possible
 // detectMultiScale(CV_HAAR_SCALE_IMAGE) on two images of one geometry with shared launches (api.cpp; used by parts.cpp)
 int detect_scale_image_pair(nvca_ctx *ctx, const nvca_cascade *casc, const void *img_a, const void *img_b, int w, int h, int stride,
                             int mem, double sf, int min_neighbors, int minw, int minh, std::vector<nvca_rect> *outs /* [2] */);

@@ -25,10 +25,11 @@ struct nvca_part_stream {
     RectV faces, la, lb;
     int num_frame = 0, num_frames_to_process = 0, no_det_a = 0, no_det_b = 0;
     std::deque<RectV> queue;
-    DevBuf d_frame, d_gray, d_small, d_part, d_flip;
 };
 
+namespace nvca { extern double g_jobs_enqueue_s, g_jobs_wait_s, g_jobs_advance_s; }
 namespace {
+inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline int cv_round(double v)
 {
     if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
@@ -38,15 +39,38 @@ inline int area(const nvca_rect &r) { return r.w * r.h; }
 
 // One frame of one part stream on its way through a batched call: what the three phases hand to each other.
 struct RoiJob { DetectJob *job = nullptr; nvca_rect roi{0, 0, 0, 0}; int side = 0; };
+// Streams of one batched call that were handed the same frame (the part detectors of one video stream all see the buffer the
+// face detector saw) share what they compute identically from it: the upload, the working images and the face pass.  And the
+// frames of the call share launches: every working image of one (frame geometry, size, chain) is made by one launch set, every
+// face pass of one kind over those images is one job.  Same arithmetic on the same bytes: the results are those of per-stream calls.
+struct FrameGroup {
+    const void *data = nullptr; int w = 0, h = 0, stride = 0, mem = 0;
+    const void *bgr = nullptr;               // device BGR (the caller's, or the one upload of a host frame)
+    int eye_index = -1;                      // an eye detector looks at it: index of its full-size gray image / LUT
+    size_t upload_at = 0, gray_at = 0;       // arena offsets
+};
+struct ImageRef { int batch = -1, k = 0; };
+struct ImageBatch {                          // the working images [equalizeHist](resize(gray or equalized gray)) of one size
+    int W = 0, H = 0, stride = 0, dw = 0, dh = 0; bool eye = false, post_eq = true, flips = false;
+    std::vector<int> members;                // frame groups, image k belongs to members[k]
+    size_t at = 0, slot = 0; uint8_t *base = nullptr;        // image k at base + k * slot (pitch dw), its mirror image at base + (count + k) * slot
+};
+struct FacePass {                            // type 0: EYE's plain scan, 1: NOSE / MOUTH SCALE_IMAGE pass, 2: EAR's pass over images and mirror images
+    int type = 0; const nvca_cascade *c = nullptr; int batch = 0; double sf = 0;
+    std::vector<int> members;                // images of the batch that some stream wants searched
+    std::vector<DetectJob *> jobs;           // kJobImages images per job
+    ~FacePass() { for (DetectJob *j : jobs) detect_job_free(j); }
+};
 struct PartWork {
     nvca_part_stream *s = nullptr; const nvca_frame *f = nullptr;
     bool early_return = false, run = false;
     int W = 0, H = 0, fw = 0, fh = 0, pw = 0, ph = 0;
     double scale_o2f = 1, scale_x2o = 1, scale_f2x = 1;
-    DetectJob *face_job = nullptr;           // the face pass (EAR: profile faces of the image and of its mirror)
+    int lane = 0, group = -1, pass = -1;
+    ImageRef small, part_ref;
     std::vector<RoiJob> rois;                // per face, in face order (EYE: right then left; EAR: side 0 then side 1)
     size_t n_side0 = 0;                      // EAR: how many of `rois` belong to side 0
-    ~PartWork() { detect_job_free(face_job); for (RoiJob &r : rois) detect_job_free(r.job); }
+    ~PartWork() { for (RoiJob &r : rois) detect_job_free(r.job); }
 };
 
 // detectMultiScale on a sub-matrix of a device image (pitch == cols), as a queued job; job == nullptr: cv::Mat's ROI
@@ -214,7 +238,6 @@ void nvca_part_stream_destroy(nvca_part_stream *s)
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    s->d_frame.release(); s->d_gray.release(); s->d_small.release(); s->d_part.release(); s->d_flip.release();
     delete s;
 }
 int nvca_part_stream_set_params(nvca_part_stream *s, const nvca_part_params *params)
@@ -255,18 +278,45 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     (void)hipSetDevice(ctx->device);
     // the image primitives below hand device buffers to each other on the context's stream: no drain in between
     struct Defer { nvca_ctx *c; Defer(nvca_ctx *x) : c(x) { c->defer_device_sync++; } ~Defer() { c->defer_device_sync--; } } defer(ctx);
+    std::vector<FrameGroup> groups;
+    std::vector<ImageBatch> batches;
+    std::deque<FacePass> passes;
     std::vector<PartWork> work(n);
     std::vector<DetectJob *> jobs;
     std::vector<int> job_lane;
-    // stream i's image chain and searches run on lane i mod kLanes: in order on that lane, side by side with the other lanes
+    int n_eye = 0;
+    // image k of the batch of (frame geometry, size, chain): asked for by frame group gi
+    auto request = [&](int gi, int dw, int dh, bool eye, bool post_eq) {
+        const FrameGroup &fg = groups[gi];
+        ImageRef r;
+        for (size_t bi = 0; bi < batches.size() && r.batch < 0; bi++) {
+            const ImageBatch &b = batches[bi];
+            if (b.W == fg.w && b.H == fg.h && b.stride == fg.stride && b.dw == dw && b.dh == dh && b.eye == eye && b.post_eq == post_eq) r.batch = (int)bi;
+        }
+        if (r.batch < 0) {
+            batches.emplace_back();
+            ImageBatch &b = batches.back();
+            b.W = fg.w; b.H = fg.h; b.stride = fg.stride; b.dw = dw; b.dh = dh; b.eye = eye; b.post_eq = post_eq;
+            r.batch = (int)batches.size() - 1;
+        }
+        ImageBatch &b = batches[r.batch];
+        const auto it = std::find(b.members.begin(), b.members.end(), gi);
+        r.k = (int)(it - b.members.begin());
+        if (it == b.members.end()) b.members.push_back(gi);
+        return r;
+    };
+    // the images are made on one lane; the face passes and the part searches run on the lanes side by side behind them.  Calls with
+    // several streams stay off lane 0, where a face detector's batch may be in flight (nvca_face_batch_submit)
     struct LaneGuard { nvca_ctx *c; ~LaneGuard() { c->cur_lane = 0; } } lane_guard{ctx};
     int rc = NVCA_OK;
     const int D = NVCA_MEM_DEVICE;
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
+    static const bool stats = getenv("NVCA_PART_STATS") != nullptr;    // diagnostic: the host's time per phase of calls with 8 or more streams, every 8 such calls
+    static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
+    const double ts0 = mono_s();
     // ---- phase 1: gating, image chains and face passes of every stream, in stream order
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
-        ctx->cur_lane = n > 1 ? i % kLanes : 0;
         nvca_part_stream *s = w.s = streams[i]; const nvca_frame *f = w.f = &frames[i];
         const int kind = s->p.kind, W = w.W = f->width, H = w.H = f->height;
         // conf_images: float arithmetic (EYE/kmseyedetect.cpp:331-339 and siblings)
@@ -295,46 +345,129 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         const int fw = w.fw = cv_round(W / w.scale_o2f), fh = w.fh = cv_round(H / w.scale_o2f);
         const int pw = w.pw = cv_round(W / w.scale_x2o), ph = w.ph = cv_round(H / w.scale_x2o);
         if (fw <= 0 || fh <= 0 || pw <= 0 || ph <= 0) { ctx->set_error("part stream: frame too small"); return NVCA_ERR_ARG; }
-        if (s->d_gray.ensure((size_t)W * H + 64) || s->d_small.ensure((size_t)fw * fh + 64) || s->d_part.ensure((size_t)pw * ph + 64) ||
-            s->d_flip.ensure((size_t)fw * fh + 64)) { ctx->set_error("part stream: allocation failed"); return NVCA_ERR_NOMEM; }
-        const void *src = f->data; const int sstride = f->stride;
-        if (f->mem == NVCA_MEM_HOST) {
-            if (s->d_frame.ensure((size_t)f->stride * H + 64)) { ctx->set_error("part stream: allocation failed"); return NVCA_ERR_NOMEM; }
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(s->d_frame.p, f->data, (size_t)f->stride * (H - 1) + (size_t)W * 3, hipMemcpyHostToDevice, ctx->cs()));
-            src = s->d_frame.p;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            const FrameGroup &fg = groups[gi];
+            if (fg.data == f->data && fg.w == W && fg.h == H && fg.stride == f->stride && fg.mem == f->mem) w.group = (int)gi;
         }
-        uint8_t *gray = s->d_gray.as<uint8_t>(), *small = s->d_small.as<uint8_t>(), *part = s->d_part.as<uint8_t>();
-        const double sf_face = 1 + s->p.scale_factor_pct * 1.0 / 100;
-        CK(nvca_bgr2gray(ctx, src, W, H, sstride, 3, D, gray, W));
-        if (kind == NVCA_PART_EYE) CK(nvca_equalize_hist(ctx, gray, W, H, W, D, gray, W));          // EYE :950
-        if (kind == NVCA_PART_EAR) {
-            CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, small, fw, fh, fw));
-            CK(nvca_equalize_hist(ctx, small, fw, fh, fw, D, small, fw));
-            CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, part, pw, ph, pw));
-            CK(nvca_equalize_hist(ctx, part, pw, ph, pw, D, part, pw));
-            CK(nvca_flip_horizontal(ctx, small, fw, fh, fw, D, s->d_flip.p, fw));                    // EAR :800
-            // profile faces in the image and in its mirror: one launch set (EAR :656-659, :796-803)
-            if (!(w.face_job = detect_job_new())) return NVCA_ERR_NOMEM;
-            CK(make_detect_job(ctx, *w.face_job, s->face, small, fw, fh, fw, D, sf_face, 2, NVCA_HAAR_SCALE_IMAGE, 3, 3, fw, fh, false));
-            detect_job_pair(w.face_job, s->d_flip.p);
+        if (w.group < 0) {
+            groups.emplace_back();
+            w.group = (int)groups.size() - 1;
+            FrameGroup &fg = groups.back();
+            fg.data = f->data; fg.w = W; fg.h = H; fg.stride = f->stride; fg.mem = f->mem;
+        }
+        w.lane = n > 1 ? 1 + w.group % (kLanes - 1) : 0;     // the part searches of one frame's streams share a lane
+        // the images this stream works on: requested here, computed below for all streams at once
+        if (kind == NVCA_PART_EYE) {
+            FrameGroup &fg = groups[w.group];
+            if (fg.eye_index < 0) fg.eye_index = n_eye++;
+            if (0 == s->p.detect_event) w.small = request(w.group, fw, fh, true, false);
+            w.part_ref = request(w.group, pw, ph, true, true);
         } else {
-            if (0 == s->p.detect_event) {
-                CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, small, fw, fh, fw));
-                if (!(w.face_job = detect_job_new())) return NVCA_ERR_NOMEM;
-                if (kind == NVCA_PART_EYE)
-                    CK(make_detect_job(ctx, *w.face_job, s->face, small, fw, fh, fw, D, sf_face, 3, 0, 30, 30, 0, 0, false));
-                else {
-                    CK(nvca_equalize_hist(ctx, small, fw, fh, fw, D, small, fw));
-                    CK(make_detect_job(ctx, *w.face_job, s->face, small, fw, fh, fw, D, sf_face, 2, NVCA_HAAR_SCALE_IMAGE, 3, 3, 0, 0, false));
-                }
-            }
-            CK(nvca_resize_linear(ctx, gray, W, H, W, 1, D, part, pw, ph, pw));
-            CK(nvca_equalize_hist(ctx, part, pw, ph, pw, D, part, pw));
+            if (kind == NVCA_PART_EAR || 0 == s->p.detect_event) w.small = request(w.group, fw, fh, false, true);
+            w.part_ref = request(w.group, pw, ph, false, true);
+            if (kind == NVCA_PART_EAR) batches[w.small.batch].flips = true;
         }
-        if (w.face_job) { jobs.push_back(w.face_job); job_lane.push_back(ctx->cur_lane); }
+        // its face pass: one job per (kind of pass, cascade, image set, scale factor), however many streams ask for it
+        if (w.small.batch >= 0) {
+            const double sf_face = 1 + s->p.scale_factor_pct * 1.0 / 100;
+            const int type = kind == NVCA_PART_EYE ? 0 : (kind == NVCA_PART_EAR ? 2 : 1);
+            for (size_t pi = 0; pi < passes.size(); pi++)
+                if (passes[pi].type == type && passes[pi].c == s->face && passes[pi].batch == w.small.batch && passes[pi].sf == sf_face) w.pass = (int)pi;
+            if (w.pass < 0) { passes.emplace_back(); w.pass = (int)passes.size() - 1; FacePass &fp = passes.back(); fp.type = type; fp.c = s->face; fp.batch = w.small.batch; fp.sf = sf_face; }
+            FacePass &fp = passes[w.pass];
+            if (std::find(fp.members.begin(), fp.members.end(), w.small.k) == fp.members.end()) fp.members.push_back(w.small.k);
+        }
     }
-    ctx->cur_lane = 0;
+    // ---- phase 1b: every image the call needs, in a handful of launches
+    {
+        ctx->cur_lane = n > 1 ? 1 : 0;
+        // arena: uploads of host frames | full-size gray images of the eye detectors' frames | the working images, batch by batch
+        size_t need = 0;
+        auto carve = [&](size_t bytes) { const size_t at = need; need += (bytes + 255) & ~(size_t)255; return at; };
+        for (FrameGroup &fg : groups) if (fg.mem == NVCA_MEM_HOST) fg.upload_at = carve((size_t)fg.stride * fg.h);
+        for (int e = 0; e < n_eye; e++)              // in LUT order: frames of one geometry then sit at equal distances
+            for (FrameGroup &fg : groups) if (fg.eye_index == e) fg.gray_at = carve((size_t)fg.w * fg.h);
+        for (ImageBatch &b : batches) { b.slot = ((size_t)b.dw * b.dh + 255) & ~(size_t)255; b.at = carve(b.slot * b.members.size() * (b.flips ? 2 : 1)); }
+        uint8_t *arena = nullptr, *eye_luts = nullptr;
+        CK(part_arena(ctx, need, &arena));
+        size_t max_members = 1;
+        for (const ImageBatch &b : batches) max_members = std::max(max_members, b.members.size());
+        CK(part_luts(ctx, n_eye, (int)max_members, &eye_luts));
+        for (FrameGroup &fg : groups) {
+            fg.bgr = fg.data;
+            if (fg.mem == NVCA_MEM_HOST) {
+                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(arena + fg.upload_at, fg.data, (size_t)fg.stride * (fg.h - 1) + (size_t)fg.w * 3, hipMemcpyHostToDevice, ctx->cs()));
+                fg.bgr = arena + fg.upload_at;
+            }
+        }
+        // EYE :948-950: cvtColor + equalizeHist of the whole frame -- gray images + LUTs here, the LUT is applied where the resizes read
+        {
+            std::vector<char> done(groups.size(), 0);
+            for (size_t gi = 0; gi < groups.size(); gi++) {
+                if (groups[gi].eye_index < 0 || done[gi]) continue;
+                // frames of one geometry whose gray slots and LUT indices run on: one launch set
+                std::vector<const void *> srcs; const FrameGroup &g0 = groups[gi];
+                const size_t slot = ((size_t)g0.w * g0.h + 255) & ~(size_t)255;
+                for (size_t gj = gi; gj < groups.size(); gj++) {
+                    const FrameGroup &fg = groups[gj];
+                    if (fg.eye_index < 0 || done[gj] || fg.w != g0.w || fg.h != g0.h || fg.stride != g0.stride) continue;
+                    if (fg.eye_index != g0.eye_index + (int)srcs.size() || fg.gray_at != g0.gray_at + slot * srcs.size()) continue;
+                    srcs.push_back(fg.bgr); done[gj] = 1;
+                }
+                CK(part_gray_eq(ctx, srcs.data(), (int)srcs.size(), g0.w, g0.h, g0.stride, arena + g0.gray_at, slot, eye_luts + (size_t)g0.eye_index * 256));
+            }
+        }
+        for (ImageBatch &b : batches) {
+            PartImageBatch ib;
+            ib.bgr = !b.eye; ib.post_eq = b.post_eq; ib.sw = b.W; ib.sh = b.H; ib.sstride = b.eye ? b.W : b.stride; ib.dw = b.dw; ib.dh = b.dh;
+            ib.dst = b.base = arena + b.at; ib.slot = b.slot;
+            for (int gi : b.members) {
+                const FrameGroup &fg = groups[gi];
+                ib.src.push_back(b.eye ? (const void *)(arena + fg.gray_at) : fg.bgr);
+                if (b.eye) ib.lut_idx.push_back(fg.eye_index);
+            }
+            CK(part_image_batch(ctx, ib, eye_luts));
+            if (b.flips) CK(part_flip_batch(ctx, b.base, b.base + b.slot * b.members.size(), b.dw, b.dh, (int)b.members.size(), b.slot));     // EAR :800
+        }
+        // the face passes: members in image order, so that a pass over all images of a batch reads them in place
+        int next_lane = 2;
+        std::vector<int> used_lanes;
+        for (FacePass &fp : passes) {
+            std::sort(fp.members.begin(), fp.members.end());
+            const ImageBatch &b = batches[fp.batch];
+            const int per_job = fp.type == 2 ? kJobImages / 2 : kJobImages;
+            for (size_t m0 = 0; m0 < fp.members.size(); m0 += per_job) {
+                const size_t m1 = std::min(fp.members.size(), m0 + per_job);
+                DetectJob *job = detect_job_new();
+                if (!job) return NVCA_ERR_NOMEM;
+                fp.jobs.push_back(job);
+                const uint8_t *first = b.base + b.slot * fp.members[m0];
+                if (fp.type == 0) CK(make_detect_job(ctx, *job, fp.c, first, b.dw, b.dh, b.dw, D, fp.sf, 3, 0, 30, 30, 0, 0, false));                               // EYE :958-960
+                else if (fp.type == 1) CK(make_detect_job(ctx, *job, fp.c, first, b.dw, b.dh, b.dw, D, fp.sf, 2, NVCA_HAAR_SCALE_IMAGE, 3, 3, 0, 0, false));       // NOSE :843-846, MOUTH :845-848
+                else CK(make_detect_job(ctx, *job, fp.c, first, b.dw, b.dh, b.dw, D, fp.sf, 2, NVCA_HAAR_SCALE_IMAGE, 3, 3, b.dw, b.dh, false));                    // EAR :656-659
+                for (size_t m = m0 + 1; m < m1; m++) if (detect_job_add_image(job, b.base + b.slot * fp.members[m]) < 0) return NVCA_ERR_ARG;
+                if (fp.type == 2)          // ... and the mirrored images (EAR :796-803): results k + count
+                    for (size_t m = m0; m < m1; m++) if (detect_job_add_image(job, b.base + b.slot * (b.members.size() + fp.members[m])) < 0) return NVCA_ERR_ARG;
+                const int lane = n > 1 ? next_lane : 0;
+                next_lane = next_lane + 1 < kLanes ? next_lane + 1 : 2;
+                jobs.push_back(job); job_lane.push_back(lane); used_lanes.push_back(lane);
+            }
+        }
+        for (const PartWork &w : work) if (w.run) used_lanes.push_back(w.lane);     // the part searches of phase 2 read these images on the streams' lanes
+        std::sort(used_lanes.begin(), used_lanes.end());
+        used_lanes.erase(std::unique(used_lanes.begin(), used_lanes.end()), used_lanes.end());
+        CK(part_images_done(ctx, used_lanes.data(), (int)used_lanes.size()));
+    }
+    const double ts1 = mono_s();
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 1: every face pass
+    // a stream's faces: result k of its pass's job
+    auto pass_result = [&](const PartWork &w, bool mirrored) -> const std::vector<nvca_rect> & {
+        const FacePass &fp = passes[w.pass];
+        const size_t pos = std::find(fp.members.begin(), fp.members.end(), w.small.k) - fp.members.begin();
+        const size_t per_job = fp.type == 2 ? kJobImages / 2 : kJobImages, ji = pos / per_job, in_job = std::min(fp.members.size() - ji * per_job, per_job);
+        return detect_job_out(fp.jobs[ji], (int)(pos % per_job + (mirrored ? in_job : 0)));
+    };
+    const double ts2 = mono_s();
     // ---- phase 2: the part searches of every face of every stream
     jobs.clear(); job_lane.clear();
     for (int i = 0; i < n; i++) {
@@ -342,13 +475,13 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         if (!w.run) continue;
         nvca_part_stream *s = w.s;
         const int kind = s->p.kind;
-        const uint8_t *part = s->d_part.as<uint8_t>();
+        const uint8_t *part = batches[w.part_ref.batch].base + batches[w.part_ref.batch].slot * w.part_ref.k;
         if (kind == NVCA_PART_EAR) {
-            CK(find_ears_begin(s, w, detect_job_out(w.face_job, 0), part, s->a, 0));
+            CK(find_ears_begin(s, w, pass_result(w, false), part, s->a, 0));
             w.n_side0 = w.rois.size();
-            CK(find_ears_begin(s, w, detect_job_out(w.face_job, 1), part, s->b, 1));
+            CK(find_ears_begin(s, w, pass_result(w, true), part, s->b, 1));
         } else {
-            if (w.face_job) { const std::vector<nvca_rect> &fv = detect_job_out(w.face_job, 0); s->faces.assign(fv.begin(), fv.begin() + std::min<size_t>(fv.size(), 256)); }
+            if (w.pass >= 0) { const std::vector<nvca_rect> &fv = pass_result(w, false); s->faces.assign(fv.begin(), fv.begin() + std::min<size_t>(fv.size(), 256)); }
             const double scale_f2x = w.scale_f2x;
             for (const nvca_rect &r : s->faces) {
                 if (kind == NVCA_PART_EYE) {
@@ -381,9 +514,20 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
                 }
             }
         }
-        for (RoiJob &r : w.rois) if (r.job) { jobs.push_back(r.job); job_lane.push_back(n > 1 ? i % kLanes : 0); }
+        for (RoiJob &r : w.rois) if (r.job) { jobs.push_back(r.job); job_lane.push_back(w.lane); }
     }
+    const double ts3 = mono_s();
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 2 (+ one more for searches that narrowed)
+    if (stats) {
+        const double ts4 = mono_s();
+        if (n >= 8) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
+        else g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
+        if (n >= 8 && ++calls % 8 == 0) {
+            fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f\n",
+                    acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3);
+            acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
+        }
+    }
 #undef CK
     // ---- phase 3: merging heuristics, hysteresis, emission -- in stream order
     for (int i = 0; i < n; i++) {

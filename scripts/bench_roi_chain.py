@@ -1,7 +1,7 @@
 """BASELINE config 3: 1080p face -> eye + nose + mouth + ear ROI chain on one stream, frames resident in
 HBM; the part detectors run in detect-event mode on the face boxes of the same frame (the reference's
 `nubofacedetector ! nuboeyedetector detect-event=1 ! ...` pipeline).  Prints frames/s and the per-element cost."""
-import sys, time, os
+import json, sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nubomedia-vca_amd"))
 import numpy as np, torch
@@ -76,9 +76,51 @@ def tick(i):
     return sum(len(a) + len(b) for a, b in res)
 
 
+def tick_pipelined(i):
+    """what a pipeline with a queue between the face detector and the part detectors does: the face detector's batch is
+    queued (nvca_face_batch_submit), the part detectors' call runs meanwhile, then the face results are collected"""
+    fb = [fr[(i + 3 * v) % N] for v in range(V)]
+    tk = ctx.face_batch_submit(faces_v, fb)
+    res = capi.part_batch_process(ctx, flat, [fb[v] for v in range(V) for _ in range(4)])
+    ctx.face_batch_collect(tk)
+    return sum(len(a) + len(b) for a, b in res)
+
+
+# detect-event chain: the part detectors take the faces the face detector published (no face pass of their own); the face
+# detector works on tick i + 1 while they work on tick i
+faces_e = [capi.FaceStream(ctx, face_c, width_to_process=W, multi_scale_factor=10) for _ in range(V)]
+parts_e = [capi.PartStream(ctx, k, face_c, pc[a], pc[b] if b else None, detect_event=1) for _ in range(V) for k, a, b in kinds]
+state = {}
+
+
+def tick_event(i):
+    fb = [fr[(i + 3 * v) % N] for v in range(V)]
+    if "boxes" not in state:
+        state["boxes"] = [b for b, _ in ctx.face_batch_process(faces_e, fb)]
+    nxt = [fr[(i + 1 + 3 * v) % N] for v in range(V)]
+    tk = ctx.face_batch_submit(faces_e, nxt)
+    for v in range(V):
+        for j in range(4):
+            parts_e[4 * v + j].push_faces(state["boxes"][v])
+    res = capi.part_batch_process(ctx, parts_e, [fb[v] for v in range(V) for _ in range(4)])
+    state["boxes"] = [b for b, _ in ctx.face_batch_collect(tk)]
+    return sum(len(a) + len(b) for a, b in res)
+
+
+K2 = 24
+for name, fn in (("pipelined", tick_pipelined), ("detect_event_pipelined", tick_event)):
+    for i in range(3):
+        fn(i)
+    t0 = time.perf_counter()
+    found = 0
+    for i in range(3, 3 + K2):
+        found += fn(i)
+    ctx.synchronize()
+    dtv = time.perf_counter() - t0
+    print(json.dumps({"roi_chain_batched_" + name: {"video_streams": V, "frames_per_s": V * K2 / dtv, "ms_per_tick": dtv / K2 * 1e3, "parts_per_frame": found / (V * K2)}}))
+
 for i in range(3):
     tick(i)
-K2 = 24
 t0 = time.perf_counter()
 found = 0
 for i in range(K2):
@@ -93,7 +135,6 @@ ctx.synchronize()
 kt = ctx.kernel_timing()
 ctx.enable_kernel_timing(0)
 busy_ms = sum(v[0] for v in kt.values())
-import json
 # algorithmic bytes of the chain per video frame (SURVEY.md 8d formula applied to each working image): the face detector's
 # 60.21 MB plus, per part detector, BGR in + gray out/in + the small working images' integrals
 alg = 60.21e6 + 4 * (3 * W * H + 2 * W * H) + 4 * 25 * (320 * 180 + 160 * 90)

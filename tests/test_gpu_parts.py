@@ -159,6 +159,44 @@ def test_part_batch_mixed_sizes_and_event_mode(env):
         capi.part_batch_process(ctx, [pairs[0][0], pairs[0][0]], [scenes[0][0], scenes[0][0]])
 
 
+def test_part_batch_streams_on_one_frame_share_their_work(env):
+    """several part detectors handed the SAME frame in one call (the elements of one video stream): the upload, the gray
+    image, the working images and the face pass are computed once per frame and shared where the requests are identical --
+    and only there: different working widths, scale factors, the eye detector's equalized chain and event-mode streams all
+    sit in the same group.  Host frames (one upload per frame) and device frames; lists as if every stream ran alone."""
+    import torch
+    from nubovca import capi
+    ctx, dev, cpu = env
+    specs = [("nose", {}), ("mouth", {}), ("ear", {}), ("eye", {}), ("nose", {"width_to_process": 160}), ("mouth", {"multi_scale_factor": 15}),
+             ("nose", {}), ("eye", {"detect_event": 1}), ("mouth", {"detect_event": 1}), ("ear", {"width_to_process": 160})]
+    for mem in ("host", "device"):
+        V = 2
+        pairs = [[_streams(env, k, **p) for k, p in specs] for _ in range(V)]
+        scenes = [_scene(800, 600, 4, 4100 + 57 * v, two_faces=(v == 0)) for v in range(V)]
+        fs = [capi.FaceStream(ctx, dev["face"]) for _ in range(V)]
+        tot = 0
+        for t in range(4):
+            frames = [scenes[v][t] for v in range(V)]
+            for v in range(V):
+                boxes, _ = fs[v].process(frames[v])
+                for (k, p), (g, o) in zip(specs, pairs[v]):
+                    if p.get("detect_event") and len(boxes) and t != 2:
+                        g.push_faces(boxes); o.push_faces(boxes)
+            if mem == "device":
+                keep = [torch.from_numpy(f).cuda() for f in frames]
+                torch.cuda.synchronize()
+                handed = [capi.make_frame(k.data_ptr(), 800, 600, 800 * 3, capi.MEM_DEVICE) for k in keep]
+            else:
+                handed = frames
+            order = [(v, j) for j in range(len(specs)) for v in range(V)]          # the streams of a frame are not adjacent in the call
+            res = capi.part_batch_process(ctx, [pairs[v][j][0] for v, j in order], [handed[v] for v, j in order])
+            for (v, j), (ga, gb) in zip(order, res):
+                ea, eb = pairs[v][j][1].process(frames[v])
+                assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (mem, t, v, specs[j], ga, ea, gb, eb)
+                tot += len(ea) + len(eb)
+        assert tot > 0
+
+
 def test_flip_primitive(env):
     import ctypes as C
     import orc
