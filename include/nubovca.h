@@ -143,6 +143,17 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src_gray, int w, int h, int st
 /* cv::flip(src, dst, 1) EAR/kmseardetect.cpp:800 */
 int nvca_flip_horizontal(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,
                          void *dst_gray, int dst_stride);
+/* view-faces / view-eyes / ...: the outlines the elements draw on a viewed frame, on the frame where it is --
+ * host memory (the GStreamer shim's mapped buffer) or device memory (a viewed stream that stays in HBM makes no round trip).
+ * NVCA_SHAPE_RECT3: cvRectangle(img, (x, y), (x + w, y + h), colour, 3, 8, 0) as FACE/kmsfacedetect.cpp:836-845,
+ * TRK/gstnubotracker.cpp:388-395 and the nose / mouth / ear elements call it: the 3-pixel band around the outline, the four
+ * outermost corner pixels left out (round joins of radius 1).  NVCA_SHAPE_RING4: circle(img, (x, y), w, colour, 4, 8, 0),
+ * EYE/kmseyedetect.cpp:1075-1092: the pixels at distance [w - 2, w + 2] from the centre.  Shapes are drawn in order.
+ * The rasterisation rules are this library's statement of OpenCV's thick-line code, not pixel-verified against it. */
+#define NVCA_SHAPE_RECT3 0
+#define NVCA_SHAPE_RING4 1
+typedef struct { int kind; int x, y, w, h; uint8_t bgra[4]; } nvca_shape;
+int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const nvca_shape *shapes, int n);
 /* cv::integral as used inside detectMultiScale: sum int32 and sqsum float64,
  * both dense (h+1)*(w+1) */
 int nvca_integral(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,

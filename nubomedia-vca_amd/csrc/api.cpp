@@ -1075,6 +1075,34 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     return unstage_2d(ctx, dst, dst_stride, ws.ln().aux.p, g.gpitch, w, h, mem);
 }
 
+int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const nvca_shape *shapes, int n)
+{
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!frame || (channels != 3 && channels != 4) || n < 0 || (n > 0 && !shapes) || n > 1024) return NVCA_ERR_ARG;
+    int rc = check_img(ctx, frame->data, frame->width, frame->height, frame->stride, channels, frame->mem);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++)
+        if ((shapes[i].kind != NVCA_SHAPE_RECT3 && shapes[i].kind != NVCA_SHAPE_RING4) || std::abs((long long)shapes[i].x) > (1 << 24) || std::abs((long long)shapes[i].y) > (1 << 24) ||
+            std::abs((long long)shapes[i].w) > (1 << 24) || std::abs((long long)shapes[i].h) > (1 << 24)) return NVCA_ERR_ARG;
+    if (!n) return NVCA_OK;
+    if (frame->mem == NVCA_MEM_HOST) { draw_shapes_host((uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, shapes, n); return NVCA_OK; }
+    (void)hipSetDevice(ctx->device);
+    int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;          // common bounding box, clipped to the frame
+    for (int i = 0; i < n; i++) {
+        const nvca_shape &sh = shapes[i];
+        int x0, y0, x1, y1;
+        if (sh.kind == NVCA_SHAPE_RING4) { const int r = (sh.w > 0 ? sh.w : 0) + 2; x0 = sh.x - r; x1 = sh.x + r; y0 = sh.y - r; y1 = sh.y + r; }
+        else { x0 = std::min(sh.x, sh.x + sh.w) - 1; x1 = std::max(sh.x, sh.x + sh.w) + 1; y0 = std::min(sh.y, sh.y + sh.h) - 1; y1 = std::max(sh.y, sh.y + sh.h) + 1; }
+        bx0 = std::min(bx0, x0); by0 = std::min(by0, y0); bx1 = std::max(bx1, x1); by1 = std::max(by1, y1);
+    }
+    bx0 = std::max(bx0, 0); by0 = std::max(by0, 0); bx1 = std::min(bx1, frame->width - 1); by1 = std::min(by1, frame->height - 1);
+    if (bx0 > bx1 || by0 > by1) return NVCA_OK;
+    void *d_shapes = nullptr;
+    if ((rc = part_table(ctx, shapes, (size_t)n * sizeof(nvca_shape), &d_shapes))) return rc;
+    launch_draw_shapes(ctx->cs(), (uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, (const nvca_shape *)d_shapes, n, bx0, by0, bx1, by1);
+    return finish_device_op(ctx);
+}
+
 int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
 {
     NVCA_LOCK_OR_FAIL(ctx);
@@ -1565,7 +1593,7 @@ int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep)
     return NVCA_OK;
 }
 // a small table for the next launch: page-locked staging ring -> device ring, copied on the current lane
-static int part_table(nvca_ctx *ctx, const void *host, size_t bytes, void **dev)
+int part_table(nvca_ctx *ctx, const void *host, size_t bytes, void **dev)
 {
     PartWorkspace &pw = ctx->part;
     static constexpr size_t kRing = 256 * 1024;

@@ -174,4 +174,22 @@ void join_objects(std::vector<nvca_rect> &sb, int min_area, long max_area, int d
     }
 }
 
+// view-* outlines on a host frame: the bounding box of every shape is walked, the last shape that covers a pixel colours it
+void draw_shapes_host(uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *shapes, int n)
+{
+    for (int i = 0; i < n; i++) {
+        const nvca_shape &sh = shapes[i];
+        int x0, y0, x1, y1;
+        if (sh.kind == NVCA_SHAPE_RING4) { const int r = (sh.w > 0 ? sh.w : 0) + 2; x0 = sh.x - r; x1 = sh.x + r; y0 = sh.y - r; y1 = sh.y + r; }
+        else { x0 = std::min(sh.x, sh.x + sh.w) - 1; x1 = std::max(sh.x, sh.x + sh.w) + 1; y0 = std::min(sh.y, sh.y + sh.h) - 1; y1 = std::max(sh.y, sh.y + sh.h) + 1; }
+        x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, w - 1); y1 = std::min(y1, h - 1);
+        for (int y = y0; y <= y1; y++)
+            for (int x = x0; x <= x1; x++)
+                if (shape_covers(sh, x, y)) {
+                    uint8_t *p = data + (size_t)y * stride + (size_t)x * channels;
+                    for (int k = 0; k < channels; k++) p[k] = sh.bgra[k];
+                }
+    }
+}
+
 } // namespace nvca

@@ -829,4 +829,28 @@ void launch_pyr_integral(hipStream_t st, const uint8_t *aux, size_t aux_slot, co
     NVCA_LAUNCH(k_pyr_integral, dim3(nlev * nimg), dim3(1024), (size_t)kSmallIntWords * sizeof(unsigned), st, aux, aux_slot, levels, nimg, sum, sq32, sum_slot, P);
 }
 
+// ---- view-* outlines on a device frame: a thread per pixel of the shapes' common bounding box; the last shape of the list
+// that covers the pixel colours it (= the shapes drawn one after the other)
+__global__ __launch_bounds__(256) void k_draw_shapes(uint8_t *__restrict__ data, int w, int h, int stride, int channels,
+                                                     const nvca_shape *__restrict__ shapes, int n, int bx0, int by0, int bx1, int by1)
+{
+    extern __shared__ nvca_shape sh_s[];
+    for (int i = threadIdx.x; i < n; i += 256) sh_s[i] = shapes[i];
+    __syncthreads();
+    const int x = bx0 + blockIdx.x * 64 + (threadIdx.x & 63), y = by0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x > bx1 || y > by1 || x >= w || y >= h) return;
+    for (int i = n - 1; i >= 0; i--)
+        if (shape_covers(sh_s[i], x, y)) {
+            uint8_t *p = data + (size_t)y * stride + (size_t)x * channels;
+            for (int k = 0; k < channels; k++) p[k] = sh_s[i].bgra[k];
+            return;
+        }
+}
+void launch_draw_shapes(hipStream_t st, uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *d_shapes, int n,
+                        int bx0, int by0, int bx1, int by1)
+{
+    dim3 grid((bx1 - bx0 + 64) / 64, (by1 - by0 + 4) / 4, 1);
+    NVCA_LAUNCH(k_draw_shapes, grid, dim3(256), (size_t)n * sizeof(nvca_shape), st, data, w, h, stride, channels, d_shapes, n, bx0, by0, bx1, by1);
+}
+
 } // namespace nvca

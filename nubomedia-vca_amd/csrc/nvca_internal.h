@@ -379,6 +379,33 @@ struct CascadeArgs {
 // hipError_t (as int) when the grant is refused, 0 otherwise
 int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant);
 // detectMultiScale calls in halves (api.cpp): many calls share one wait per round
+// ---- view-* outlines (nvca_draw_shapes): one coverage rule for the host rasteriser and the kernel
+#if defined(__HIPCC__)
+#define NVCA_HD __host__ __device__
+#else
+#define NVCA_HD
+#endif
+NVCA_HD inline bool shape_covers(const nvca_shape &sh, int px, int py)
+{
+    if (sh.kind == NVCA_SHAPE_RING4) {
+        if (sh.w < 0) return false;
+        const long long ro = sh.w + 2, ri = sh.w - 2 > 0 ? sh.w - 2 : 0, dx = px - sh.x, dy = py - sh.y, d2 = dx * dx + dy * dy;
+        return d2 <= ro * ro && d2 >= ri * ri;
+    }
+    int x0 = sh.x, y0 = sh.y, x1 = sh.x + sh.w, y1 = sh.y + sh.h;
+    if (x0 > x1) { const int t = x0; x0 = x1; x1 = t; }
+    if (y0 > y1) { const int t = y0; y0 = y1; y1 = t; }
+    const int ax0 = px > x0 ? px - x0 : x0 - px, ax1 = px > x1 ? px - x1 : x1 - px;
+    const int ay0 = py > y0 ? py - y0 : y0 - py, ay1 = py > y1 ? py - y1 : y1 - py;
+    if (px >= x0 && px <= x1 && (ay0 <= 1 || ay1 <= 1)) return true;          // the two horizontal edges, 3 rows each
+    if (py >= y0 && py <= y1 && (ax0 <= 1 || ax1 <= 1)) return true;          // the two vertical edges, 3 columns each
+    const int mx = ax0 < ax1 ? ax0 : ax1, my = ay0 < ay1 ? ay0 : ay1;         // round joins: the 4-neighbourhood of a vertex
+    return mx + my == 1;
+}
+void draw_shapes_host(uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *shapes, int n);
+void launch_draw_shapes(hipStream_t st, uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *d_shapes, int n,
+                        int bx0, int by0, int bx1, int by1);
+
 // ---- working images of a batched part call (api.cpp), all on the current lane
 // N images of one launch set: image k = [equalizeHist](resize(source k)) at dst + k * slot, pitch dw.  BGR sources: gray of the frame
 // computed on the fly (cvtColor then resize); gray sources go through LUT lut_idx[k] of `luts` first when lut_idx is given
@@ -388,6 +415,7 @@ struct PartImageBatch {
     std::vector<const void *> src; std::vector<int> lut_idx;
     uint8_t *dst = nullptr; size_t slot = 0;
 };
+int part_table(nvca_ctx *ctx, const void *host, size_t bytes, void **dev);   // a small table for the next launch on the current lane (upload ring)
 int part_arena(nvca_ctx *ctx, size_t bytes, uint8_t **base);                 // grows the arena (before anything of the call is queued)
 int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep);     // LUT storage: n_keep that live through the call + scratch
 int part_gray_eq(nvca_ctx *ctx, const void *const *bgr, int n, int w, int h, int stride, uint8_t *gray, size_t slot, uint8_t *luts);   // gray images + their equalisation LUTs

@@ -238,48 +238,28 @@ static double now_ms()
 // ("stays on host"); it is written from the documented geometry of OpenCV's thick primitives -- a 3-pixel
 // band centred on each edge with radius-1 round joins, a 4-pixel ring -- and is NOT pixel-verified against OpenCV,
 // which is not available offline.  Boxes, events and signals do not depend on it.
-struct Canvas { guint8 *data; int w, h, stride, bpp; };
-static inline void put_px(const Canvas &c, int x, int y, const guint8 *col)
+// view-* outlines: the library draws them (nvca_draw_shapes, host frames here), so a pipeline that keeps its frames in HBM
+// gets the same pixels from the device kernel
+struct Canvas { nvca_ctx *ctx; nvca_frame f; int bpp; };
+static void draw_shape(const Canvas &c, int kind, int x, int y, int w, int h, const guint8 *col)
 {
-    if ((unsigned)x >= (unsigned)c.w || (unsigned)y >= (unsigned)c.h) return;
-    guint8 *p = c.data + (size_t)y * c.stride + (size_t)x * c.bpp;
-    for (int k = 0; k < c.bpp; k++) p[k] = col[k];
-}
-static void fill_span(const Canvas &c, int x0, int x1, int y0, int y1, const guint8 *col)
-{
-    x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, c.w - 1); y1 = std::min(y1, c.h - 1);
-    for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) put_px(c, x, y, col);
+    if (!c.ctx) return;
+    nvca_shape sh; sh.kind = kind; sh.x = x; sh.y = y; sh.w = w; sh.h = h;
+    for (int k = 0; k < 4; k++) sh.bgra[k] = col[k];
+    nvca_draw_shapes(c.ctx, &c.f, c.bpp, &sh, 1);
 }
 // corners (x0, y0) and (x1, y1) inclusive, as cvRectangle takes them
-static void draw_rect3(const Canvas &c, int x0, int y0, int x1, int y1, const guint8 *col)
-{
-    if (x0 > x1) std::swap(x0, x1);
-    if (y0 > y1) std::swap(y0, y1);
-    fill_span(c, x0, x1, y0 - 1, y0 + 1, col); fill_span(c, x0, x1, y1 - 1, y1 + 1, col);
-    fill_span(c, x0 - 1, x0 + 1, y0, y1, col); fill_span(c, x1 - 1, x1 + 1, y0, y1, col);
-    const int cx[4] = {x0, x1, x1, x0}, cy[4] = {y0, y0, y1, y1};
-    for (int k = 0; k < 4; k++) {                           // radius-1 round join: the 4-neighbourhood of the vertex
-        put_px(c, cx[k] - 1, cy[k], col); put_px(c, cx[k] + 1, cy[k], col);
-        put_px(c, cx[k], cy[k] - 1, col); put_px(c, cx[k], cy[k] + 1, col);
-    }
-}
-static void draw_ring4(const Canvas &c, int cx, int cy, int radius, const guint8 *col)
-{
-    if (radius < 0) return;
-    const int ro = radius + 2, ri = std::max(radius - 2, 0);
-    for (int y = -ro; y <= ro; y++)
-        for (int x = -ro; x <= ro; x++) {
-            const int d2 = x * x + y * y;
-            if (d2 <= ro * ro && d2 >= ri * ri) put_px(c, cx + x, cy + y, col);
-        }
-}
+static void draw_rect3(const Canvas &c, int x0, int y0, int x1, int y1, const guint8 *col) { draw_shape(c, NVCA_SHAPE_RECT3, x0, y0, x1 - x0, y1 - y0, col); }
+static void draw_ring4(const Canvas &c, int cx, int cy, int radius, const guint8 *col) { draw_shape(c, NVCA_SHAPE_RING4, cx, cy, radius, 0, col); }
 #define BGR_OF_RGB(r, g, b) {b, g, r, 0}
-static Canvas canvas_of(GstVideoFrame *frame)
+static Canvas canvas_of(nvca_ctx *ctx, GstVideoFrame *frame)
 {
     Canvas c;
-    c.data = (guint8 *)GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
-    c.w = GST_VIDEO_FRAME_WIDTH(frame); c.h = GST_VIDEO_FRAME_HEIGHT(frame);
-    c.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0); c.bpp = GST_VIDEO_FRAME_COMP_PSTRIDE(frame, 0);
+    c.ctx = ctx;
+    c.f.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+    c.f.width = GST_VIDEO_FRAME_WIDTH(frame); c.f.height = GST_VIDEO_FRAME_HEIGHT(frame);
+    c.f.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0); c.f.mem = NVCA_MEM_HOST; c.f.pts = 0;
+    c.bpp = GST_VIDEO_FRAME_COMP_PSTRIDE(frame, 0);
     return c;
 }
 
@@ -439,7 +419,7 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
                 // Faces::draw: (x, y) .. (x + w - 1, y + h - 1) of the working-image box, times the integer scale, in
                 // colors[1] = CV_RGB(0,128,255)  (FACE/BaseFace.cpp:70-82, FACE/kmsfacedetect.cpp:144-151,832-850)
                 static const guint8 col[4] = BGR_OF_RGB(0, 128, 255);
-                const Canvas cv = canvas_of(frame);
+                const Canvas cv = canvas_of(f->slot->ctx, frame);
                 const int scale = nf.width / f->p.width_to_process;
                 for (int i = 0; i < n; i++)
                     draw_rect3(cv, boxes[i].x, boxes[i].y, boxes[i].x + boxes[i].w - scale, boxes[i].y + boxes[i].h - scale, col);
@@ -591,7 +571,7 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
             if (n > 4096) n = 4096;
             if (t->visual_mode > 0) {                        /* TRK/gstnubotracker.cpp:389: tl() .. br(), Scalar(0,0,255) */
                 static const guint8 col[4] = {0, 0, 255, 0};
-                const Canvas cv = canvas_of(frame);
+                const Canvas cv = canvas_of(t->slot->ctx, frame);
                 for (int i = 0; i < n; i++) draw_rect3(cv, bx[i].x, bx[i].y, bx[i].x + bx[i].w, bx[i].y + bx[i].h, col);
             }
             std::string s;
@@ -829,7 +809,7 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
                 for (int k = 0; k < na; k++) str += box_str(a[k]);
             }
             if (1 == f->view && !f->image_to_overlay) {
-                const Canvas cv = canvas_of(frame);
+                const Canvas cv = canvas_of(f->slot->ctx, frame);
                 if (kind == NVCA_PART_EYE) {                 // one circle per side, first box only (EYE :1069-1099)
                     static const guint8 col[4] = {255, 0, 0, 0};              /* Scalar(255, 0, 0) */
                     int radius = -1;

@@ -30,6 +30,13 @@ class Rect(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
 
 
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int), ("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int), ("bgra", C.c_uint8 * 4)]
+
+
+SHAPE_RECT3, SHAPE_RING4 = 0, 1
+
+
 class Frame(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int),
                 ("mem", C.c_int), ("pts", C.c_uint64)]
@@ -68,7 +75,7 @@ SYMBOLS = [
     "nvca_part_params_default", "nvca_part_stream_create", "nvca_part_stream_destroy", "nvca_part_stream_set_params",
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
-    "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count",
+    "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count", "nvca_draw_shapes",
 ]
 
 _lib = None
@@ -160,6 +167,7 @@ def load():
     L.nvca_tracker_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(C.c_double),
                                              C.POINTER(Rect), C.c_int, ip]
     L.nvca_flip_horizontal.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.nvca_draw_shapes.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Shape), C.c_int]
     L.nvca_part_params_default.argtypes = [C.POINTER(PartParams), C.c_int]
     L.nvca_part_params_default.restype = None
     L.nvca_part_stream_create.argtypes = [vp, C.POINTER(PartParams), vp, vp, vp, C.POINTER(vp)]
@@ -274,6 +282,16 @@ class Context:
         self.check(self.L.nvca_integral(self.h, img.ctypes.data, w, h, img.strides[0], MEM_HOST,
                                         s.ctypes.data_as(C.POINTER(C.c_int32)), q.ctypes.data_as(C.POINTER(C.c_double))))
         return s, q
+
+    def draw_shapes(self, frame, channels, shapes):
+        """nvca_draw_shapes: shapes = [(kind, x, y, w, h, (b, g, r, a))]; frame: a Frame (device memory) or a writable numpy image (drawn in place)"""
+        fr = frame if isinstance(frame, Frame) else make_frame(frame)
+        arr = (Shape * max(len(shapes), 1))()
+        for i, (kind, x, y, w, h, col) in enumerate(shapes):
+            arr[i].kind, arr[i].x, arr[i].y, arr[i].w, arr[i].h = kind, x, y, w, h
+            for k in range(4):
+                arr[i].bgra[k] = col[k]
+        self.check(self.L.nvca_draw_shapes(self.h, C.byref(fr), channels, arr, len(shapes)))
 
     def integral_tilted(self, img):
         img = np.ascontiguousarray(img, np.uint8)
