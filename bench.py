@@ -165,6 +165,81 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
         content[name] = {"frames_per_s": fps, "ms_per_step": ms}
     tab["content"] = content
     tab["content_note"] = "device-resident, %d frames per call (8 distinct frames cycled), same cascade and parameters as the headline" % F
+
+    # the other BASELINE configs on this GPU, a few ticks each (their own `--workload` runs give the full line)
+    def multi(Wm, Hm, S, with_tracker, ticks=3, reps=4):
+        bgs = [synth.make_gray(Wm, Hm, 9000 + s, "natural") for s in range(S)]
+        kx, ky = Wm / 1920.0, Hm / 1080.0
+        rows, rows4 = [], []
+        for t in range(ticks):
+            row = []
+            for s in range(S):
+                faces = [(int((200 + 8 * t + 16 * (s % 7)) * kx), int(150 * ky), int(300 * min(kx, ky))), (int((900 + 8 * t) * kx), int(400 * ky), int(180 * min(kx, ky)))]
+                row.append(torch.from_numpy(synth.gray_to_bgr(synth.paste_faces(bgs[s], faces, s), 9000 + s)).to(dev))
+            rows.append(row)
+            if with_tracker:
+                rows4.append([torch.cat([x, torch.full((Hm, Wm, 1), 255, dtype=torch.uint8, device=dev)], dim=2).contiguous() for x in row])
+        torch.cuda.synchronize()
+        sts = [capi.FaceStream(ctx, casc, width_to_process=Wm, multi_scale_factor=props["multi_scale_factor"]) for _ in range(S)]
+        trk = [capi.Tracker(ctx) for _ in range(S)] if with_tracker else None
+        prep = [ctx.prepare_face_batch(sts, [capi.make_frame(x.data_ptr(), Wm, Hm, Wm * 3, capi.MEM_DEVICE) for x in row], cap=MAX_BOXES) for row in rows]
+        fr4 = [[capi.make_frame(x.data_ptr(), Wm, Hm, Wm * 4, capi.MEM_DEVICE) for x in row] for row in rows4]
+
+        def tick(i):
+            prep[i % ticks].process()
+            if trk:
+                capi.tracker_batch_process(ctx, trk, fr4[i % ticks], [33.3 * i] * S, cap=256)
+        for i in range(ticks):
+            tick(i)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(ticks, ticks + reps * ticks):
+            tick(i)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        for st in sts:
+            st.close()
+        return S * reps * ticks / dt, dt / (reps * ticks) * 1e3
+    f720, ms720 = multi(1280, 720, 32, False)
+    ftrk, mstrk = multi(1920, 1080, 8, True)
+    # BASELINE configs[2]: the face -> eye / nose / mouth / ear chain on V concurrent 1080p streams, batched entry points
+    def roi_chain(V=8, ticks=3, reps=4):
+        pcs = {nm: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(nm)) for nm in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+        fcs = [capi.FaceStream(ctx, casc, width_to_process=1920, multi_scale_factor=props["multi_scale_factor"]) for _ in range(V)]
+        kinds = [(0, "righteye", "lefteye"), (1, "nose", None), (2, "mouth", None), (3, "leftear", "rightear")]
+        parts = [capi.PartStream(ctx, k, casc, pcs[a], pcs[b] if b else None) for _ in range(V) for k, a, b in kinds]
+        base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
+        keep = [[torch.from_numpy(synth.make_bgr(1920, 1080, 40 + 5 * t + v, "natural", [(x + 8 * (t + v), y, sz) for x, y, sz in base])).to(dev) for v in range(V)]
+                for t in range(ticks)]
+        torch.cuda.synchronize()
+        frs = [[capi.make_frame(x.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for x in row] for row in keep]
+        found = [0]
+
+        def tick(i):
+            fb = frs[i % ticks]
+            tk = ctx.face_batch_submit(fcs, fb)            # the face detector's batch runs under the part detectors' call
+            res = capi.part_batch_process(ctx, parts, [fb[v] for v in range(V) for _ in range(4)])
+            ctx.face_batch_collect(tk)
+            found[0] += sum(len(a) + len(b) for a, b in res)
+        for i in range(ticks):
+            tick(i)
+        ctx.synchronize()
+        found[0] = 0
+        t0 = time.perf_counter()
+        for i in range(ticks, ticks + reps * ticks):
+            tick(i)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        for st in fcs:
+            st.close()
+        for pt in parts:
+            pt.close()
+        return V * reps * ticks / dt, dt / (reps * ticks) * 1e3, found[0] / (V * reps * ticks)
+    froi, msroi, nparts = roi_chain() if (W, H) == (1920, 1080) else (None, None, None)
+    tab["workloads"] = {"roi_chain": {"frames_per_s": froi, "ms_per_tick": msroi, "streams": 8, "parts_per_frame": nparts,
+                                      "note": "BASELINE configs[2]: 8 x 1080p streams x (face detector + eye + nose + mouth + ear, own face pass each), nvca_face_batch_submit/collect around nvca_part_batch_process; scripts/bench_roi_chain.py gives the breakdown"},
+                        "streams720p": {"frames_per_s": f720, "ms_per_tick": ms720, "streams": 32, "note": "BASELINE configs[3] per GPU: 32 independent 1280x720 streams, one frame each per call"},
+                        "face_tracker": {"frames_per_s": ftrk, "ms_per_tick": mstrk, "streams": 8, "note": "BASELINE configs[4] per GPU: 8 x 1080p streams through NuboFaceDetector + NuboTracker per tick"}}
     return tab
 
 
