@@ -113,13 +113,13 @@ struct ResultBufs {
 // holds several of those tiny kernels at a time instead of one.  What a job leaves for the host lives in ResultBufs regions
 // of its own, shared by all lanes.
 struct Lane {
-    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, tilted, staging, aux, failbits, vnf, deep, list_cnt, list_ent, list_off;
+    DevBuf gray, hist, lut, bandsum, bandsq, sum, sqsum, tilted, staging, aux, failbits, vnf, deep;
     int hist_clean = 0;               // leading histogram slots known to be all zero
     void release_all()
     {
         gray.release(); hist.release(); lut.release(); bandsum.release(); bandsq.release(); sum.release();
         sqsum.release(); tilted.release(); staging.release(); aux.release();
-        failbits.release(); vnf.release(); deep.release(); list_cnt.release(); list_ent.release(); list_off.release();
+        failbits.release(); vnf.release(); deep.release();
     }
 };
 struct Workspace {
@@ -184,7 +184,7 @@ struct GeomPlan {
 DetectPlan::~DetectPlan()
 {
     release_tables();
-    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_list_off.release(); d_blob.release();
+    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -417,8 +417,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame;
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
-        a.list_from = 0;
-        a.nscales = (int)dp.scales.size(); a.list_cnt = nullptr; a.list_ent = nullptr; a.list_off = nullptr; a.list_cap = 0;
+        a.nscales = (int)dp.scales.size();
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
@@ -449,27 +448,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             return e;
         };
         if (!use_band) { TimedLaunch t(ctx, NVCA_K_STAGE0); if (launch(0)) return NVCA_ERR_HIP; }
-        const int early_last = std::min<int>(dp.deep_stage, (int)dp.stages.size());
-        const bool lists = !use_band && dp.use_lists && batch <= 64 && dp.list_windows > 0 && dp.list_from < early_last;
-        if (lists) {
-            // per-scale segment offsets depend on the batch (segment = windows of the scale x batch)
-            const size_t cap_l = (size_t)dp.list_windows * batch;
-            if (dp.list_off_batch != batch) {
-                std::vector<unsigned> off(dp.scales.size());
-                for (size_t i = 0; i < off.size(); i++) off[i] = dp.list_off[i] * (unsigned)batch;
-                if (dp.d_list_off.ensure(sizeof(unsigned) * 64)) { ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM; }
-                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
-                NVCA_HIP_CHECK(ctx, hipMemcpy(dp.d_list_off.p, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-                dp.list_off_batch = batch;
-            }
-            if (ws.ln().list_cnt.ensure(sizeof(unsigned) * 64 * (dp.stages.size() + 1)) || ws.ln().list_ent.ensure(sizeof(unsigned) * 2 * cap_l + 64)) {
-                ctx->set_error("device allocation failed (survivor lists)"); return NVCA_ERR_NOMEM;
-            }
-            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().list_cnt.p, 0, sizeof(unsigned) * 64 * (dp.stages.size() + 1), ctx->cs()));
-            a.list_cnt = ws.ln().list_cnt.as<unsigned>(); a.list_ent = ws.ln().list_ent.as<unsigned>(); a.list_off = dp.d_list_off.as<unsigned>();
-            a.list_cap = (unsigned)cap_l; a.list_from = dp.list_from;
-            TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(4)) return NVCA_ERR_HIP;
-        } else if (use_band) {
+        if (use_band) {
             TimedLaunch t(ctx, NVCA_K_BAND); if (launch(5)) return NVCA_ERR_HIP;
         } else {
             { TimedLaunch t(ctx, NVCA_K_TILE); if (launch(3)) return NVCA_ERR_HIP; }

@@ -16,7 +16,7 @@
 //                    is appended to the deep list.
 //  K5a k_stage0 +    (smaller batches) the same as a pre-pass over all windows with global reads
 //  K5b k_tile        (reject bits + variance normaliser per window) followed by one workgroup per
-//                    tile.  k_strip / k_list_*: older variants with global gathers (NVCA_TILES=0).
+//                    tile.  k_strip: the older variant with global gathers (NVCA_TILES=0; the fallback when a plan has no tiles).
 //  K5c k_deep        one workgroup per surviving window, one stump per thread (the long stages have
 //                    33..213 stumps); after the first late stage the window's samples are staged in LDS.
 //  K6  k_group       cv::groupRectangles per frame.
@@ -336,8 +336,6 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
 
     int cur = 0;
     int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    const bool to_list = a.list_from > 0 && a.list_from < last;      // later early stages run on the global lists
-    if (to_list) last = a.list_from;
     for (int s = 1; s < last; s++) {
         __syncthreads();
         const int n = qn[cur];
@@ -412,19 +410,6 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     __syncthreads();
     const int nh = qn[cur];
     if (nh == 0) return;
-    if (to_list) {               // one atomic per strip: survivors join the scale's global list for stage `last`
-        unsigned *cnt = a.list_cnt + (size_t)(last - 1) * 64 + strip.scale;
-        unsigned *ent = a.list_ent + (size_t)((last - 1) & 1) * a.list_cap + a.list_off[strip.scale];
-        if (tid == 0) gbase_s = atomicAdd(cnt, (unsigned)nh);
-        __syncthreads();
-        const unsigned gb = gbase_s;
-        for (int i = tid; i < nh; i += 256) {
-            const int w = q[cur][i];
-            const int r = w / endX, ix = ix0 + (w - r * endX);
-            ent[gb + i] = ((unsigned)slot << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
-        }
-        return;
-    }
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
@@ -436,94 +421,6 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
         const int r = w / endX, ix = ix0 + (w - r * endX);
         const unsigned key = ((unsigned)strip.scale << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
         if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
-    }
-}
-
-// ---- K5b'': early stages on GLOBAL per-scale survivor lists -----------------------------
-// The strip kernel's waves run mostly empty once a 512-window strip has been thinned out, and the gather
-// units pay per wave instruction, not per lane.  Here the survivors of all strips of a scale go to one
-// list per scale (entries slot << 26 | iy << 13 | ix), and each stage is a launch over the lists with
-// full waves; a wave only ever holds windows of one scale, so stump records stay scalar loads.
-//   k_list_seed:  visited stage-0 survivors -> lists[0]
-//   k_list_stage: lists[s-1] -> stage s -> lists[s]   (last early stage -> deep list / hits)
-__global__ __launch_bounds__(256) void k_list_seed(CascadeArgs a)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int slot, bidx;
-    if (!xcd_chunk_index((a.ntasks + 3) / 4, slot, bidx)) return;
-    const int t = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);
-    if (t >= a.ntasks) return;
-    const unsigned task = a.tasks[t];
-    const int s = task >> 20, iy = (task >> 7) & 8191, k = task & 127;
-    const ScaleRec &sc = a.scales[s];
-    const int ix = k * 64 + lane;
-    const unsigned long long *rb = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr;
-    bool keep = false;
-    if (ix < sc.endX && !((rb[k] >> lane) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
-    const unsigned long long km = __ballot(keep);
-    if (!km) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&a.list_cnt[s], (unsigned)__popcll(km));
-    base = __shfl(base, 0);
-    if (keep) a.list_ent[(size_t)a.list_off[s] + base + __popcll(km & ((1ull << lane) - 1ull))] =
-                  ((unsigned)slot << 26) | ((unsigned)iy << 13) | (unsigned)ix;
-}
-
-__global__ __launch_bounds__(256) void k_list_stage(CascadeArgs a, int stage)
-{
-    __shared__ unsigned pref[65];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned *cnt_in = a.list_cnt + (size_t)(stage - 1) * 64;
-    unsigned *cnt_out = a.list_cnt + (size_t)stage * 64;
-    const unsigned *ent_in = a.list_ent + (size_t)((stage - 1) & 1) * a.list_cap;
-    unsigned *ent_out = a.list_ent + (size_t)(stage & 1) * a.list_cap;
-    if (tid < 64) {            // exclusive prefix of 64-window chunks per scale
-        unsigned c = tid < a.nscales ? (cnt_in[tid] + 63) / 64 : 0, incl = c;
-        for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-        pref[tid + 1] = incl;
-        if (tid == 0) pref[0] = 0;
-    }
-    __syncthreads();
-    const unsigned total = pref[a.nscales];
-    const StageRec st = a.stages[stage];
-    const bool last = stage + 1 >= a.deep_stage || stage + 1 >= a.nstages;
-    // blocks sharing an XCD (b % 8) walk one contiguous eighth of the chunk sequence (speed only)
-    const unsigned per_x = (total + 7) / 8, xcd = blockIdx.x & 7, nbx = gridDim.x / 8, bx = blockIdx.x >> 3;
-    for (unsigned c = bx * 4 + wave; c < per_x; c += nbx * 4) {
-        const unsigned chunk = xcd * per_x + c;
-        if (chunk >= total) break;
-        int s = 0;
-        while (pref[s + 1] <= chunk) s++;                    // wave-uniform, <= 25 steps
-        s = __builtin_amdgcn_readfirstlane(s);
-        const ScaleRec &sc = a.scales[s];
-        const unsigned idx = (chunk - pref[s]) * 64 + lane;
-        bool pass = false;
-        unsigned key = 0;
-        if (idx < cnt_in[s]) {
-            key = ent_in[(size_t)a.list_off[s] + idx];
-            const int slot = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
-            const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
-            const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
-            const double vnf = a.vnf[((size_t)slot * a.ntasks + sc.task_off + (size_t)iy * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-            pass = run_stage(sum, off, sc.pitch, vnf, (CTStumpRec *)sc.trecs, st, a.pair_policy);
-        }
-        const unsigned long long pm = __ballot(pass);
-        if (!pm) continue;
-        const unsigned n = (unsigned)__popcll(pm), rank = (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
-        if (!last) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&cnt_out[s], n);
-            base = __shfl(base, 0);
-            if (pass) ent_out[(size_t)a.list_off[s] + base + rank] = key;
-        } else {
-            unsigned long long *list = stage + 1 >= a.nstages ? a.hits : a.deep;
-            const unsigned cap = stage + 1 >= a.nstages ? a.hit_cap : a.deep_cap;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(list, (unsigned long long)n);
-            base = __shfl(base, 0);
-            if (pass && base + rank < cap)
-                list[1 + base + rank] = ((unsigned long long)(key >> 26) << 32) | ((unsigned)s << 26) | (key & 0x3ffffffu);
-        }
     }
 }
 
@@ -1279,17 +1176,6 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
     if (which == 0) {
         const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
         NVCA_LAUNCH(k_stage0, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
-    } else if (which == 4) {         // strips for the crowded first stages, global lists (full waves) for the thinned-out ones
-        const int s0_blocks = (((a.ntasks + 3) / 4 + 7) / 8) * 8;
-        const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-        int from = a.list_from;
-        if (from <= 1) {             // everything on lists
-            NVCA_LAUNCH(k_list_seed, dim3((unsigned)s0_blocks * (unsigned)batch), dim3(256), 0, st, a);
-            from = 1;
-        } else if (a.blocks_per_frame > 0)
-            NVCA_LAUNCH(k_strip, dim3((unsigned)a.blocks_per_frame * (unsigned)batch), dim3(256), 0, st, a);
-        for (int sidx = from; sidx < last; sidx++)
-            NVCA_LAUNCH(k_list_stage, dim3(2048), dim3(256), 0, st, a, sidx);
     } else if (which == 3) {
         if (a.tile_blocks_per_frame > 0) {
             if (int e = grant_lds(reinterpret_cast<const void *>(k_tile), 0, a.tile_lds, &lds_grant[0])) return e;

@@ -350,12 +350,7 @@ struct CascadeArgs {
     const unsigned short *tcoords; int tile_lds;
     const BandRec *bands; const int *band_order; int band_blocks_per_frame; int batch; int band_map;  // k_band
     const DeepRec *deeprecs;                  // [nscales] or null (k_deep: LDS patches)
-    // global survivor lists (k_list_*): per-scale segments; counts per stage
-    unsigned *list_cnt;            // [nstages][64]
-    unsigned *list_ent;            // [2][list_cap]
-    const unsigned *list_off;      // [nscales] segment offsets
-    unsigned list_cap; int nscales;
-    int list_from;                 // first stage run on the lists (0: lists unused; 1: all early stages)
+    int nscales;
     const unsigned *tasks; int ntasks;        // k_stage0 wave tasks: scale << 20 | iy << 7 | word
     unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
@@ -374,7 +369,7 @@ struct CascadeArgs {
     unsigned long long *dbg;       // diagnostic build only: per-phase s_memtime stamps of the first workgroups (scripts/stamps.py)
 #endif
 };
-// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 4 = k_list_seed + k_list_stage per early stage, 5 = k_band
+// which: 0 = k_stage0, 1 = k_strip, 2 = k_deep, 3 = k_tile, 5 = k_band
 // lds_grant: the calling context's record of the dynamic LDS already granted to k_tile ([0]) / k_band ([1]); returns a
 // hipError_t (as int) when the grant is refused, 0 otherwise
 int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which, int *lds_grant);

@@ -425,13 +425,6 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
         band_blocks_per_frame = (int)bands.size();
     }
     // per-scale segments of the global survivor lists (sized per frame; api.cpp scales them by the batch)
-    list_off.clear(); list_windows = 0;
-    for (const ScaleRec &sr : scales) { list_off.push_back(list_windows); list_windows += (unsigned)std::max(sr.endX, 0) * (unsigned)std::max(sr.endY, 0); }
-    // global survivor lists (k_list_*) are an option as well: full waves, but lanes of a wave then come from different
-    // strips and every gather touches more cache lines -- measured slower than the strips
-    use_lists = false;
-    if (const char *e = getenv("NVCA_LISTS")) use_lists = atoi(e) != 0 && !use_tiles;
-    if (const char *e = getenv("NVCA_LIST_FROM")) list_from = std::max(1, atoi(e));
     device_group_ok = true;
     for (size_t q = 0; q < specs.size(); q++)
         if (specs[q].out_factor != 0 || specs[q].out_w != scales[q].winw || specs[q].out_h != scales[q].winh) device_group_ok = false;

@@ -66,15 +66,10 @@ struct DetectPlan {
     std::vector<DeepRec> deeprecs;  // per scale (k_deep LDS patches); empty: not used
     std::vector<BandRec> bands;  // rows of tiles (k_band); usable when every scale is tiled
     std::vector<int> band_order; int band_blocks_per_frame = 0;
-    std::vector<unsigned> list_off;   // per-scale offsets (windows per frame) into the survivor lists
-    unsigned list_windows = 0;        // windows per frame
-    bool use_lists = true;
-    int list_from = 3;                // strips run stages 1..list_from-1, the lists the rest of the early stages
-    int list_off_batch = 0;           // batch size d_list_off was built for
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_list_off, d_blob;   // the table buffers are views into d_blob
+    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_blob;   // the table buffers are views into d_blob
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);

@@ -612,13 +612,12 @@ def test_detect_roi_view(ctx, casc, orc_cascade):
 
 
 # ------------------------------------------------------------------ optional evaluator paths stay correct
-@pytest.mark.parametrize("env", [{"NVCA_TILES": "0"}, {"NVCA_TILES": "0", "NVCA_LISTS": "1", "NVCA_LIST_FROM": "1"},
-                                 {"NVCA_TILES": "0", "NVCA_LISTS": "1", "NVCA_LIST_FROM": "3"}, {"NVCA_DEEP_STAGE": "1"},
+@pytest.mark.parametrize("env", [{"NVCA_TILES": "0"}, {"NVCA_DEEP_STAGE": "1"},
                                  {"NVCA_DEEP_STAGE": "2"}, {"NVCA_DEEP_STAGE": "30"}, {"NVCA_TILES": "0", "NVCA_DEEP_STAGE": "30"},
                                  {"NVCA_BAND": "1"}, {"NVCA_BAND": "1", "NVCA_DEEP_STAGE": "30"}, {"NVCA_BAND": "1", "NVCA_DEEP_STAGE": "2"},
                                  {"NVCA_DEEP_LDS_OFF": "1"}, {"NVCA_DEEP_STAGE": "20"}])
 def test_optional_evaluator_paths(ctx, casc, orc_cascade, env, monkeypatch):
-    """k_strip (row strips, global gathers), k_list_* (global survivor lists) and other deep-stage splits are kept as
+    """k_strip (row strips, global gathers: the fallback of plans without tiles) and other deep-stage splits are kept as
     measured alternatives; plans read the switches when they are built, so new geometries pick them up"""
     import orc
     from nubovca import synth
