@@ -345,7 +345,12 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                 }
                 ok = worst_c <= kTileMaxCols && worst_r <= kTileThreads && worst_r * tile_pitch(worst_c) < 65536 &&
                      tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy) <= kTileLdsBudget;
-                if (ok) break;
+                if (ok) {
+                    if (getenv("NVCA_PLAN_DEBUG"))
+                        fprintf(stderr, "[nvca plan] scale %zu factor %.3f windows %d x %d: tile side %d, %d x %d samples, %d B of LDS (budget %d)\n", s, sp.table_factor > 0 ? sp.table_factor : sp.out_factor,
+                                sr.endX, sr.endY, tw, worst_c, worst_r, tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy), kTileLdsBudget);
+                    break;
+                }
             }
             if (tw >= 1) {
                 for (int iy0 = 0; iy0 < sr.endY; iy0 += tw) {

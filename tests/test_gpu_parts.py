@@ -197,6 +197,31 @@ def test_part_batch_streams_on_one_frame_share_their_work(env):
         assert tot > 0
 
 
+def test_part_batch_more_images_than_one_job_carries(env):
+    """40 nose + 20 ear + 6 eye streams on distinct frames of one size in ONE call: the face passes are split over several
+    N-image jobs (32 images per job, 16 image + mirror pairs for the ear detector), the working images come from single
+    launch sets of 40+ frames; two ticks so that the ring of launch tables and the arena are reused"""
+    from nubovca import capi
+    ctx, dev, cpu = env
+    kinds = ["nose"] * 40 + ["ear"] * 20 + ["eye"] * 6
+    pairs = [_streams(env, k) for k in kinds]
+    W, H = 320, 240
+    tot = 0
+    for t in range(2):
+        frames = []
+        for i in range(len(kinds)):
+            from nubovca import synth
+            faces = [] if i % 7 == 3 else [(40 + (5 * i + 3 * t) % 60, 30 + (3 * i) % 25, 130 + (i % 4) * 10)]
+            frames.append(synth.make_bgr(W, H, 8800 + 11 * i + t, "natural", faces))
+        res = capi.part_batch_process(ctx, [g for g, _ in pairs], frames)
+        for i, (ga, gb) in enumerate(res):
+            ea, eb = pairs[i][1].process(frames[i])
+            assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (t, i, kinds[i], ga, ea, gb, eb)
+            tot += len(ea) + len(eb)
+    assert tot > 0
+    assert capi.part_batch_process(ctx, [], []) == []
+
+
 def test_flip_primitive(env):
     import ctypes as C
     import orc
