@@ -274,6 +274,12 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         const nvca_part_stream *s = streams[i]; const nvca_frame *f = &frames[i];
         if (!s || s->ctx != ctx || !f->data || f->width <= 0 || f->height <= 0 || f->stride < f->width * 3 || s->p.width_to_process <= 0) return NVCA_ERR_ARG;
         for (int j = 0; j < i; j++) if (streams[j] == s) { ctx->set_error("a part stream may appear once per batch"); return NVCA_ERR_ARG; }
+        // every frame is validated before any stream's gate advances: a refused call leaves all streams as they were
+        const float o2f = (s->p.kind != NVCA_PART_EAR && s->p.detect_event) ? 1.f : ((float)f->width) / ((float)160);
+        const float x2o = ((float)f->width) / ((float)s->p.width_to_process);
+        if (cv_round(f->width / (double)o2f) <= 0 || cv_round(f->height / (double)o2f) <= 0 || cv_round(f->width / (double)x2o) <= 0 || cv_round(f->height / (double)x2o) <= 0) {
+            ctx->set_error("part stream: frame too small"); return NVCA_ERR_ARG;
+        }
     }
     (void)hipSetDevice(ctx->device);
     // the image primitives below hand device buffers to each other on the context's stream: no drain in between

@@ -87,6 +87,8 @@ template <class Req> struct Combiner {
 static const int kFaceCap = 256, kTrkCap = 4096;
 struct FaceReq { nvca_face_stream *stream; nvca_frame frame; nvca_rect *out; int n, rc; bool done; };
 struct TrkReq { nvca_tracker *trk; nvca_frame frame; double ts; nvca_rect *out; int n, rc; bool done; };
+static const int kPartCap = 64;
+struct PartReq { nvca_part_stream *stream; nvca_frame frame; nvca_rect *a, *b; int na, nb, rc; bool done; };
 struct GpuSlot {
     int index = 0, device = 0;
     nvca_ctx *ctx = nullptr;
@@ -95,6 +97,7 @@ struct GpuSlot {
     std::map<std::string, SharedCascade> cascades;
     Combiner<FaceReq> face_q;
     Combiner<TrkReq> trk_q;
+    Combiner<PartReq> part_q;                   // eye / nose / mouth / ear elements of all streams of the slot
     std::atomic<int> registered{0};             // pool memories page-locked so far (NVCA_GST_STATS)
 };
 
@@ -197,6 +200,29 @@ static void face_run_round(nvca_ctx *ctx, std::vector<FaceReq *> &round)
     if (!batched)
         for (FaceReq *r : round) r->rc = nvca_face_stream_process(r->stream, &r->frame, r->out, NULL, kFaceCap, &r->n);
 }
+static void part_run_round(nvca_ctx *ctx, std::vector<PartReq *> &round)
+{
+    const int n = (int)round.size();
+    bool batched = false;
+    if (n > 1) {
+        std::vector<nvca_part_stream *> streams(n);
+        std::vector<nvca_frame> frames(n);
+        std::vector<nvca_rect> a((size_t)n * kPartCap), b((size_t)n * kPartCap);
+        std::vector<int> na(n, 0), nb(n, 0);
+        for (int i = 0; i < n; i++) { streams[i] = round[i]->stream; frames[i] = round[i]->frame; }
+        const int rc = nvca_part_batch_process(ctx, n, streams.data(), frames.data(), a.data(), kPartCap, na.data(), b.data(), kPartCap, nb.data());
+        batched = rc != NVCA_ERR_ARG;                       // refused before any stream was touched: each frame on its own
+        for (int i = 0; batched && i < n; i++) {
+            PartReq *r = round[i];
+            r->rc = rc; r->na = rc == NVCA_OK ? na[i] : 0; r->nb = rc == NVCA_OK ? nb[i] : 0;
+            memcpy(r->a, a.data() + (size_t)i * kPartCap, sizeof(nvca_rect) * (size_t)std::min(r->na, kPartCap));
+            memcpy(r->b, b.data() + (size_t)i * kPartCap, sizeof(nvca_rect) * (size_t)std::min(r->nb, kPartCap));
+        }
+    }
+    if (!batched)
+        for (PartReq *r : round) r->rc = nvca_part_stream_process(r->stream, &r->frame, r->a, kPartCap, &r->na, r->b, kPartCap, &r->nb);
+}
+
 static void trk_run_round(nvca_ctx *ctx, std::vector<TrkReq *> &round)
 {
     const int n = (int)round.size();
@@ -782,7 +808,11 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
         nf.stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
         nf.mem = NVCA_MEM_HOST; nf.pts = GST_BUFFER_PTS(frame->buffer);
         nvca_rect a[64], b[64], faces[64]; int na = 0, nb = 0, nfaces = 0;
-        const int rc = nvca_part_stream_process(f->stream, &nf, a, 64, &na, b, 64, &nb);
+        // part detectors of other streams (and other kinds) that arrive meanwhile share the call: nvca_part_batch_process
+        PartReq req{f->stream, nf, a, b, 0, 0, NVCA_OK, false};
+        nvca_ctx *ctx = f->slot->ctx;
+        const int rc = f->slot->part_q.process(&req, [ctx](std::vector<PartReq *> &round) { part_run_round(ctx, round); });
+        na = req.na; nb = req.nb;
         if (rc != NVCA_OK) GST_ERROR("nvca_part_stream_process: %d", rc);
         else {
             na = MIN(na, 64); nb = MIN(nb, 64);
@@ -855,6 +885,10 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
 static void nvca_part_finalize(GObject *o)
 {
     NvcaPart *f = (NvcaPart *)o;
+    if (getenv("NVCA_GST_STATS") && f->slot) {
+        std::lock_guard<std::mutex> lk(f->slot->part_q.m);
+        fprintf(stderr, "nubovca: largest combined part-detector batch %d (slot %d)\n", f->slot->part_q.max_batch, f->slot->index);
+    }
     if (f->stream) nvca_part_stream_destroy(f->stream);
     if (f->cf) release_cascade(f->slot, f->cf);
     if (f->ca) release_cascade(f->slot, f->ca);

@@ -404,6 +404,37 @@ def test_part_pipeline_matches_oracle(shim, synth_xml, orc_cascade, factory, kin
     assert seen > 0
 
 
+@pytest.mark.gpu
+def test_part_branches_are_combined_and_keep_per_stream_results(shim, synth_xml, orc_cascade):
+    """four `nubomouthdetector` branches in one process: frames that arrive together ride in one nvca_part_batch_process
+    call, every branch still emits what the oracle predicts for its own sequence"""
+    import re
+    import orc
+    from nubovca import synth
+    files = _part_files()
+    NB, NF = 4, 8
+    branches = [[synth.make_bgr(640, 480, 5200 + 40 * b + i, "natural", [] if (i + b) % 5 == 3 else [(100 + 20 * b + 5 * i, 90 + 5 * b, 230 - 10 * b)])
+                 for i in range(NF)] for b in range(NB)]
+    r = _run_harness("nubomouthdetector", "BGR", 640, 480, branches, cascade_xml=synth_xml, extra_cascades=files, extra_env={"NVCA_GST_STATS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    seen = 0
+    for b, seq in enumerate(branches):
+        tag = "event " if b == 0 else "event#%d " % b
+        events = [l for l in lines if l.startswith(tag)]
+        assert len(events) == NF, (b, len(events))
+        o = orc.PartStream(2, orc_cascade, orc.parse_cascade_xml(files["haarcascade_mcs_mouth.xml"]))
+        for fr, line in zip(seq, events):
+            a, _ = o.process(fr)
+            got = [t for t in (line.split(" ", 2)[2] if len(line.split(" ", 2)) > 2 else "").split(";") if t.startswith("mouth/mouth")]
+            assert got == ["mouth/mouth:%d,%d,%d,%d" % tuple(x) for x in a], (b, line)
+            seen += len(a)
+    assert seen > 0
+    m = re.findall(r"largest combined part-detector batch (\d+)", r.stderr)
+    assert m, r.stderr[-800:]
+    print("largest combined part-detector batch", max(int(x) for x in m))
+
+
 def test_kurento_double_parses_signal_payload():
     from nubovca import kurento_double as kd
     msg = "x:10,y:20,width:30,height:40;x:1,y:2,width:3,height:4;"
