@@ -420,7 +420,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.nscales = (int)dp.scales.size();
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
-        a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>();
+        a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>(); a.deep_lds = dp.deep_lds;
         a.tilted = dp.needs_tilted ? ws.ln().tilted.as<int>() : nullptr;
         a.galpha = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_galpha; a.gcls_first = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_gcls_first;
         a.stump_based = dp.generic_stumps ? 1 : 0;

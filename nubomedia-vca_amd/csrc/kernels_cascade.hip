@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
     // staged in LDS (DeepRec), and the remaining ~1900 stumps x 8-12 corners become LDS reads.
     __shared__ double part[2][4];
     __shared__ double votes[256];
-    __shared__ int T[kDeepMaxSide * (kDeepMaxSide + 1)];
+    extern __shared__ int T[];              // the patch: sized by the plan's largest (a.deep_lds) -- the kernel lives on the windows in flight per CU
     __shared__ unsigned short cmap[kDeepMaxSpan], rmap[kDeepMaxSpan];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long cnt = a.deep[0];
@@ -1195,7 +1195,7 @@ int launch_cascade_sc(hipStream_t st, const CascadeArgs &a, int batch, int which
         long long wg = (long long)a.ntasks * batch / 2;
         if (wg < 128) wg = 128;
         if (wg > 8192) wg = 8192;
-        NVCA_LAUNCH(k_deep, dim3((unsigned)wg), dim3(256), 0, st, a);
+        NVCA_LAUNCH(k_deep, dim3((unsigned)wg), dim3(256), (size_t)(a.deeprecs ? a.deep_lds : 0), st, a);
     }
     return 0;
 }

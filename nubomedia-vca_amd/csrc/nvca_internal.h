@@ -356,6 +356,7 @@ struct CascadeArgs {
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
     int deep_stage;                // first stage evaluated by k_deep
+    int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key
     unsigned deep_cap;
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key

@@ -403,7 +403,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
     if (!strips.empty()) bands.clear();          // the band kernel has no strip counterpart: all scales tiled, or none
     // late stages: per scale the distinct corner columns / rows of their stumps (k_deep's LDS patch of one window)
-    deeprecs.clear();
+    deeprecs.clear(); deep_lds = 0;
     if (strips.empty() && !tiles.empty() && deep_stage < (int)stages.size() && getenv("NVCA_DEEP_LDS_OFF") == nullptr) {
         deeprecs.resize(scales.size());
         std::vector<char> tiled(scales.size(), 0);
@@ -418,6 +418,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                     d.col_off = (int)tcoords.size(); for (int v : ox) tcoords.push_back((unsigned short)v);
                     d.row_off = (int)tcoords.size(); for (int v : oy) tcoords.push_back((unsigned short)v);
                     d.ncol = (int)ox.size(); d.nrow = (int)oy.size(); d.span_x = ox.back() + 1; d.span_y = oy.back() + 1;
+                    deep_lds = std::max(deep_lds, d.nrow * (d.ncol | 1) * 4);
                 }
             }
             deeprecs[s] = d;

@@ -64,6 +64,7 @@ struct DetectPlan {
     std::vector<unsigned short> tcoords;
     int tile_lds = 0;            // dynamic LDS bytes of the largest tile
     std::vector<DeepRec> deeprecs;  // per scale (k_deep LDS patches); empty: not used
+    int deep_lds = 0;               // bytes of the largest patch
     std::vector<BandRec> bands;  // rows of tiles (k_band); usable when every scale is tiled
     std::vector<int> band_order; int band_blocks_per_frame = 0;
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
