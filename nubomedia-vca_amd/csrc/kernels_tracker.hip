@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, C
     if (r == i) { CompAcc c; c.minx = c.miny = 0x7fffffff; c.maxx = c.maxy = -1; c.seed = 0x7fffffff; c.pad = 0; ac[i] = c; }
 }
 
+// bounding box / first seed of a root: min / max atomics, attempted only when the value read (at device scope, past the
+// per-CU cache) would still be improved -- minima only fall and maxima only rise, so a stale read costs an atomic, never a
+// result.  A moving scene is one component as large as the frame: without the test every run of every row queues up on the
+// same five words (12 ms per 720p frame instead of 0.1).
+__device__ __forceinline__ void acc_min(int *p, int v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v); }
+__device__ __forceinline__ void acc_max(int *p, int v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v); }
+
 __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
                                                     CompAcc *__restrict__ acc, int w, int h)
 {
@@ -154,18 +161,33 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     const int n = w * h;
     const int *lab = labels + (size_t)blockIdx.z * n;
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
     const int i = y * w + x;
-    int r = lab[i];
-    if (r < 0) return;
-    const bool same_l = x > 0 && lab[i - 1] == r;     // labels are final roots after k_ccl_flatten
-    const bool same_r = x + 1 < w && lab[i + 1] == r;
-    if (!same_l) { atomicMin(&ac[r].minx, x); atomicMin(&ac[r].miny, y); atomicMax(&ac[r].maxy, y); }
-    if (!same_r) atomicMax(&ac[r].maxx, x);
-    if (__float_as_int(s.mhi[i]) == __float_as_int(s.ts)) {
-        const bool seed_l = same_l && __float_as_int(s.mhi[i - 1]) == __float_as_int(s.ts);
-        if (!seed_l) atomicMin(&ac[r].seed, i);
+    const int r = x < w ? lab[i] : -1;                // labels are final roots after k_ccl_flatten
+    bool start_l = false, end_r = false, seed0 = false;
+    if (r >= 0) {
+        const bool same_l = x > 0 && lab[i - 1] == r;
+        start_l = !same_l;                            // a horizontal run of the component starts / ends here
+        end_r = !(x + 1 < w && lab[i + 1] == r);
+        if (__float_as_int(s.mhi[i]) == __float_as_int(s.ts))
+            seed0 = !(same_l && __float_as_int(s.mhi[i - 1]) == __float_as_int(s.ts));
+    }
+    // A wave holds 64 consecutive pixels of one row: what its lanes have to report for one root is the leftmost run start,
+    // the rightmost run end, the row, and the leftmost seed -- bit scans of ballots, one lane per root does the atomics.
+    const unsigned long long m_l = __ballot(start_l), m_r = __ballot(end_r), m_s = __ballot(seed0);
+    unsigned long long todo = m_l | m_r | m_s;
+    while (todo) {                                    // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r0 = __shfl(r, leader);
+        const unsigned long long g = __ballot(r == r0);
+        if (lane == leader) {
+            const unsigned long long gl = g & m_l, gr = g & m_r, gs = g & m_s;
+            const int xb = x - lane;
+            if (gl) { acc_min(&ac[r0].minx, xb + __ffsll((long long)gl) - 1); acc_min(&ac[r0].miny, y); acc_max(&ac[r0].maxy, y); }
+            if (gr) acc_max(&ac[r0].maxx, xb + 63 - __clzll((long long)gr));
+            if (gs) acc_min(&ac[r0].seed, i - lane + __ffsll((long long)gs) - 1);
+        }
+        todo &= ~g;
     }
 }
 
