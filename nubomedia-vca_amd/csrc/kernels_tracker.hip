@@ -161,7 +161,11 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     const int n = w * h;
     const int *lab = labels + (size_t)blockIdx.z * n;
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    // rows and row segments are visited from the outside in (0, last, 1, last - 1, ...): the extreme rows / columns of a
+    // component arrive first, and everything that follows fails the "would it still improve" test instead of queueing up
+    const int by = (blockIdx.y & 1) ? h - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1);
+    const int bx = (blockIdx.x & 1) ? (int)gridDim.x - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1);
+    const int x = bx * 256 + threadIdx.x, y = by, lane = threadIdx.x & 63;
     const int i = y * w + x;
     const int r = x < w ? lab[i] : -1;                // labels are final roots after k_ccl_flatten
     bool start_l = false, end_r = false, seed0 = false;
@@ -172,11 +176,13 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
         if (__float_as_int(s.mhi[i]) == __float_as_int(s.ts))
             seed0 = !(same_l && __float_as_int(s.mhi[i - 1]) == __float_as_int(s.ts));
     }
-    // A wave holds 64 consecutive pixels of one row: what its lanes have to report for one root is the leftmost run start,
-    // the rightmost run end, the row, and the leftmost seed -- bit scans of ballots, one lane per root does the atomics.
+    // A wave holds 64 consecutive pixels of one row.  The components that draw crowds are few and large (a moving scene is one
+    // component as large as the frame), so the roots of the wave's first lanes with something to report -- two rounds -- are
+    // handled by one lane each: the leftmost run start, the rightmost run end, the row and the leftmost seed of that root in
+    // the wave, taken from ballots.  Whatever is left (small components: little company) reports lane by lane, in parallel.
     const unsigned long long m_l = __ballot(start_l), m_r = __ballot(end_r), m_s = __ballot(seed0);
     unsigned long long todo = m_l | m_r | m_s;
-    while (todo) {                                    // wave-uniform
+    for (int round = 0; round < 2 && todo; round++) {         // wave-uniform
         const int leader = __ffsll((long long)todo) - 1;
         const int r0 = __shfl(r, leader);
         const unsigned long long g = __ballot(r == r0);
@@ -188,6 +194,11 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
             if (gs) acc_min(&ac[r0].seed, i - lane + __ffsll((long long)gs) - 1);
         }
         todo &= ~g;
+    }
+    if ((todo >> lane) & 1ull) {
+        if (start_l) { acc_min(&ac[r].minx, x); acc_min(&ac[r].miny, y); acc_max(&ac[r].maxy, y); }
+        if (end_r) acc_max(&ac[r].maxx, x);
+        if (seed0) acc_min(&ac[r].seed, i);
     }
 }
 
