@@ -1649,7 +1649,8 @@ int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
 
 // run a set of detectMultiScale calls to completion: one wait per round for all of them.  lanes (optional, [n]): the lane
 // each job runs on -- jobs of one lane execute in order, lanes side by side
-double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS: where run_detect_jobs spends the host's time
+double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS (diagnostic, one context at a time): where run_detect_jobs spends the host's time
+static const bool g_job_stats = getenv("NVCA_PART_STATS") != nullptr;
 static inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
 {
@@ -1661,7 +1662,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         if (!total) return NVCA_OK;
         int r0 = 0, rc = NVCA_OK;
         bool used[kLanes] = {false};
-        const double t0 = mono_s();
+        const double t0 = g_job_stats ? mono_s() : 0;
         for (int i = 0; i < n && !rc; i++) {
             if (jobs[i]->phase == 3) continue;
             ctx->cur_lane = lanes ? lanes[i] : lane0;
@@ -1669,17 +1670,17 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
             r0 += jobs[i]->slots();
         }
-        const double t1 = mono_s();
-        g_jobs_enqueue_s += t1 - t0;
+        const double t1 = g_job_stats ? mono_s() : 0;
+        if (g_job_stats) g_jobs_enqueue_s += t1 - t0;
         for (int l = 0; l < kLanes; l++) {
             if (!used[l]) continue;
             const hipError_t he = hipStreamSynchronize(ctx->lane_streams[l]);
             if (he != hipSuccess && !rc) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); rc = NVCA_ERR_HIP; }
         }
         ctx->cur_lane = lane0;
-        const double t2 = mono_s();
-        g_jobs_wait_s += t2 - t1;
-        struct Adv { double t; ~Adv() { g_jobs_advance_s += mono_s() - t; } } adv{t2};
+        const double t2 = g_job_stats ? mono_s() : 0;
+        if (g_job_stats) g_jobs_wait_s += t2 - t1;
+        struct Adv { double t; ~Adv() { if (g_job_stats) g_jobs_advance_s += mono_s() - t; } } adv{t2};
         drain_timer(ctx);
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;

@@ -319,7 +319,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
     static const bool stats = getenv("NVCA_PART_STATS") != nullptr;    // diagnostic: the host's time per phase of calls with 8 or more streams, every 8 such calls
     static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
-    const double ts0 = mono_s();
+    const double ts0 = stats ? mono_s() : 0;
     // ---- phase 1: gating, image chains and face passes of every stream, in stream order
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
@@ -464,7 +464,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         used_lanes.erase(std::unique(used_lanes.begin(), used_lanes.end()), used_lanes.end());
         CK(part_images_done(ctx, used_lanes.data(), (int)used_lanes.size()));
     }
-    const double ts1 = mono_s();
+    const double ts1 = stats ? mono_s() : 0;
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 1: every face pass
     // a stream's faces: result k of its pass's job
     auto pass_result = [&](const PartWork &w, bool mirrored) -> const std::vector<nvca_rect> & {
@@ -473,7 +473,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         const size_t per_job = fp.type == 2 ? kJobImages / 2 : kJobImages, ji = pos / per_job, in_job = std::min(fp.members.size() - ji * per_job, per_job);
         return detect_job_out(fp.jobs[ji], (int)(pos % per_job + (mirrored ? in_job : 0)));
     };
-    const double ts2 = mono_s();
+    const double ts2 = stats ? mono_s() : 0;
     // ---- phase 2: the part searches of every face of every stream
     jobs.clear(); job_lane.clear();
     for (int i = 0; i < n; i++) {
@@ -522,7 +522,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         }
         for (RoiJob &r : w.rois) if (r.job) { jobs.push_back(r.job); job_lane.push_back(w.lane); }
     }
-    const double ts3 = mono_s();
+    const double ts3 = stats ? mono_s() : 0;
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 2 (+ one more for searches that narrowed)
     if (stats) {
         const double ts4 = mono_s();
