@@ -23,12 +23,12 @@ with tempfile.TemporaryDirectory() as td:
     def run(nframes, extra):
         env = build_gst.env(); env["NVCA_CASCADE_DIR"] = td; env["NVCA_GST_STATS"] = "1"; env["NVCA_HARNESS_LOOP"] = str(nframes); env.update(extra)
         t0 = time.time()
-        r = subprocess.run([build_gst.HARNESS, "nubofacedetector", "BGR", str(W), str(H), ",".join([raw] * B), "process-x-every-4-frames=4"],
+        r = subprocess.run([build_gst.HARNESS, "nubofacedetector", "BGR", str(W), str(H), ",".join([raw] * B), "process-x-every-4-frames=4"] + os.environ.get("BENCH_GST_PROPS", "").split(),
                            env=env, capture_output=True, text=True, timeout=600)
         dt = time.time() - t0
         assert r.returncode == 0, r.stderr[-1000:]
         stat = [l for l in r.stderr.splitlines() if "largest combined" in l]
-        return dt, (stat[-1].split()[-1] if stat else "?")
+        return dt, (stat[-1].split("batch")[1].split()[0] if stat else "?")
 
     # every branch pushes the same one-frame file n times (multifilesrc loop); start-up is removed by differencing
     n1 = 50
