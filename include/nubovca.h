@@ -263,7 +263,11 @@ int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, 
 
 /* Batched frontend for the part detectors (BASELINE config 3, the ROI chain): frame i belongs to streams[i] (a stream at most
  * once per call; the streams may be of different kinds).  The device work of all streams is queued together: one wait for
- * every face pass, one for every part search, instead of several per stream.  out_a is [n][cap_a], out_b [n][cap_b]. */
+ * every face pass, one for every part search, instead of several per stream.  Streams handed the same frame (same data
+ * pointer and geometry: the detectors of one video stream) share its upload and whatever they compute identically from it;
+ * working images of all frames come out of one launch set per size, face passes run as N-image jobs.  Every frame is
+ * validated before any stream's frame gate advances (NVCA_ERR_ARG leaves all streams untouched).  Results are those of
+ * nvca_part_stream_process per stream.  out_a is [n][cap_a], out_b [n][cap_b]. */
 int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames,
                              nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
 

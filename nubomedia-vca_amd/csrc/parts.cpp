@@ -262,9 +262,9 @@ int nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, i
 }
 
 // One transform_frame_ip of every stream of the batch.  The streams' device work is queued together and waited for three
-// times per call, however many streams there are: (1) gray / equalize / resize / flip of every frame and every face pass,
-// (2) every part search in every face's region (FIND_BIGGEST searches that narrow their scan take one more round),
-// (3) nothing -- the merging heuristics that follow are host code on the collected boxes.
+// times per call, however many streams there are: (1) the working images of all frames (a launch set per image size) and the
+// face passes (an N-image job per kind of pass), (2) every part search in every face's region (FIND_BIGGEST searches that
+// narrow their scan take one more round), (3) nothing -- the merging heuristics that follow are host code on the collected boxes.
 int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, nvca_rect *out_a, int cap_a,
                             int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
 {
@@ -282,8 +282,6 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         }
     }
     (void)hipSetDevice(ctx->device);
-    // the image primitives below hand device buffers to each other on the context's stream: no drain in between
-    struct Defer { nvca_ctx *c; Defer(nvca_ctx *x) : c(x) { c->defer_device_sync++; } ~Defer() { c->defer_device_sync--; } } defer(ctx);
     std::vector<FrameGroup> groups;
     std::vector<ImageBatch> batches;
     std::deque<FacePass> passes;
@@ -320,7 +318,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     static const bool stats = getenv("NVCA_PART_STATS") != nullptr;    // diagnostic: the host's time per phase of calls with 8 or more streams, every 8 such calls
     static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
     const double ts0 = stats ? mono_s() : 0;
-    // ---- phase 1: gating, image chains and face passes of every stream, in stream order
+    // ---- phase 1a: gating of every stream, in stream order; what the streams that run need is only noted down here
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
         nvca_part_stream *s = w.s = streams[i]; const nvca_frame *f = w.f = &frames[i];
