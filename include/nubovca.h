@@ -149,7 +149,8 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src_gray, int w, int h, int 
  * TRK/gstnubotracker.cpp:388-395 and the nose / mouth / ear elements call it: the 3-pixel band around the outline, the four
  * outermost corner pixels left out (round joins of radius 1).  NVCA_SHAPE_RING4: circle(img, (x, y), w, colour, 4, 8, 0),
  * EYE/kmseyedetect.cpp:1075-1092: the pixels at distance [w - 2, w + 2] from the centre.  Shapes are drawn in order.
- * The rasterisation rules are this library's statement of OpenCV's thick-line code, not pixel-verified against it. */
+ * The rasterisation rules are this library's statement of OpenCV's thick-line code, not pixel-verified against it.
+ * Host frames need no device: ctx may be NULL for them. */
 #define NVCA_SHAPE_RECT3 0
 #define NVCA_SHAPE_RING4 1
 typedef struct { int kind; int x, y, w, h; uint8_t bgra[4]; } nvca_shape;

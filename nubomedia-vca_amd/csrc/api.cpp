@@ -1056,15 +1056,17 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
 
 int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const nvca_shape *shapes, int n)
 {
-    NVCA_LOCK_OR_FAIL(ctx);
-    if (!frame || (channels != 3 && channels != 4) || n < 0 || (n > 0 && !shapes) || n > 1024) return NVCA_ERR_ARG;
-    int rc = check_img(ctx, frame->data, frame->width, frame->height, frame->stride, channels, frame->mem);
-    if (rc) return rc;
+    // host frames need no device (and no context): plain loops over the mapped buffer
+    const bool host = frame && frame->mem == NVCA_MEM_HOST;
+    if (!frame || (!ctx && !host) || (channels != 3 && channels != 4) || n < 0 || (n > 0 && !shapes) || n > 1024) return NVCA_ERR_ARG;
+    if (!frame->data || frame->width <= 0 || frame->height <= 0 || frame->stride < frame->width * channels || (frame->mem != NVCA_MEM_HOST && frame->mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
     for (int i = 0; i < n; i++)
         if ((shapes[i].kind != NVCA_SHAPE_RECT3 && shapes[i].kind != NVCA_SHAPE_RING4) || std::abs((long long)shapes[i].x) > (1 << 24) || std::abs((long long)shapes[i].y) > (1 << 24) ||
             std::abs((long long)shapes[i].w) > (1 << 24) || std::abs((long long)shapes[i].h) > (1 << 24)) return NVCA_ERR_ARG;
     if (!n) return NVCA_OK;
-    if (frame->mem == NVCA_MEM_HOST) { draw_shapes_host((uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, shapes, n); return NVCA_OK; }
+    if (host) { draw_shapes_host((uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, shapes, n); return NVCA_OK; }
+    NVCA_LOCK_OR_FAIL(ctx);
+    int rc;
     (void)hipSetDevice(ctx->device);
     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;          // common bounding box, clipped to the frame
     for (int i = 0; i < n; i++) {

@@ -430,6 +430,20 @@ class Cascade:
             self.h = None
 
 
+def draw_shapes_host(img, channels, shapes):
+    """nvca_draw_shapes on a host image without a context (no device needed): drawn in place"""
+    L = load()
+    fr = make_frame(img)
+    arr = (Shape * max(len(shapes), 1))()
+    for i, (kind, x, y, w, h, col) in enumerate(shapes):
+        arr[i].kind, arr[i].x, arr[i].y, arr[i].w, arr[i].h = kind, x, y, w, h
+        for k in range(4):
+            arr[i].bgra[k] = col[k]
+    rc = L.nvca_draw_shapes(None, C.byref(fr), channels, arr, len(shapes))
+    if rc != 0:
+        raise NvcaError(rc, "nvca_draw_shapes")
+
+
 def make_frame(arr_or_ptr, width=None, height=None, stride=None, mem=MEM_HOST, pts=0):
     """Frame from a numpy HxWxC uint8 array (host) or a raw device pointer."""
     if isinstance(arr_or_ptr, np.ndarray):

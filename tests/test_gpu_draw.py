@@ -1,11 +1,13 @@
 """view-* outlines: nvca_draw_shapes on host frames (what the GStreamer shim calls) and on device frames
-(a viewed stream that stays in HBM) against a reference written here from the rule include/nubovca.h states: the rectangle
+(a viewed stream that stays in HBM) against the reference of tests/draw_reference.py, written from the rule include/nubovca.h states: the rectangle
 of cvRectangle(..., thickness 3) as the union of its four 3-pixel edge bands plus the 4-neighbourhood of each vertex
 (FACE/kmsfacedetect.cpp:836-845), the circle of circle(..., thickness 4) as the ring of distances [r - 2, r + 2]
 (EYE/kmseyedetect.cpp:1075-1092).  Not pinned against OpenCV's rasteriser (no OpenCV offline): the three implementations
 (numpy here, the library's host loop, the kernel) agree pixel for pixel."""
 import numpy as np
 import pytest
+
+from draw_reference import _ref, _shapes
 
 pytestmark = pytest.mark.gpu
 
@@ -16,43 +18,6 @@ def ctx():
     c = capi.Context(0)
     yield c
     c.close()
-
-
-def _ref(img, shapes):
-    H, W, C = img.shape
-    yy, xx = np.mgrid[0:H, 0:W]
-    for kind, x, y, w, h, col in shapes:
-        if kind == 1:
-            if w < 0:
-                continue
-            d2 = (xx - x).astype(np.int64) ** 2 + (yy - y).astype(np.int64) ** 2
-            m = (d2 <= (w + 2) ** 2) & (d2 >= max(w - 2, 0) ** 2)
-        else:
-            x0, x1 = sorted((x, x + w))
-            y0, y1 = sorted((y, y + h))
-            m = np.zeros((H, W), bool)
-
-            def span(ax0, ax1, ay0, ay1):
-                m[max(ay0, 0):max(ay1 + 1, 0), max(ax0, 0):max(ax1 + 1, 0)] = True
-            span(x0, x1, y0 - 1, y0 + 1); span(x0, x1, y1 - 1, y1 + 1)
-            span(x0 - 1, x0 + 1, y0, y1); span(x1 - 1, x1 + 1, y0, y1)
-            for cx, cy in ((x0, y0), (x1, y0), (x1, y1), (x0, y1)):
-                for dx, dy in ((-1, 0), (1, 0), (0, -1), (0, 1)):
-                    if 0 <= cx + dx < W and 0 <= cy + dy < H:
-                        m[cy + dy, cx + dx] = True
-        img[m] = np.asarray(col[:C], np.uint8)
-    return img
-
-
-def _shapes(rng, W, H, n):
-    out = []
-    for i in range(n):
-        col = tuple(int(v) for v in rng.integers(0, 256, 4))
-        if i % 3 == 2:
-            out.append((1, int(rng.integers(-20, W + 20)), int(rng.integers(-20, H + 20)), int(rng.integers(-2, H // 2)), 0, col))
-        else:
-            out.append((0, int(rng.integers(-30, W + 10)), int(rng.integers(-30, H + 10)), int(rng.integers(-W // 2, W)), int(rng.integers(-H // 2, H)), col))
-    return out
 
 
 @pytest.mark.parametrize("C,W,H,n", [(3, 160, 120, 7), (4, 333, 251, 12), (3, 1920, 1080, 40), (4, 64, 48, 1), (3, 40, 30, 0)])
