@@ -317,6 +317,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
     static const bool stats = getenv("NVCA_PART_STATS") != nullptr;    // diagnostic: the host's time per phase of calls with 8 or more streams, every 8 such calls
     static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
+    static const int stats_min = stats && atoi(getenv("NVCA_PART_STATS")) > 0 ? atoi(getenv("NVCA_PART_STATS")) : 8;     // NVCA_PART_STATS=n: calls with n or more streams
     const double ts0 = stats ? mono_s() : 0;
     // ---- phase 1a: gating of every stream, in stream order; what the streams that run need is only noted down here
     for (int i = 0; i < n; i++) {
@@ -524,9 +525,9 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 2 (+ one more for searches that narrowed)
     if (stats) {
         const double ts4 = mono_s();
-        if (n >= 8) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
+        if (n >= stats_min) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
         else g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
-        if (n >= 8 && ++calls % 8 == 0) {
+        if (n >= stats_min && ++calls % 8 == 0) {
             fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f\n",
                     acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3);
             acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
