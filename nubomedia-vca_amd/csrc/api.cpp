@@ -438,10 +438,10 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             if (getenv("NVCA_STAMPS_OUT") && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->cs()); ctx->stamps = a.dbg; }
         }
 #endif
-        // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots; otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
+        // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots (>= 540 bands); otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
         const char *band_e = getenv("NVCA_BAND");
         const int band_env = band_e ? atoi(band_e) : -1;
-        const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 640);     // measured crossover at 1080p: 8 frames (544 bands) equal, 16 frames +20 %
+        const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 540);     // measured crossover at 1080p (68 bands per frame): 4 frames -21 %, 8 frames +5 %, 12 frames +24 %
         auto launch = [&](int which) {
             const int e = launch_cascade_sc(ctx->cs(), a, batch, which, ctx->lds_grant);
             if (e) ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e));

@@ -93,7 +93,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             if (t->num_frames > 0) any_ccl = true;
         }
         if (ws.slots.ensure(sizeof(TrkSlot) * batch) || ws.h_slots.ensure(sizeof(TrkSlot) * batch) ||
-            ws.labels.ensure(sizeof(int) * N * batch) || ws.acc.ensure(sizeof(CompAcc) * N * batch) ||
+            ws.labels.ensure(sizeof(int) * N * batch) || ws.acc.ensure(sizeof(CompAcc) * N * batch) || ws.flags.ensure(tracker_flag_bytes(W, H, batch) + 64) ||
             ws.out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) || ws.h_out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) ||
             (stage_bytes && ws.staging.ensure(stage_bytes))) { ctx->set_error("tracker workspace allocation failed"); return NVCA_ERR_NOMEM; }
         TrkSlot *hs = ws.h_slots.as<TrkSlot>();
@@ -117,8 +117,9 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
         }
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->stream));
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->stream));
         { TimedLaunch tl(ctx, NVCA_K_TRACKER);
-          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl); }
+          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>()); }
         NVCA_HIP_CHECK(ctx, hipGetLastError());
         tp1 = std::chrono::steady_clock::now();
         int *ho = ws.h_out.as<int>();
