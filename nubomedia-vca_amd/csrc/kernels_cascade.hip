@@ -5,7 +5,7 @@
 // FACE/kmsfacedetect.cpp:809-811.
 //
 // Launches per batch of frames:
-//  K5  k_band        (batches with >= 640 bands in flight, api.cpp) one workgroup per row of tiles of a
+//  K5  k_band        (batches with >= 540 bands in flight, api.cpp) one workgroup per row of tiles of a
 //                    scale, walking it left to right: per tile (<= 32 x 32 windows) the integral
 //                    samples the windows touch are staged, compacted, in LDS; window variance and
 //                    stage 0 for every window; OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
