@@ -26,15 +26,15 @@ __device__ __forceinline__ int gray4(unsigned px)
 
 // 4 pixels per thread; w4 = ceil(w / 4); rows packed (prev / mhi pitch == w)
 // does this block's 1024-pixel row segment hold any motion history?  (block-wide OR; one byte per segment)
-// live segments are also counted per slot (the int counters sit behind the flag bytes, zeroed before the launch): a scene
-// that moves everywhere is walked differently by k_ccl_reduce
+// live segments of every 16th row are also counted per slot (the int counters sit behind the flag bytes, zeroed before the
+// launch): a scene that moves everywhere is walked differently by k_ccl_reduce
 __device__ __forceinline__ int *segment_counts(const uint8_t *flags, int nseg, int h) { return (int *)(flags + (((size_t)nseg * h * gridDim.z + 63) & ~(size_t)63)); }
 __device__ __forceinline__ void segment_flag(uint8_t *__restrict__ flags, int h, bool any)
 {
     const int hit = __syncthreads_or(any ? 1 : 0);
     if (threadIdx.x == 0) {
         flags[((size_t)blockIdx.z * h + blockIdx.y) * gridDim.x + blockIdx.x] = hit ? 1 : 0;
-        if (hit) atomicAdd(segment_counts(flags, gridDim.x, h) + blockIdx.z, 1);
+        if (hit && (blockIdx.y & 15) == 0) atomicAdd(segment_counts(flags, gridDim.x, h) + blockIdx.z, 1);       // every 16th row: an estimate is all that is asked
     }
 }
 
@@ -183,15 +183,25 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, C
 // per-CU cache) would still be improved -- minima only fall and maxima only rise, so a stale read costs an atomic, never a
 // result.  A moving scene is one component as large as the frame: without the test every run of every row queues up on the
 // same five words (12 ms per 720p frame instead of 0.1).
-__device__ __forceinline__ void acc_min(int *p, int v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v); }
-__device__ __forceinline__ void acc_max(int *p, int v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v); }
+// what one lane reports for a root: candidates for the box and the first seed (INT_MAX / -1: nothing to report for that word).
+// The five words are read first -- independent loads, one round trip -- then only the atomics that still improve are issued.
+__device__ __forceinline__ int acc_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void acc_report(CompAcc *c, int minx, int maxx, int y, bool row, int seed)
+{
+    const int cur_minx = acc_peek(&c->minx), cur_miny = acc_peek(&c->miny), cur_maxx = acc_peek(&c->maxx), cur_maxy = acc_peek(&c->maxy), cur_seed = acc_peek(&c->seed);
+    if (minx < cur_minx) atomicMin(&c->minx, minx);
+    if (maxx > cur_maxx) atomicMax(&c->maxx, maxx);
+    if (row && y < cur_miny) atomicMin(&c->miny, y);
+    if (row && y > cur_maxy) atomicMax(&c->maxy, y);
+    if (seed < cur_seed) atomicMin(&c->seed, seed);
+}
 
 __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
                                                     CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags, int order)
 {
     const TrkSlot s = slots[blockIdx.z];
     const int nseg = (w + 1023) / 1024;
-    if (order < 0) order = 2 * segment_counts(flags, nseg, h)[blockIdx.z] > nseg * h ? 1 : 0;      // most of the frame holds motion: outside in
+    if (order < 0) order = 2 * segment_counts(flags, nseg, h)[blockIdx.z] > nseg * ((h + 15) / 16) ? 1 : 0;      // most of the frame holds motion: outside in
     const int n = w * h;
     const int *lab = labels + (size_t)blockIdx.z * n;
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
@@ -219,24 +229,20 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     // the wave, taken from ballots.  Whatever is left (small components: little company) reports lane by lane, in parallel.
     const unsigned long long m_l = __ballot(start_l), m_r = __ballot(end_r), m_s = __ballot(seed0);
     unsigned long long todo = m_l | m_r | m_s;
-    for (int round = 0; round < 2 && todo; round++) {         // wave-uniform
+    const int rounds = order ? 2 : 1;                         // a crowded frame: two roots by proxy; otherwise the first one only
+    for (int round = 0; round < rounds && todo; round++) {    // wave-uniform
         const int leader = __ffsll((long long)todo) - 1;
         const int r0 = __shfl(r, leader);
         const unsigned long long g = __ballot(r == r0);
         if (lane == leader) {
             const unsigned long long gl = g & m_l, gr = g & m_r, gs = g & m_s;
             const int xb = x - lane;
-            if (gl) { acc_min(&ac[r0].minx, xb + __ffsll((long long)gl) - 1); acc_min(&ac[r0].miny, y); acc_max(&ac[r0].maxy, y); }
-            if (gr) acc_max(&ac[r0].maxx, xb + 63 - __clzll((long long)gr));
-            if (gs) acc_min(&ac[r0].seed, i - lane + __ffsll((long long)gs) - 1);
+            acc_report(&ac[r0], gl ? xb + __ffsll((long long)gl) - 1 : 0x7fffffff, gr ? xb + 63 - __clzll((long long)gr) : -1, y, gl != 0,
+                       gs ? i - lane + __ffsll((long long)gs) - 1 : 0x7fffffff);
         }
         todo &= ~g;
     }
-    if ((todo >> lane) & 1ull) {
-        if (start_l) { acc_min(&ac[r].minx, x); acc_min(&ac[r].miny, y); acc_max(&ac[r].maxy, y); }
-        if (end_r) acc_max(&ac[r].maxx, x);
-        if (seed0) acc_min(&ac[r].seed, i);
-    }
+    if ((todo >> lane) & 1ull) acc_report(&ac[r], start_l ? x : 0x7fffffff, end_r ? x : -1, y, start_l, seed0 ? i : 0x7fffffff);
 }
 
 __global__ __launch_bounds__(256) void k_ccl_collect(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
