@@ -25,16 +25,18 @@ __device__ __forceinline__ int gray4(unsigned px)
 }
 
 // 4 pixels per thread; w4 = ceil(w / 4); rows packed (prev / mhi pitch == w)
-// does this block's 1024-pixel row segment hold any motion history?  (block-wide OR; one byte per segment)
-// live segments of every 16th row are also counted per slot (the int counters sit behind the flag bytes, zeroed before the
-// launch): a scene that moves everywhere is walked differently by k_ccl_reduce
-__device__ __forceinline__ int *segment_counts(const uint8_t *flags, int nseg, int h) { return (int *)(flags + (((size_t)nseg * h * gridDim.z + 63) & ~(size_t)63)); }
-__device__ __forceinline__ void segment_flag(uint8_t *__restrict__ flags, int h, bool any)
+// Does a 256-pixel row segment (one wave of the pixel pass = one block of the component kernels) hold any motion history?  One
+// byte per segment.  Live segments of every 16th row are also counted per slot (int counters behind the flag bytes, zeroed
+// before the launch): a scene that moves everywhere is walked differently by k_ccl_reduce.
+__device__ __forceinline__ int seg_per_row(int w) { return (w + 255) / 256; }
+__device__ __forceinline__ int *segment_counts(const uint8_t *flags, int w, int h) { return (int *)(flags + (((size_t)seg_per_row(w) * h * gridDim.z + 63) & ~(size_t)63)); }
+__device__ __forceinline__ void segment_flag(uint8_t *__restrict__ flags, int w, int h, bool any)
 {
-    const int hit = __syncthreads_or(any ? 1 : 0);
-    if (threadIdx.x == 0) {
-        flags[((size_t)blockIdx.z * h + blockIdx.y) * gridDim.x + blockIdx.x] = hit ? 1 : 0;
-        if (hit && (blockIdx.y & 15) == 0) atomicAdd(segment_counts(flags, gridDim.x, h) + blockIdx.z, 1);       // every 16th row: an estimate is all that is asked
+    const bool hit = __ballot(any) != 0ull;
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && seg < seg_per_row(w)) {
+        flags[((size_t)blockIdx.z * h + blockIdx.y) * seg_per_row(w) + seg] = hit ? 1 : 0;
+        if (hit && (blockIdx.y & 15) == 0) atomicAdd(segment_counts(flags, w, h) + blockIdx.z, 1);       // an estimate is all that is asked
     }
 }
 
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void k_trk_pixel(const TrkSlot *__restrict__ s
         }
         s.prev[o + k] = (uint8_t)g;
     }
-    segment_flag(flags, h, any);
+    segment_flag(flags, w, h, any);
 }
 
 // vectorised variant: w % 4 == 0, 16-byte aligned frame rows
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_trk_pixel4(const TrkSlot *__restrict__ 
         }
         *(unsigned *)(s.prev + o) = (unsigned)g0 | ((unsigned)g1 << 8) | ((unsigned)g2 << 16) | ((unsigned)g3 << 24);
     }
-    segment_flag(flags, h, any);
+    segment_flag(flags, w, h, any);
 }
 
 // ---- union-find on pixel indices (labels[i] = parent; roots are self-parented) ----
@@ -112,10 +114,10 @@ __device__ __forceinline__ bool joined(float a, float b, float seg)
     return -seg <= d && d <= seg;
 }
 
-// the component kernels run 256 pixels of a row per block: four blocks per flagged segment
+// the component kernels run 256 pixels of a row per block: one flagged segment
 __device__ __forceinline__ bool segment_live(const uint8_t *__restrict__ flags, int w, int h)
 {
-    return flags[((size_t)blockIdx.z * h + blockIdx.y) * ((w + 1023) / 1024) + (blockIdx.x >> 2)] != 0;
+    return flags[((size_t)blockIdx.z * h + blockIdx.y) * seg_per_row(w) + blockIdx.x] != 0;
 }
 
 // Labels start as horizontal runs: within a wave (64 consecutive pixels of a row) every pixel points at the first pixel
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
                                                     CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags, int order)
 {
     const TrkSlot s = slots[blockIdx.z];
-    const int nseg = (w + 1023) / 1024;
-    if (order < 0) order = 2 * segment_counts(flags, nseg, h)[blockIdx.z] > nseg * ((h + 15) / 16) ? 1 : 0;      // most of the frame holds motion: outside in
+    const int nseg = seg_per_row(w);
+    if (order < 0) order = 2 * segment_counts(flags, w, h)[blockIdx.z] > nseg * ((h + 15) / 16) ? 1 : 0;      // most of the frame holds motion: outside in
     const int n = w * h;
     const int *lab = labels + (size_t)blockIdx.z * n;
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     // queueing up (0.76 -> 0.46 ms per 4 x 720p); otherwise top to bottom, which is kinder to memory (0.49 -> 0.42 ms per 8 x 1080p)
     const int by = (order & 1) ? ((blockIdx.y & 1) ? h - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1)) : (int)blockIdx.y;
     const int bx = (int)blockIdx.x;
-    if (!flags[((size_t)blockIdx.z * h + by) * ((w + 1023) / 1024) + (bx >> 2)]) return;
+    if (!flags[((size_t)blockIdx.z * h + by) * nseg + bx]) return;
     const int x = bx * 256 + threadIdx.x, y = by, lane = threadIdx.x & 63;
     const int i = y * w + x;
     const int r = x < w ? lab[i] : -1;                // labels are final roots after k_ccl_flatten

@@ -336,12 +336,12 @@ struct TrkSlot {                // per tracker in the batch
 };
 struct CompAcc { int minx, miny, maxx, maxy, seed, pad; };   // per root, stored at the root's pixel index
 // out: [0] = component count, [1] unused, then 6 ints per component: slot, first seed index, x, y, w, h
-// flags: one byte per 1024-pixel row segment and slot, set by the pixel pass where the motion history holds anything -- the
+// flags: one byte per 256-pixel row segment and slot, set by the pixel pass where the motion history holds anything -- the
 // component kernels leave the other segments alone (a static scene with a few moving objects is mostly such segments)
 void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
                     int *out, int cap, bool run_ccl, uint8_t *flags);
-inline size_t tracker_flag_bytes(int w, int h, int batch) { return (((size_t)((w + 1023) / 1024) * h * batch + 63) & ~(size_t)63) + sizeof(int) * (size_t)batch; }   // flag bytes, then a live-segment count per slot
-inline size_t tracker_count_offset(int w, int h, int batch) { return ((size_t)((w + 1023) / 1024) * h * batch + 63) & ~(size_t)63; }
+inline size_t tracker_count_offset(int w, int h, int batch) { return ((size_t)((w + 255) / 256) * h * batch + 63) & ~(size_t)63; }
+inline size_t tracker_flag_bytes(int w, int h, int batch) { return tracker_count_offset(w, h, batch) + sizeof(int) * (size_t)batch; }   // flag bytes, then a live-segment count per slot
 
 struct CascadeArgs {
     const int *sum; const unsigned long long *sqsum;
