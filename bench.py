@@ -467,8 +467,17 @@ def main():
                         "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
                         "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
                         "kernels": kern, "lds": lds,
+                        "dominant_launch": None,
                         "timed_steps": sampled_steps,      # steps of the timed region whose launches carried HIP events (every `stride`-th)
                         "detail_ms_per_launch": {k: v[0] / v[1] for k, v in ktimes.items() if v[1]}}
+        if roofline and dom == "cascade":
+            # `frac` prices the whole cascade group (band / tile + late stages + grouping) against its algorithmic bytes; the single
+            # longest launch of the group on its own (what `rocprofv3 --stats` lists first):
+            det = roofline["detail_ms_per_launch"]
+            name = max((k for k in det if k.startswith("cascade_")), key=lambda k: det[k], default=None)
+            if name and det[name] > 0:
+                ach = kern[dom]["alg_bytes_per_launch"] / (det[name] * 1e-3) / 1e9
+                roofline["dominant_launch"] = {"name": name, "ms": det[name], "achieved": ach, "frac": ach / HBM_PEAK_GBS}
         out = {
             "metric": "1080p frames/sec/node (NuboFaceDetector); achieved HBM GB/s vs peak",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
