@@ -1037,23 +1037,35 @@ __global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restr
     if (tid == 0) o[1] = n;
     if (n > kGroupMax || thr <= 0) { if (tid == 0) o[0] = -1; return; }       // host path (rare / ungrouped)
     if (n == 0) { if (tid == 0) o[0] = 0; return; }
-    // ---- bitonic sort of the keys (ascending), padded with 0xffffffff
-    int np = 1;
-    while (np < n) np <<= 1;
-    for (int i = n + tid; i < np; i += 256) keys[i] = 0xffffffffu;
-    __syncthreads();
-    for (int k = 2; k <= np; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned x = keys[i], y = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+    // ---- keys in ascending order.  Up to 256 of them (the usual case: a few dozen candidates per face): every thread counts
+    // the keys below its own (keys are distinct windows; equal keys would be told apart by position) and stores it at that
+    // rank -- two barriers instead of the ~30 of a bitonic network, which is what longer lists go through
+    if (n <= 256) {
+        const unsigned mine = tid < n ? keys[tid] : 0u;
+        int rank = 0;
+        if (tid < n)
+            for (int j = 0; j < n; j++) { const unsigned o = keys[j]; rank += (o < mine || (o == mine && j < tid)) ? 1 : 0; }
+        __syncthreads();
+        if (tid < n) keys[rank] = mine;
+        __syncthreads();
+    } else {
+        int np = 1;
+        while (np < n) np <<= 1;
+        for (int i = n + tid; i < np; i += 256) keys[i] = 0xffffffffu;
+        __syncthreads();
+        for (int k = 2; k <= np; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned x = keys[i], y = keys[l];
+                        const bool up = (i & k) == 0;
+                        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+    }
     // ---- rectangles + singleton sets
     for (int i = tid; i < n; i += 256) {
         const unsigned key = keys[i];
