@@ -267,8 +267,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline, boxes_match, the OpenCV probe)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary table (single-frame latency, host-frame rates, content sweep)")
     ap.add_argument("--host-frames", action="store_true", help="feed host buffers (PCIe-inclusive rate; not `value`)")
-    ap.add_argument("--pipeline", action="store_true", help="nvca_face_batch_submit / _collect with two batches in flight instead of one synchronous "
-                    "nvca_face_batch_process per step (faster without per-kernel timing, NVCA_BENCH_NOTIMING=1; the per-kernel events cost more than it gains)")
+    ap.add_argument("--pipeline", action="store_true", help="(the default since round 2) nvca_face_batch_submit / _collect with two batches in flight")
+    ap.add_argument("--sync", action="store_true", help="one synchronous nvca_face_batch_process call per step instead of the submit / collect serving loop")
     ap.add_argument("--pinned", action="store_true", help="with --host-frames: page-lock the frame buffers (nvca_host_register)")
     ap.add_argument("--workload", default="face1080p", choices=["face1080p", "streams720p", "face_tracker"],
                     help="face1080p: BASELINE configs[1] (default, the headline metric); streams720p: configs[3], "
@@ -356,7 +356,7 @@ def main():
 
     # serving loop: two batches in flight -- the next batch is queued before the previous one is unpacked, so the host
     # work between batches overlaps the GPU.  K steps = K submits + K collects; one batch stays in flight across steps.
-    pipelined = args.pipeline
+    pipelined = not args.sync              # the serving loop: the next batch is queued before the previous one is unpacked
     rows = [0] if pipelined else []          # frame-set index of every batch handed in, in order (the oracle replays them)
     inflight = [ctx.face_batch_submit(streams, frames_t[0])] if pipelined else [None]
     # the synchronous loop hands the same frame buffers in again and again: marshal the ctypes arguments once per buffer set
