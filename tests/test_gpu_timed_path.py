@@ -65,6 +65,36 @@ def test_face_batch_1080p_band_kernel_vs_oracle(ctx, casc, orc_cascade):
     fs.close()
 
 
+def test_face_batch_1080p_serving_loop_vs_oracle(ctx, casc, orc_cascade):
+    """the loop bench.py times by default: nvca_face_batch_submit / _collect with two batches of the ONE stream in flight
+    (batch k + 1 is queued before batch k is unpacked; the temporal logic of a stream runs in collect order), 10 frames of
+    1920x1080 per batch -> k_band; boxes and ids of every batch against the oracle fed the same frames in the same order"""
+    import orc
+    from nubovca import capi, synth
+    W, H, N, B = 1920, 1080, 10, 4
+    sets = [[synth.make_bgr(W, H, synth.frame_seed(7, 10 * b + i), "natural", [(x + 8 * i + 40 * b, y, s) for (x, y, s) in FACES_1080] if (i + b) % 6 != 3 else [])
+             for i in range(N)] for b in range(2)]
+    dev = [_device_frames(fs_) for fs_ in sets]
+    fs = capi.FaceStream(ctx, casc, width_to_process=W, multi_scale_factor=10)
+    ofs = orc.FaceStream(orc_cascade, width_to_process=W, scale_factor_pct=10)
+    ctx.enable_kernel_timing(1)
+    pending = ctx.face_batch_submit([fs] * N, dev[0][1])
+    seen = 0
+    for b in range(1, B + 1):
+        nxt = ctx.face_batch_submit([fs] * N, dev[b % 2][1]) if b < B else None
+        res = ctx.face_batch_collect(pending)
+        for i in range(N):
+            eb, eid = ofs.process(sets[(b - 1) % 2][i])
+            assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (b, i, res[i][0], eb)
+            seen += len(eb)
+        pending = nxt
+    kt = ctx.kernel_timing()
+    ctx.enable_kernel_timing(0)
+    assert _launched(kt, "cascade_band") == B and _launched(kt, "cascade_tile") == 0, kt
+    assert seen > 4 * B * (N - 4)
+    fs.close()
+
+
 def test_face_batch_32x720p_streams_vs_oracle(ctx, casc, orc_cascade):
     """configs[3], one GPU's shard: 32 streams of 1280x720, one frame each per tick, one batched call per tick"""
     import orc
