@@ -190,22 +190,40 @@ __device__ __forceinline__ double gen_node_sum(const int *__restrict__ pl, unsig
     if ((n.flags & 255) == 3) v += (double)((float)rs(2) * n.w[2]);
     return v;
 }
+// The weak classifiers of a stage are independent of one another up to their votes: four roots are evaluated per step -- their
+// 32 to 48 gathers are in flight together instead of one classifier's at a time -- then each walk is finished and the votes are
+// added in stage order (OpenCV's order: the f64 sum is the same).
 __device__ __forceinline__ bool gen_stage(const CascadeArgs &a, const int *__restrict__ sum, const int *__restrict__ tilt, unsigned off, int pitch,
                                           double vnf, const GNodeRec *recs, const StageRec &st)
 {
     const bool pair = a.pair_policy && a.stump_based && (st.flags & 1);
     double stage_sum = 0.0;
-    for (int j = 0; j < st.count; j++) {
-        const int base = a.gcls_first[st.first + j];
-        CGNodeRec &root = ((CGNodeRec *)recs)[base];
-        const double s = gen_node_sum((root.flags & 256) ? tilt : sum, off, pitch, root, pair);
-        int idx = s < (double)root.thr * vnf ? root.left : root.right;      // node->threshold * variance_norm_factor
-        while (idx > 0) {                                                   // below the root the lanes of a wave part ways
+    auto finish = [&](int base, int idx) {                                  // below the root the lanes of a wave part ways
+        while (idx > 0) {
             const GNodeRec &n = recs[base + idx];
             const double sn = gen_node_sum((n.flags & 256) ? tilt : sum, off, pitch, n, false);
             idx = sn < (double)n.thr * vnf ? n.left : n.right;
         }
-        stage_sum += (double)a.galpha[-idx];
+        return (double)a.galpha[-idx];
+    };
+    int j = 0;
+    for (; j + 4 <= st.count; j += 4) {
+        int base[4], idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            base[u] = a.gcls_first[st.first + j + u];
+            CGNodeRec &root = ((CGNodeRec *)recs)[base[u]];
+            const double s = gen_node_sum((root.flags & 256) ? tilt : sum, off, pitch, root, pair);
+            idx[u] = s < (double)root.thr * vnf ? root.left : root.right;   // node->threshold * variance_norm_factor
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) stage_sum += finish(base[u], idx[u]);
+    }
+    for (; j < st.count; j++) {
+        const int base = a.gcls_first[st.first + j];
+        CGNodeRec &root = ((CGNodeRec *)recs)[base];
+        const double s = gen_node_sum((root.flags & 256) ? tilt : sum, off, pitch, root, pair);
+        stage_sum += finish(base, s < (double)root.thr * vnf ? root.left : root.right);
     }
     return !(stage_sum < (double)st.thr);
 }
