@@ -272,7 +272,8 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     if (n < 0 || (n > 0 && (!streams || !frames || !n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
     for (int i = 0; i < n; i++) {
         const nvca_part_stream *s = streams[i]; const nvca_frame *f = &frames[i];
-        if (!s || s->ctx != ctx || !f->data || f->width <= 0 || f->height <= 0 || f->stride < f->width * 3 || s->p.width_to_process <= 0) return NVCA_ERR_ARG;
+        if (!s || s->ctx != ctx || !f->data || f->width <= 0 || f->height <= 0 || f->stride < f->width * 3 || s->p.width_to_process <= 0 ||
+            (f->mem != NVCA_MEM_HOST && f->mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
         for (int j = 0; j < i; j++) if (streams[j] == s) { ctx->set_error("a part stream may appear once per batch"); return NVCA_ERR_ARG; }
         // every frame is validated before any stream's gate advances: a refused call leaves all streams as they were
         const float o2f = (s->p.kind != NVCA_PART_EAR && s->p.detect_event) ? 1.f : ((float)f->width) / ((float)160);
