@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restr
                                                           unsigned *__restrict__ sq32)
 {
     __shared__ uint8_t sl[256];
-    __shared__ unsigned ws_s[2][kIntWaves], ws_q[2][kIntWaves];
+    __shared__ unsigned wrow_s[kIntegralBand][kIntWaves], wrow_q[kIntegralBand][kIntWaves];
     __shared__ unsigned wb_s[kIntWaves];
     __shared__ unsigned long long wb_q[kIntWaves];
     __shared__ unsigned carry_s[kIntegralBand], carry_q[kIntegralBand];
@@ -577,39 +577,59 @@ __global__ __launch_bounds__(kIntThreads) void k_integral(const uint8_t *__restr
             *(uint4 *)(lbase + X0) = make_uint4(0, 0, 0, 0);
             *(unsigned *)(hbase + X0) = 0u;
         }
-        // ---- rows of the band (the next row's pixels are in flight while this one is scanned)
-        unsigned px_next = 0;
-        if (X0 < g.w && y0 < y1) px_next = *(const unsigned *)(gbase + (size_t)y0 * g.gpitch + X0);
-        for (int y = y0; y < y1; y++) {
-            const int r = y - y0, par = r & 1;
-            const unsigned px = px_next;
-            if (X0 < g.w && y + 1 < y1) px_next = *(const unsigned *)(gbase + (size_t)(y + 1) * g.gpitch + X0);
+        // ---- rows of the band.  All rows' pixels are requested at once; every row's prefix over x is scanned inside the waves
+        // (DPP), the wave totals of all rows are exchanged through LDS behind ONE barrier (it was one per row), and the
+        // vertical running sums are then carried and stored row by row without further synchronisation.
+        const int nr = y1 - y0;
+        unsigned px[kIntegralBand];
+#pragma unroll
+        for (int r = 0; r < kIntegralBand; r++)
+            px[r] = (X0 < g.w && r < nr) ? *(const unsigned *)(gbase + (size_t)(y0 + r) * g.gpitch + X0) : 0u;
+        unsigned inc_s[kIntegralBand], inc_q[kIntegralBand];          // inclusive prefix (inside the wave) of the thread totals, per row
+#pragma unroll
+        for (int r = 0; r < kIntegralBand; r++) {
+            unsigned rs = 0, rq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned v = (X0 + k < g.w) ? (unsigned)sl[(px[r] >> (8 * k)) & 255] : 0u;
+                rs += v; rq += v * v;
+            }
+            inc_s[r] = wave_incl_scan_u32(rs, lane); inc_q[r] = wave_incl_scan_u32(rq, lane);
+            if (lane == 63) { wrow_s[r][wave] = inc_s[r]; wrow_q[r][wave] = inc_q[r]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kIntegralBand; r++) {
+            if (r < nr) {
+            // exclusive prefix of this thread in row r: the chunks to the left (carry), the waves to the left, the lanes to the left
+            unsigned e_s = carry_s[r], e_q = carry_q[r];
+            for (int j = 0; j < wave; j++) { e_s += wrow_s[r][j]; e_q += wrow_q[r][j]; }
             unsigned ls[4], lq[4];
             unsigned rs = 0, rq = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const unsigned v = (X0 + k < g.w) ? (unsigned)sl[(px >> (8 * k)) & 255] : 0u;
+                const unsigned v = (X0 + k < g.w) ? (unsigned)sl[(px[r] >> (8 * k)) & 255] : 0u;
                 rs += v; rq += v * v;
                 ls[k] = rs; lq[k] = rq;
             }
-            const unsigned t_s = rs, t_q = rq;
-            unsigned i_s = wave_incl_scan_u32(t_s + (tid == 0 ? carry_s[r] : 0u), lane);
-            unsigned i_q = wave_incl_scan_u32(t_q + (tid == 0 ? carry_q[r] : 0u), lane);
-            if (lane == 63) { ws_s[par][wave] = i_s; ws_q[par][wave] = i_q; }
-            __syncthreads();
-            for (int j = 0; j < wave; j++) { i_s += ws_s[par][j]; i_q += ws_q[par][j]; }
-            if (tid == kIntThreads - 1) { carry_s[r] = i_s; carry_q[r] = i_q; }
-            const unsigned e_s = i_s - t_s, e_q = i_q - t_q;
+            e_s += inc_s[r] - rs; e_q += inc_q[r] - rq;
             acc_s[0] += e_s; acc_q[0] += e_q;
 #pragma unroll
             for (int k = 1; k < 4; k++) { acc_s[k] += e_s + ls[k - 1]; acc_q[k] += e_q + lq[k - 1]; }
             if (in_pitch) {
-                const size_t o = (size_t)(y + 1) * g.spitch + X0;
+                const size_t o = (size_t)(y0 + r + 1) * g.spitch + X0;
                 *(int4 *)(sbase + o) = make_int4((int)acc_s[0], (int)acc_s[1], (int)acc_s[2], (int)acc_s[3]);
                 *(uint4 *)(lbase + o) = make_uint4((unsigned)acc_q[0], (unsigned)acc_q[1], (unsigned)acc_q[2], (unsigned)acc_q[3]);
                 *(unsigned *)(hbase + o) = (unsigned)(acc_q[0] >> 32) | ((unsigned)(acc_q[1] >> 32) << 8) | ((unsigned)(acc_q[2] >> 32) << 16) |
                                            ((unsigned)(acc_q[3] >> 32) << 24);
             }
+            }
+        }
+        __syncthreads();                                   // wrow_* and carry_* consumed
+        if (tid < kIntegralBand) {                          // this chunk's row totals join the carries (images wider than one chunk)
+            unsigned ts_ = 0, tq_ = 0;
+            for (int j = 0; j < kIntWaves; j++) { ts_ += wrow_s[tid][j]; tq_ += wrow_q[tid][j]; }
+            carry_s[tid] += ts_; carry_q[tid] += tq_;
         }
         __syncthreads();
     }
