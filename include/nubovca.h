@@ -11,7 +11,10 @@
  *
  * Conventions: plain C types only; opaque handles; the caller owns all frame
  * memory; the library owns device state.  Every function returns an int status
- * (NVCA_OK == 0, < 0 error) and never throws.  A handle may be used by one
+ * (NVCA_OK == 0, < 0 error) and never throws: every entry point is a function-try-block
+ * (csrc/nvca_internal.h, NVCA_API_CATCH) that turns std::bad_alloc / std::length_error into NVCA_ERR_NOMEM and anything
+ * else into NVCA_ERR_INTERNAL -- the reference never lets a frame error out of the element either
+ * (FACE/kmsfacedetect.cpp:897 always returns GST_FLOW_OK).  A handle may be used by one
  * thread at a time; distinct contexts may be used concurrently.  There is no
  * CPU fallback: without a HIP device nvca_ctx_create fails.
  */
@@ -34,6 +37,8 @@ extern "C" {
                                     feature that leaves the image at some scale    */
 #define NVCA_ERR_OVERFLOW   -7   /* more raw candidates than the context's cap     */
 #define NVCA_ERR_NOMEM      -8
+#define NVCA_ERR_INTERNAL   -9   /* an internal check failed (a device result out of range, an exception caught at the
+                                    ABI boundary): the call's results are void, the context stays usable          */
 
 /* where a buffer handed to the library lives */
 #define NVCA_MEM_HOST   0
@@ -76,6 +81,12 @@ const char *nvca_version(void);
 /* raw-candidate capacity per frame (default 16384); more -> NVCA_ERR_OVERFLOW */
 int  nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap);
 int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
+/* Measurement / bisecting switches, per context.  The process-wide defaults come from the environment
+ * (NVCA_BAND, NVCA_TILES, ... read once, when the first context is created); this sets one for this context.  Names: "band"
+ * (-1 / 0 / 1), "band_map", "tiles", "deep_stage", "deep_lds", "pyr_off", "host_group", "group_zerocopy", "sparse_ingest",
+ * "ingest_chunk", "skip_cascade", "host_profile", "part_stats", "trk_order", "plan_debug", "quiet".  None of them changes a
+ * result.  Switches that shape plans drop the context's cached plans (not while a submitted batch is in flight). */
+int  nvca_ctx_set_option(nvca_ctx *ctx, const char *name, int value);
 /* block until everything queued on the context's HIP stream has finished */
 int  nvca_ctx_synchronize(nvca_ctx *ctx);
 /* the hipStream_t the context launches on (for interop / profiling) */
@@ -120,6 +131,15 @@ const char *nvca_kernel_name(int k);
 int  nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out);
 int  nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out);
 void nvca_cascade_free(nvca_cascade *c);
+/* The loader alone: parses an old-format cascade on the host and reports its shape (any out pointer may be NULL) or the
+ * loader's error text -- no device and no context needed, so cascade files can be checked on a box without a GPU.
+ * Same status codes as nvca_cascade_load_mem. */
+int  nvca_cascade_validate_mem(const char *xml, int64_t len, int *win_w, int *win_h, int *n_stages, int *n_weak,
+                               char *err, int err_cap);
+/* Exercises the exception barrier of the ABI (see "never throws" above): throws the exception `kind` names from inside an
+ * entry point and returns what the barrier made of it -- 0: std::bad_alloc -> NVCA_ERR_NOMEM, 1: std::length_error ->
+ * NVCA_ERR_NOMEM, 2: std::runtime_error, 3: a non-standard exception, 4: std::out_of_range -> NVCA_ERR_INTERNAL. */
+int  nvca_abi_selftest(int kind);
 /* window size, stage count, weak-classifier count (any pointer may be NULL) */
 int  nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stages, int *n_weak);
 /* has_tilted / has_trees (either pointer may be NULL): what kind of cascade the loader found */
@@ -267,7 +287,9 @@ int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, 
  * every face pass, one for every part search, instead of several per stream.  Streams handed the same frame (same data
  * pointer and geometry: the detectors of one video stream) share its upload and whatever they compute identically from it;
  * working images of all frames come out of one launch set per size, face passes run as N-image jobs.  Every frame is
- * validated before any stream's frame gate advances (NVCA_ERR_ARG leaves all streams untouched).  Results are those of
+ * validated before any stream's frame gate advances, and a call that fails later (a plan that cannot be built, an allocation,
+ * a refused launch) restores every stream's gates, queued face events and lists before it returns: ANY error leaves all
+ * streams as they were, and nothing of the call stays in flight.  Results are those of
  * nvca_part_stream_process per stream.  out_a is [n][cap_a], out_b [n][cap_b]. */
 int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames,
                              nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);

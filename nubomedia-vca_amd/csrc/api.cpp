@@ -11,6 +11,8 @@
 #include <fstream>
 #include <sstream>
 #include <chrono>
+#include <stdexcept>
+#include <new>
 
 using namespace nvca;
 
@@ -52,6 +54,20 @@ TimedLaunch::~TimedLaunch()
 {
     if (active) g_scope = prev;
 }
+static thread_local hipError_t g_launch_err = hipSuccess;
+static thread_local const char *g_launch_kernel = nullptr;
+void note_launch(const char *kernel)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && g_launch_err == hipSuccess) { g_launch_err = e; g_launch_kernel = kernel; }
+}
+hipError_t take_launch_error(const char **kernel)
+{
+    const hipError_t e = g_launch_err;
+    if (kernel) *kernel = g_launch_kernel;
+    g_launch_err = hipSuccess; g_launch_kernel = nullptr;
+    return e;
+}
 bool launch_events(hipEvent_t *a, hipEvent_t *b)
 {
     TimedLaunch *sc = g_scope;
@@ -90,6 +106,53 @@ static void drain_timer_now(nvca_ctx *ctx)
 static void drain_timer(nvca_ctx *ctx)
 {
     if (ctx->timer.pending.size() > 4096) drain_timer_now(ctx);
+}
+
+// handler of the ABI's function-try-blocks (NVCA_API_CATCH): called inside a catch (...) clause
+int api_catch(nvca_ctx *ctx) noexcept
+{
+    int code = NVCA_ERR_INTERNAL;
+    const char *what = "unknown exception";
+    char buf[160];
+    try { throw; }
+    catch (const std::bad_alloc &) { code = NVCA_ERR_NOMEM; what = "out of host memory (std::bad_alloc)"; }
+    catch (const std::length_error &e) { code = NVCA_ERR_NOMEM; snprintf(buf, sizeof(buf), "container size limit exceeded (%s)", e.what()); what = buf; }
+    catch (const std::exception &e) { snprintf(buf, sizeof(buf), "internal error: %s", e.what()); what = buf; }
+    catch (...) { }
+    if (ctx) {
+        try { std::lock_guard<std::recursive_mutex> lk(ctx->mu); ctx->err.assign(what); } catch (...) { }
+    }
+    return code;
+}
+
+static Switches read_switches()
+{
+    Switches w;
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    auto set = [](const char *name) { return getenv(name) != nullptr; };
+    w.group_zero_copy = num("NVCA_GROUP_ZEROCOPY", 1) != 0;
+    w.skip_cascade = set("NVCA_SKIP_CASCADE");
+    w.host_group = set("NVCA_HOST_GROUP");
+    w.band_map = num("NVCA_BAND_MAP", 0);
+    w.band = num("NVCA_BAND", -1);
+    w.host_profile = set("NVCA_HOST_PROFILE");
+    w.sparse_ingest = num("NVCA_SPARSE_INGEST", 1) != 0;
+    w.pyr_off = set("NVCA_PYR_OFF");
+    if (set("NVCA_PART_STATS")) { const int n = num("NVCA_PART_STATS", 0); w.part_stats = n > 0 ? n : 8; }
+    w.ingest_chunk = num("NVCA_INGEST_CHUNK", 8);
+    w.deep_stage = set("NVCA_DEEP_STAGE") ? std::max(1, num("NVCA_DEEP_STAGE", 0)) : 0;
+    w.tiles = num("NVCA_TILES", 1) != 0;
+    w.plan_debug = set("NVCA_PLAN_DEBUG");
+    w.deep_lds = !set("NVCA_DEEP_LDS_OFF");
+    w.trk_order = num("NVCA_TRK_ORDER", -1);
+    w.quiet = set("NVCA_QUIET");
+    w.stamps_out = getenv("NVCA_STAMPS_OUT");
+    return w;
+}
+const Switches &switches()
+{
+    static const Switches w = read_switches();      // first use: nvca_ctx_create
+    return w;
 }
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -362,7 +425,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
 {
     Workspace &ws = *ctx->ws;
     ResultBufs &rb = ws.res[ws.cur_res];
-    static const bool grp_zero_copy = !(getenv("NVCA_GROUP_ZEROCOPY") && atoi(getenv("NVCA_GROUP_ZEROCOPY")) == 0);
+    const bool grp_zero_copy = ctx->sw.group_zero_copy;
     const int batch = job.n, total = std::max(job.total, job.r0 + job.n);
     const size_t hits_stride = (size_t)ctx->hit_cap + 1;                 // u64 words per result slot
     const unsigned cap = (unsigned)ctx->hit_cap * (unsigned)batch;
@@ -380,8 +443,8 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(job.d_hits, 0, sizeof(unsigned long long), ctx->cs()));
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.ln().deep.p, 0, sizeof(unsigned long long), ctx->cs()));
     }
-    static const bool skip_cascade = getenv("NVCA_SKIP_CASCADE") != nullptr;     // timing experiments on the pre-processing kernels only
-    static const bool host_group = getenv("NVCA_HOST_GROUP") != nullptr;         // keep cv::groupRectangles on the host (A/B testing)
+    const bool skip_cascade = ctx->sw.skip_cascade;
+    const bool host_group = ctx->sw.host_group;
     const bool dev_group = group_thr && want_group && dp.device_group_ok && !host_group && !dp.tasks.empty() && !skip_cascade;
     job.dev_group = dev_group;
     const size_t rec = 2 + 4 * kGroupOutCap;
@@ -419,7 +482,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
         a.nscales = (int)dp.scales.size();
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
-        { const char *bme = getenv("NVCA_BAND_MAP"); const int bm = bme ? atoi(bme) : 0; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
+        { const int bm = ctx->sw.band_map; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>(); a.deep_lds = dp.deep_lds;
         a.tilted = dp.needs_tilted ? ws.ln().tilted.as<int>() : nullptr;
         a.galpha = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_galpha; a.gcls_first = dp.tabs.empty() ? nullptr : dp.tabs[0]->d_gcls_first;
@@ -435,12 +498,11 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         {   // diagnostic build: the stamps of the last band launch are written to $NVCA_STAMPS_OUT when the context synchronises
             static DevBuf dbgbuf;
             a.dbg = nullptr;
-            if (getenv("NVCA_STAMPS_OUT") && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->cs()); ctx->stamps = a.dbg; }
+            if (switches().stamps_out && !dbgbuf.ensure(64 * 16 * 64 * 8)) { a.dbg = dbgbuf.as<unsigned long long>(); (void)hipMemsetAsync(a.dbg, 0, 64 * 16 * 64 * 8, ctx->cs()); ctx->stamps = a.dbg; }
         }
 #endif
         // one workgroup per band of window rows (k_band) when the batch offers enough bands to fill the 512 workgroup slots (>= 540 bands); otherwise stage-0 pre-pass + one workgroup per tile.  NVCA_BAND=0/1 forces the choice.
-        const char *band_e = getenv("NVCA_BAND");
-        const int band_env = band_e ? atoi(band_e) : -1;
+        const int band_env = ctx->sw.band;
         const bool use_band = !dp.bands.empty() && (band_env >= 0 ? band_env != 0 : (long long)dp.bands.size() * batch >= 540);     // measured crossover at 1080p (68 bands per frame): 4 frames -21 %, 8 frames +5 %, 12 frames +24 %
         auto launch = [&](int which) {
             const int e = launch_cascade_sc(ctx->cs(), a, batch, which, ctx->lds_grant);
@@ -460,7 +522,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         // buffer (plain stores, visible to the host once the stream has drained) -- no copy operation behind the last kernel
         if (dev_group) { TimedLaunch t(ctx, NVCA_K_GROUP); launch_group(ctx->cs(), a, rb.gthr.as<int>() + job.r0, grp_zero_copy ? job.h_grp : job.d_grp, kGroupOutCap, batch); }
     }
-    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    NVCA_LAUNCH_CHECK(ctx);
     if (dev_group && grp_zero_copy) {
         // nothing to copy: k_group wrote the host buffer
     } else if (dev_group) {      // the device hands back final boxes; the raw list is only fetched for frames it declined
@@ -476,7 +538,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
 static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job, std::vector<std::vector<nvca_rect>> &raw,
                            std::vector<char> *grouped, std::vector<std::vector<int>> *scale_of = nullptr)
 {
-    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    const bool hostprof = ctx->sw.host_profile;
     const int batch = job.n;
     raw.assign(batch, {});
     if (scale_of) scale_of->assign(batch, {});
@@ -517,7 +579,14 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
     }
     std::sort(hh + 1, hh + 1 + total);
     for (unsigned long long i = 0; i < total; i++) {
-        const int slot = (int)(hh[1 + i] >> 32);
+        // a candidate word comes from the device: it indexes host tables only after it has been checked against them (a kernel that
+        // did not run, or ran on stale tables, must end as an error code, never as a wild host access)
+        const unsigned long long slot_u = hh[1 + i] >> 32;
+        if (slot_u >= (unsigned long long)batch || !dp.hit_valid((unsigned)hh[1 + i])) {
+            ctx->set_error("internal: candidate list holds an entry outside the scan (device result rejected)");
+            return NVCA_ERR_INTERNAL;
+        }
+        const int slot = (int)slot_u;
         if (!job.dev_group || !(*grouped)[slot]) {
             raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
             if (scale_of) (*scale_of)[slot].push_back((int)((unsigned)hh[1 + i] >> 26));
@@ -557,6 +626,7 @@ static int stage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, si
 static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
                       size_t height, int mem)
 {
+    NVCA_LAUNCH_CHECK(ctx);
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                          ctx->cs()));
@@ -569,7 +639,7 @@ static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, 
 // end of a primitive that wrote device memory directly
 static int finish_device_op(nvca_ctx *ctx)
 {
-    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    NVCA_LAUNCH_CHECK(ctx);
     if (ctx->defer_device_sync > 0) return NVCA_OK;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer(ctx);
@@ -657,16 +727,17 @@ extern "C" {
 const char *nvca_version(void) { return "nubovca-hip 0.1 (gfx950)"; }
 
 int nvca_device_count(int *n)
-{
+try {
     if (!n) return NVCA_ERR_ARG;
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) { *n = 0; return NVCA_ERR_NO_DEVICE; }
     *n = c;
     return NVCA_OK;
 }
+NVCA_API_CATCH(nullptr)
 
 int nvca_ctx_create(int device_id, nvca_ctx **out)
-{
+try {
     if (!out) return NVCA_ERR_ARG;
     *out = nullptr;
     int n = 0;
@@ -675,6 +746,7 @@ int nvca_ctx_create(int device_id, nvca_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) return NVCA_ERR_HIP;
     nvca_ctx *ctx = new (std::nothrow) nvca_ctx();
     if (!ctx) return NVCA_ERR_NOMEM;
+    ctx->sw = switches();                                   // the environment is read here, once per process
     ctx->device = device_id;
     ctx->ws.reset(new Workspace());
     ctx->ws->cur_lane = &ctx->cur_lane;
@@ -686,55 +758,96 @@ int nvca_ctx_create(int device_id, nvca_ctx **out)
     *out = ctx;
     return NVCA_OK;
 }
+NVCA_API_CATCH(nullptr)
 
 void nvca_ctx_destroy(nvca_ctx *ctx)
-{
+try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     delete ctx;
 }
+NVCA_API_CATCH_VOID
 
 const char *nvca_last_error(const nvca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap)
-{
+try {
     if (!ctx || cap < 1 || cap > (1 << 22)) return NVCA_ERR_ARG;
     ctx->hit_cap = cap;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
+// One of the A/B switches of DESIGN.md's appendix, for this context (the environment variable of the same name, without
+// the NVCA_ prefix and in lower case, sets the process default).  Switches that shape plans drop the context's cached plans.
+int nvca_ctx_set_option(nvca_ctx *ctx, const char *name, int value)
+try {
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!name) return NVCA_ERR_ARG;
+    const std::string n(name);
+    Switches &w = ctx->sw;
+    bool replan = false;
+    if (n == "band") w.band = value;
+    else if (n == "band_map") w.band_map = value;
+    else if (n == "group_zerocopy") w.group_zero_copy = value != 0;
+    else if (n == "host_group") w.host_group = value != 0;
+    else if (n == "skip_cascade") w.skip_cascade = value != 0;
+    else if (n == "host_profile") w.host_profile = value != 0;
+    else if (n == "sparse_ingest") w.sparse_ingest = value != 0;
+    else if (n == "ingest_chunk") w.ingest_chunk = value;
+    else if (n == "part_stats") w.part_stats = value;
+    else if (n == "trk_order") w.trk_order = value;
+    else if (n == "quiet") w.quiet = value != 0;
+    else if (n == "plan_debug") w.plan_debug = value != 0;
+    else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
+    else if (n == "tiles") { w.tiles = value != 0; replan = true; }
+    else if (n == "deep_stage") { w.deep_stage = value > 0 ? value : 0; replan = true; }
+    else if (n == "deep_lds") { w.deep_lds = value != 0; replan = true; }
+    else { ctx->set_error("unknown option: " + n); return NVCA_ERR_ARG; }
+    if (replan) {
+        for (auto &kv : ctx->plans) if (kv.second->inflight) { ctx->set_error("a batch is in flight: collect it before changing a plan option"); return NVCA_ERR_ARG; }
+        (void)hipSetDevice(ctx->device);
+        NVCA_HIP_CHECK(ctx, hipDeviceSynchronize());
+        ctx->plans.clear();
+    }
+    return NVCA_OK;
+}
+NVCA_API_CATCH(ctx)
 int nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy)
-{
+try {
     if (!ctx || (policy != NVCA_SUM_F32PAIR && policy != NVCA_SUM_F64)) return NVCA_ERR_ARG;
     ctx->policy = policy;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 int nvca_ctx_synchronize(nvca_ctx *ctx)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
 #ifdef NVCA_STAMPS
-    if (ctx->stamps && getenv("NVCA_STAMPS_OUT")) {
+    if (ctx->stamps && switches().stamps_out) {
         std::vector<unsigned long long> h(64 * 16 * 64);
         (void)hipMemcpy(h.data(), ctx->stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE *f = fopen(getenv("NVCA_STAMPS_OUT"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        if (FILE *f = fopen(switches().stamps_out, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
 #endif
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 void *nvca_ctx_stream(nvca_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int nvca_host_register(nvca_ctx *ctx, void *ptr, size_t bytes)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ptr || !bytes) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     NVCA_HIP_CHECK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 int nvca_host_unregister(nvca_ctx *ctx, void *ptr)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ptr) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
@@ -742,9 +855,10 @@ int nvca_host_unregister(nvca_ctx *ctx, void *ptr)
     NVCA_HIP_CHECK(ctx, hipHostUnregister(ptr));
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     (void)hipStreamSynchronize(ctx->cs());
@@ -754,8 +868,9 @@ int nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on)
     for (int k = 0; k < NVCA_K_COUNT; k++) { ctx->timer.total_ms[k] = 0; ctx->timer.launches[k] = 0; }
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
@@ -767,6 +882,7 @@ int nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches)
     }
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 const char *nvca_kernel_name(int k)
 {
     static const char *names[NVCA_K_COUNT] = {"gray_resize_hist", "equalize_lut", "integral_colsum", "integral_bandscan",
@@ -779,7 +895,7 @@ const char *nvca_kernel_name(int k)
 // cascade
 // =========================================================================
 int nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_cascade **out)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || !xml || len <= 0 || !out) return NVCA_ERR_ARG;
     *out = nullptr;
@@ -792,9 +908,43 @@ int nvca_cascade_load_mem(nvca_ctx *ctx, const char *xml, int64_t len, nvca_casc
     *out = c.release();
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
+
+// the loader alone, on the host: no device, no context (a deployment can check its cascade files on a box without a GPU; the
+// CPU test-suite and the sanitizer build run the parser through the ABI this way)
+int nvca_cascade_validate_mem(const char *xml, int64_t len, int *win_w, int *win_h, int *n_stages, int *n_weak, char *err, int err_cap)
+try {
+    if (err && err_cap > 0) err[0] = 0;
+    if (!xml || len <= 0) return NVCA_ERR_ARG;
+    Cascade c;
+    std::string msg;
+    const int rc = parse_cascade_xml(xml, (size_t)len, c, msg);
+    if (rc) { if (err && err_cap > 0) snprintf(err, (size_t)err_cap, "%s", msg.c_str()); return rc; }
+    if (win_w) *win_w = c.ow;
+    if (win_h) *win_h = c.oh;
+    if (n_stages) *n_stages = (int)c.stages.size();
+    if (n_weak) *n_weak = (int)c.cls.size();
+    return NVCA_OK;
+}
+NVCA_API_CATCH(nullptr)
+
+// Throws on purpose, below the barrier every entry point has: what the caller gets back is the barrier's status code.
+// kind 0: std::bad_alloc, 1: std::length_error out of a container, 2: std::runtime_error, 3: a non-standard exception,
+// 4: std::out_of_range out of vector::at; anything else: NVCA_OK.  (tests/test_abi_cpu.py)
+int nvca_abi_selftest(int kind)
+try {
+    std::vector<int> v;
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) v.resize(v.max_size() + 1);
+    if (kind == 2) throw std::runtime_error("selftest");
+    if (kind == 3) throw 42;
+    if (kind == 4) return v.at(7);
+    return NVCA_OK;
+}
+NVCA_API_CATCH(nullptr)
 
 int nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out)
-{
+try {
     if (!ctx || !path || !out) return NVCA_ERR_ARG;
     std::ifstream f(path, std::ios::binary);
     if (!f) { ctx->set_error(std::string("cannot open cascade file ") + path); return NVCA_ERR_IO; }
@@ -803,9 +953,10 @@ int nvca_cascade_load_xml(nvca_ctx *ctx, const char *path, nvca_cascade **out)
     if (s.empty()) { ctx->set_error(std::string("empty cascade file ") + path); return NVCA_ERR_IO; }
     return nvca_cascade_load_mem(ctx, s.data(), (int64_t)s.size(), out);
 }
+NVCA_API_CATCH(ctx)
 
 void nvca_cascade_free(nvca_cascade *c)
-{
+try {
     if (!c) return;
     // drop cached plans that reference this cascade
     if (c->ctx) {
@@ -824,9 +975,10 @@ void nvca_cascade_free(nvca_cascade *c)
     }
     delete c;
 }
+NVCA_API_CATCH_VOID
 
 int nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stages, int *n_weak)
-{
+try {
     if (!c) return NVCA_ERR_ARG;
     if (win_w) *win_w = c->c.ow;
     if (win_h) *win_h = c->c.oh;
@@ -834,18 +986,20 @@ int nvca_cascade_info(const nvca_cascade *c, int *win_w, int *win_h, int *n_stag
     if (n_weak) *n_weak = (int)c->c.cls.size();
     return NVCA_OK;
 }
+NVCA_API_CATCH((c ? c->ctx : nullptr))
 
 int nvca_cascade_kind(const nvca_cascade *c, int *has_tilted, int *has_trees)
-{
+try {
     if (!c) return NVCA_ERR_ARG;
     if (has_tilted) *has_tilted = c->c.has_tilted ? 1 : 0;
     if (has_trees) *has_trees = c->c.stump_based ? 0 : 1;
     return NVCA_OK;
 }
+NVCA_API_CATCH((c ? c->ctx : nullptr))
 
 int nvca_cascade_dump(const nvca_cascade *c, int *rects, float *weights, float *thr, float *left_val,
                       float *right_val, int *stage_sizes, float *stage_thr)
-{
+try {
     if (!c) return NVCA_ERR_ARG;
     if (!c->c.stump_based) return NVCA_ERR_UNSUPPORTED;
     for (size_t i = 0; i < c->c.cls.size(); i++) {
@@ -862,6 +1016,7 @@ int nvca_cascade_dump(const nvca_cascade *c, int *rects, float *weights, float *
     }
     return NVCA_OK;
 }
+NVCA_API_CATCH((c ? c->ctx : nullptr))
 
 // =========================================================================
 // imgproc primitives
@@ -888,7 +1043,7 @@ static size_t staging_need(const nvca_frame *frames, const int *idx, int n)
 static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx, int n, int bpp, int r0 = 0,
                         hipStream_t st = nullptr, size_t *off_io = nullptr, const RowCopy *rows = nullptr)
 {
-    static const bool sparse_off = getenv("NVCA_SPARSE_INGEST") && atoi(getenv("NVCA_SPARSE_INGEST")) == 0;
+    const bool sparse_off = !ctx->sw.sparse_ingest;
     if (sparse_off || (rows && !rows->on)) rows = nullptr;
     Workspace &ws = *ctx->ws;
     if (!st) st = ctx->cs();
@@ -942,7 +1097,7 @@ static bool frames_aligned4(const nvca_frame *frames, const int *idx, int n)
 }
 
 int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int channels, int mem, void *dst, int dst_stride)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (channels != 3 && channels != 4) return NVCA_ERR_ARG;
     int rc = check_img(ctx, src, w, h, stride, channels, mem);
@@ -969,6 +1124,7 @@ int nvca_bgr2gray(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
                   ctx->ws->ln().gray.as<uint8_t>(), nullptr, 1, frames_aligned4(&f, nullptr, 1)); }
     return unstage_2d(ctx, dst, dst_stride, ctx->ws->ln().gray.p, g.gpitch, w, h, mem);
 }
+NVCA_API_CATCH(ctx)
 
 // resize coefficient tables for (source size -> destination size), cached with the other plans
 static int get_resize_plan(nvca_ctx *ctx, int sw, int sh, int dw, int dh, GeomPlan **out)
@@ -986,7 +1142,7 @@ static int get_resize_plan(nvca_ctx *ctx, int sw, int sh, int dw, int dh, GeomPl
 
 int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstride, int channels, int mem, void *dst,
                        int dw, int dh, int dstride)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (channels == 3) {
         int rc3 = check_img(ctx, src, sw, sh, sstride, 3, mem);
@@ -1028,9 +1184,10 @@ int nvca_resize_linear(nvca_ctx *ctx, const void *src, int sw, int sh, int sstri
                      ws.ln().aux.as<uint8_t>(), dw, dh, gd.gpitch, nullptr); }
     return unstage_2d(ctx, dst, dstride, ws.ln().aux.p, gd.gpitch, dw, dh, mem);
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
@@ -1053,9 +1210,10 @@ int nvca_equalize_hist(nvca_ctx *ctx, const void *src, int w, int h, int stride,
     launch_apply_lut(ctx->cs(), ws.ln().gray.as<uint8_t>(), w, h, g.gpitch, ws.ln().lut.as<uint8_t>(), ws.ln().aux.as<uint8_t>(), g.gpitch);
     return unstage_2d(ctx, dst, dst_stride, ws.ln().aux.p, g.gpitch, w, h, mem);
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const nvca_shape *shapes, int n)
-{
+try {
     // host frames need no device (and no context): plain loops over the mapped buffer
     const bool host = frame && frame->mem == NVCA_MEM_HOST;
     if (!frame || (!ctx && !host) || (channels != 3 && channels != 4) || n < 0 || (n > 0 && !shapes) || n > 1024) return NVCA_ERR_ARG;
@@ -1083,9 +1241,10 @@ int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const
     launch_draw_shapes(ctx->cs(), (uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, (const nvca_shape *)d_shapes, n, bx0, by0, bx1, by1);
     return finish_device_op(ctx);
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, void *dst, int dst_stride)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !dst || dst_stride < w) return NVCA_ERR_ARG;
@@ -1102,9 +1261,10 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src, int w, int h, int strid
     launch_flip_h(ctx->cs(), ws.ln().gray.as<uint8_t>(), w, h, g.gpitch, ws.ln().aux.as<uint8_t>(), g.gpitch);
     return unstage_2d(ctx, dst, dst_stride, ws.ln().aux.p, g.gpitch, w, h, mem);
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *sum, double *sqsum)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !sum) return NVCA_ERR_ARG;
@@ -1128,9 +1288,10 @@ int nvca_integral(nvca_ctx *ctx, const void *src, int w, int h, int stride, int 
     }
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_integral_tilted(nvca_ctx *ctx, const void *src, int w, int h, int stride, int mem, int32_t *tilted)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     int rc = check_img(ctx, src, w, h, stride, 1, mem);
     if (rc || !tilted) return NVCA_ERR_ARG;
@@ -1143,6 +1304,7 @@ int nvca_integral_tilted(nvca_ctx *ctx, const void *src, int w, int h, int strid
     if ((rc = run_tilted(ctx, g, nullptr, 1))) return rc;
     return unstage_2d(ctx, tilted, (size_t)(w + 1) * 4, ws.ln().tilted.p, (size_t)g.spitch * 4, (size_t)(w + 1) * 4, h + 1, NVCA_MEM_HOST);
 }
+NVCA_API_CATCH(ctx)
 
 // =========================================================================
 // detectMultiScale
@@ -1245,7 +1407,7 @@ static int si_plan(nvca_ctx *ctx, const DetectJob &j, GeomPlan **out)
             if ((rc = np->det.build_custom(ctx, c, std::move(specs), false, err))) { ctx->set_error(err); return rc; }
             if ((rc = np->det.upload(ctx))) return rc;
             std::vector<PyrLevelDev> dl(np->lv.size());
-            np->pyr_ok = getenv("NVCA_PYR_OFF") == nullptr;
+            np->pyr_ok = !ctx->sw.pyr_off;
             for (size_t li = 0; li < np->lv.size(); li++) {
                 const PyrLevel &L = np->lv[li]; GeomPlan *t = np->level_tabs[li].get();
                 PyrLevelDev &d = dl[li]; memset(&d, 0, sizeof(d));
@@ -1543,7 +1705,11 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
         j.phase = 3;
     } else {
         if (j.dp) {
-            for (size_t k = 0; k < raw[0].size(); k++) j.hits[j.ladder_of[sc[0][k]]].push_back(raw[0][k]);
+            for (size_t k = 0; k < raw[0].size(); k++) {
+                const size_t si = (size_t)sc[0][k];
+                if (si >= j.ladder_of.size() || (size_t)j.ladder_of[si] >= j.hits.size()) { ctx->set_error("internal: candidate of an unknown ladder step"); j.phase = 3; return NVCA_ERR_INTERNAL; }
+                j.hits[j.ladder_of[si]].push_back(raw[0][k]);
+            }
             for (int li : j.ladder_of) j.have[li] = 1;
         }
         j.dp = nullptr;
@@ -1602,7 +1768,7 @@ int part_gray_eq(nvca_ctx *ctx, const void *const *bgr, int n, int w, int h, int
     { TimedLaunch t(ctx, NVCA_K_GRAY);
       launch_gray(ctx->cs(), (const uint8_t *const *)d_ptrs, g, 0, nullptr, nullptr, nullptr, nullptr, w, gray, hist, n, aligned); }
     { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), hist, w * h, luts, n, 1); }
-    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    NVCA_LAUNCH_CHECK(ctx);
     return NVCA_OK;
 }
 int part_image_batch(nvca_ctx *ctx, const PartImageBatch &b, const uint8_t *luts)
@@ -1630,13 +1796,13 @@ int part_image_batch(nvca_ctx *ctx, const PartImageBatch &b, const uint8_t *luts
         { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), hist, b.dw * b.dh, scratch, n, 1); }
         launch_apply_lut(ctx->cs(), b.dst, b.dw, b.dh, b.dw, scratch, b.dst, b.dw, n, b.slot, b.slot);
     }
-    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    NVCA_LAUNCH_CHECK(ctx);
     return NVCA_OK;
 }
 int part_flip_batch(nvca_ctx *ctx, const uint8_t *src, uint8_t *dst, int w, int h, int n, size_t slot)
 {
     launch_flip_h(ctx->cs(), src, w, h, w, dst, w, n, slot, slot);
-    NVCA_HIP_CHECK(ctx, hipGetLastError());
+    NVCA_LAUNCH_CHECK(ctx);
     return NVCA_OK;
 }
 int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
@@ -1652,11 +1818,11 @@ int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
 // run a set of detectMultiScale calls to completion: one wait per round for all of them.  lanes (optional, [n]): the lane
 // each job runs on -- jobs of one lane execute in order, lanes side by side
 double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS (diagnostic, one context at a time): where run_detect_jobs spends the host's time
-static const bool g_job_stats = getenv("NVCA_PART_STATS") != nullptr;
 static inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
 {
     const int lane0 = ctx->cur_lane;
+    const bool g_job_stats = ctx->sw.part_stats > 0;
     struct Restore { nvca_ctx *c; int l; ~Restore() { c->cur_lane = l; } } restore{ctx, lane0};
     for (;;) {
         int total = 0;
@@ -1682,7 +1848,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         ctx->cur_lane = lane0;
         const double t2 = g_job_stats ? mono_s() : 0;
         if (g_job_stats) g_jobs_wait_s += t2 - t1;
-        struct Adv { double t; ~Adv() { if (g_job_stats) g_jobs_advance_s += mono_s() - t; } } adv{t2};
+        struct Adv { double t; bool on; ~Adv() { if (on) g_jobs_advance_s += mono_s() - t; } } adv{t2, g_job_stats};
         drain_timer(ctx);
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
@@ -1763,7 +1929,7 @@ static int detect_gray(nvca_ctx *ctx, const nvca_cascade *casc, const void *gray
 int nvca_detect_multiscale(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray, int w, int h, int stride,
                            int mem, double scale_factor, int min_neighbors, int flags, int min_w, int min_h,
                            int max_w, int max_h, nvca_rect *out, int cap, int *n_out)
-{
+try {
     if (!n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     std::vector<nvca_rect> r;
     int rc = detect_gray(ctx, cascade, gray, w, h, stride, mem, scale_factor, min_neighbors, flags, min_w, min_h, max_w,
@@ -1773,11 +1939,12 @@ int nvca_detect_multiscale(nvca_ctx *ctx, const nvca_cascade *cascade, const voi
     for (int i = 0; i < std::min<int>(cap, (int)r.size()); i++) out[i] = r[i];
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_detect_raw(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray, int w, int h, int stride, int mem,
                     double scale_factor, int flags, int min_w, int min_h, int max_w, int max_h, nvca_rect *out,
                     int cap, int *n_out)
-{
+try {
     if (!n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     if (flags & NVCA_HAAR_FIND_BIGGEST_OBJECT) return NVCA_ERR_ARG;
     std::vector<nvca_rect> r;
@@ -1787,9 +1954,10 @@ int nvca_detect_raw(nvca_ctx *ctx, const nvca_cascade *cascade, const void *gray
     for (int i = 0; i < std::min<int>(cap, (int)r.size()); i++) out[i] = r[i];
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_group_rectangles(nvca_ctx *ctx, nvca_rect *rects, int n, int group_threshold, double eps, int *n_out)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && !rects) || !n_out) return NVCA_ERR_ARG;
     std::vector<nvca_rect> v(rects, rects + n);
@@ -1798,6 +1966,7 @@ int nvca_group_rectangles(nvca_ctx *ctx, nvca_rect *rects, int n, int group_thre
     *n_out = (int)v.size();
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 } // extern "C"
 
@@ -1848,14 +2017,15 @@ bool face_gate(nvca_face_stream *s)
 extern "C" {
 
 void nvca_face_params_default(nvca_face_params *p)
-{
+try {
     if (!p) return;
     p->width_to_process = 160; p->process_x_every_4 = 4; p->scale_factor_pct = 25; p->track_threshold = 40;
     p->euclidean_threshold = 8; p->area_threshold = 500; p->min_neighbors = 3; p->detect_event = 0;
 }
+NVCA_API_CATCH_VOID
 
 int nvca_face_stream_create(nvca_ctx *ctx, const nvca_cascade *cascade, const nvca_face_params *params, nvca_face_stream **out)
-{
+try {
     if (!ctx || !cascade || !out) return NVCA_ERR_ARG;
     nvca_face_stream *s = new (std::nothrow) nvca_face_stream();
     if (!s) return NVCA_ERR_NOMEM;
@@ -1864,19 +2034,22 @@ int nvca_face_stream_create(nvca_ctx *ctx, const nvca_cascade *cascade, const nv
     *out = s;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 void nvca_face_stream_destroy(nvca_face_stream *s) { delete s; }
 int nvca_face_stream_set_params(nvca_face_stream *s, const nvca_face_params *params)
-{
+try {
     if (!s || !params) return NVCA_ERR_ARG;
     s->p = *params;
     return NVCA_OK;
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 int nvca_face_stream_motion_event(nvca_face_stream *s)
-{
+try {
     if (!s) return NVCA_ERR_ARG;
     s->pending_events++;
     return NVCA_OK;
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 
 } // extern "C"
 
@@ -1975,7 +2148,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         // Every chunk reuses planes [0, chunk); only its candidate list / box table are its own (CascadeJob).
         bool any_host = false;
         for (int b = 0; b < batch; b++) any_host = any_host || frames[idx[b]].mem == NVCA_MEM_HOST;
-        static const int chunk_env = getenv("NVCA_INGEST_CHUNK") ? atoi(getenv("NVCA_INGEST_CHUNK")) : 8;
+        const int chunk_env = ctx->sw.ingest_chunk;
         const int chunk = (any_host && chunk_env > 0 && batch >= 2 * chunk_env) ? chunk_env : batch;
         const bool piped = chunk < batch;
         if ((rc = ensure_ws(ctx, gp->g, chunk))) return rc;
@@ -2096,7 +2269,7 @@ extern "C" {
 
 int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames,
                             nvca_rect *out, int *ids, int cap, int *n_out)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (n < 0 || (n > 0 && (!streams || !frames || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     // a stream's frames are consumed in order: the synchronous call may not overtake a submitted batch of the same stream
@@ -2110,12 +2283,13 @@ int nvca_face_batch_process(nvca_ctx *ctx, int n, nvca_face_stream *const *strea
     if (rc) { (void)hipStreamSynchronize(ctx->cs()); face_release(tk); return rc; }
     return face_collect(ctx, 0, tk, out, ids, cap, n_out);
 }
+NVCA_API_CATCH(ctx)
 
 // Pipelined form of nvca_face_batch_process for a serving loop: submit() queues a batch and returns, collect() waits for
 // the oldest submitted batch and delivers its boxes.  Up to two batches may be in flight, so the host-side work between
 // batches (result unpacking, the caller's own bookkeeping) overlaps the GPU.  Batches are collected in submission order.
 int nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, const nvca_frame *frames, int *ticket)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ticket) return NVCA_ERR_ARG;
     int k = 0;
@@ -2128,8 +2302,9 @@ int nvca_face_batch_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *stream
     *ticket = k;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 int nvca_face_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out, int *ids, int cap, int *n_out)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (ticket < 1 || ticket > 2 || !ctx->face_tickets[ticket] || !ctx->face_tickets[ticket]->pending) { ctx->set_error("no such batch in flight"); return NVCA_ERR_ARG; }
     FaceTicket &tk = *ctx->face_tickets[ticket];
@@ -2140,21 +2315,24 @@ int nvca_face_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out, int *ids,
     if (cap < 0 || (cap > 0 && !out) || (tk.n > 0 && !n_out)) return NVCA_ERR_ARG;
     return face_collect(ctx, ticket, tk, out, ids, cap, n_out);
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_face_stream_process(nvca_face_stream *s, const nvca_frame *frame, nvca_rect *out, int *ids, int cap, int *n_out)
-{
+try {
     if (!s || !frame) return NVCA_ERR_ARG;
     nvca_face_stream *arr[1] = {s};
     return nvca_face_batch_process(s->ctx, 1, arr, frame, out, ids, cap, n_out);
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 
 // =========================================================================
 // NuboTracker stream (device path lands with the tracker kernels)
 // =========================================================================
 void nvca_tracker_params_default(nvca_tracker_params *p)
-{
+try {
     if (!p) return;
     p->threshold = 20; p->min_area = 50; p->max_area = 30000; p->distance = 35; p->mhi_duration = 0.2; p->seg_thresh = 32;
 }
+NVCA_API_CATCH_VOID
 
 } // extern "C"

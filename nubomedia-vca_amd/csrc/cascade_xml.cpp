@@ -120,8 +120,8 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
 
     const XNode *size = cn->child("size"), *stages = cn->child("stages");
     if (!size || !stages) { err = "missing <size> or <stages>"; return NVCA_ERR_PARSE; }
-    if (sscanf(size->text.c_str(), "%d %d", &out.ow, &out.oh) != 2 || out.ow <= 2 || out.oh <= 2) {
-        err = "bad <size>"; return NVCA_ERR_PARSE;
+    if (sscanf(size->text.c_str(), "%d %d", &out.ow, &out.oh) != 2 || out.ow <= 2 || out.oh <= 2 || out.ow > 1024 || out.oh > 1024) {
+        err = "bad <size>"; return NVCA_ERR_PARSE;             // stock cascades are 18..45 pixels a side; the bound keeps every later sum in range
     }
     out.stages.clear(); out.cls.clear(); out.nodes.clear(); out.alpha.clear();
     out.stump_based = true; out.has_tilted = false;
@@ -155,7 +155,7 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
                     }
                     for (int q = 0; q < 4; q++) hn.rect[k][q] = r[q];
                     hn.weight[k] = (float)wt;
-                    if (r[0] < 0 || r[1] < 0 || r[2] <= 0 || r[3] <= 0) { err = "rect outside the window"; return NVCA_ERR_PARSE; }
+                    if (r[0] < 0 || r[1] < 0 || r[2] <= 0 || r[3] <= 0 || r[0] > out.ow || r[2] > out.ow || r[1] > out.oh || r[3] > out.oh) { err = "rect outside the window"; return NVCA_ERR_PARSE; }
                 }
                 if (!to_int(tilted->text, hn.tilted)) { err = "bad <tilted>"; return NVCA_ERR_PARSE; }
                 hn.tilted = hn.tilted != 0;
@@ -176,7 +176,10 @@ int parse_cascade_xml(const char *text, size_t len, Cascade &out, std::string &e
                     const XNode *cn2 = nd->child(side == 0 ? "left_node" : "right_node");
                     int &dst = side == 0 ? hn.left : hn.right;
                     if (cn2) {
-                        if (!to_int(cn2->text, dst) || dst <= 0 || dst >= hc.nnodes) { err = "bad child node index"; return NVCA_ERR_PARSE; }
+                        // a child comes after its parent (haartraining writes trees in that order): every walk from the root ends,
+                        // on the device too -- an index at or before the node itself would make the evaluator loop for ever
+                        const int self = (int)out.nodes.size() - hc.first_node;
+                        if (!to_int(cn2->text, dst) || dst <= self || dst >= hc.nnodes) { err = "bad child node index"; return NVCA_ERR_PARSE; }
                     } else {
                         const XNode *cv = nd->child(side == 0 ? "left_val" : "right_val");
                         if (!cv || !to_double(cv->text, d)) { err = "node without left/right value"; return NVCA_ERR_PARSE; }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <algorithm>
+#include <climits>
 
 namespace nvca {
 
@@ -191,5 +192,87 @@ void draw_shapes_host(uint8_t *data, int w, int h, int stride, int channels, con
                 }
     }
 }
+
+// ------------------------------------------------------------ part detectors: merging heuristics
+// (moved here from parts.cpp: pure functions of box lists, O(#faces); std::vector idioms of the reference that rely on
+// libstdc++ behaviour -- erase through a reverse iterator, erase(end()-i) inside a counting loop -- are written out as the
+// index operations they perform)
+typedef std::vector<nvca_rect> RectV;
+static inline int cv_round_sat(double v)
+{
+    if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+    return (int)lrint(v);
+}
+void merge_consecutive_nm(RectV &cn, const RectV &old, const nvca_rect &face, int scale, int dis, RectV &res)
+{   // __merge_noses_consecutives_frames NOSE/kmsnosedetect.cpp:745-790 (mouth :750-796 identical but for the distance)
+    res.clear();
+    for (const nvca_rect &o : old) {
+        const int ocx = o.x + o.w / 2, ocy = o.y + o.h / 2;
+        for (size_t j = 0; j < cn.size(); j++) {
+            const int ncx = (cn[j].x + face.x) * scale + ((cn[j].w * scale) / 2);
+            const int ncy = (cn[j].y + face.y) * scale + ((cn[j].h * scale) / 2);
+            const double h2 = std::sqrt(std::pow((double)(ncx - ocx), 2) + std::pow((double)(ncy - ocy), 2));
+            if (h2 < dis) { res.push_back(o); cn.erase(cn.begin() + j); break; }
+        }
+    }
+    for (nvca_rect r : cn) {
+        r.x = cv_round_sat((face.x + r.x) * scale); r.y = cv_round_sat((face.y + r.y) * scale);
+        r.w = (r.w - 1) * scale; r.h = (r.h - 1) * scale;
+        res.push_back(r);
+    }
+}
+
+bool contain_bb(int px, int py, const nvca_rect &r) { return (py >= r.y && py <= r.y + r.h) && (px >= r.x && px <= r.x + r.w); }
+
+void merge_eyes_current(const nvca_rect &face_bb, const RectV &eye_r, RectV &eyes, int scale, bool eye_left)
+{   // __merge_eyes_current_frame EYE/kmseyedetect.cpp:778-862
+    for (int i = (int)eyes.size() - 1; i > 0; i--) {
+        int cx = eyes[i].x + eyes[i].w / 2, cy = eyes[i].y + eyes[i].h / 2;
+        if (contain_bb(cx, cy, eyes[i - 1]) && area(eyes[i]) < area(eyes[i - 1])) eyes.erase(eyes.end() - i - 1);
+        else {
+            cx = eyes[i - 1].x + eyes[i - 1].w / 2; cy = eyes[i - 1].y + eyes[i - 1].h / 2;
+            if (contain_bb(cx, cy, eyes[i]) && area(eyes[i - 1]) < area(eyes[i])) eyes.erase(eyes.end() - i);
+        }
+    }
+    for (int i = (int)eyes.size() - 1; i >= 0; i--) {
+        const int y_aux = face_bb.y * scale + face_bb.h * scale * 60 / 100;
+        if (face_bb.y * scale + eyes[i].y < y_aux) {
+            if (i == 0 && eyes.size() == 1) { if (!eye_r.empty() && eye_left) eyes[i].y = eye_r[0].y; }
+            else eyes.erase(eyes.begin() + i);
+        }
+    }
+    if (eyes.size() > 1) {
+        const int middle_y = face_bb.x * scale + face_bb.h * scale / 2;      // sic (x / y swapped in the reference)
+        const int middle_x = face_bb.y * scale + face_bb.w * scale / 2;
+        for (int i = (int)eyes.size() - 1; i > 0; i--) {
+            const int cy = eyes[i].y + eyes[i].h / 2, cx = eyes[i].x + eyes[i].w / 2;
+            const int cy2 = eyes[i - 1].y + eyes[i - 1].h / 2, cx2 = eyes[i - 1].x + eyes[i - 1].w / 2;
+            const float s1 = (float)std::sqrt(std::pow((double)(middle_x - cx), 2) + std::pow((double)(middle_y - cy), 2));
+            const float s2 = (float)std::sqrt(std::pow((double)(middle_x - cx2), 2) + std::pow((double)(middle_y - cy2), 2));
+            if (s1 < s2) eyes.erase(eyes.end() - i - 1); else eyes.erase(eyes.end() - i);
+        }
+    }
+    if (eye_left && !eye_r.empty() && !eyes.empty()) eyes[0].y = eye_r[0].y;
+}
+
+void merge_eyes_consecutive(RectV &ce, const RectV &old, RectV &res)
+{   // __merge_eyes_consecutives_frames EYE/kmseyedetect.cpp:864-900, DEFAULT_EUCLIDEAN_DIS 7
+    res.clear();
+    for (const nvca_rect &o : old) {
+        const int ocx = o.x + o.w / 2, ocy = o.y + o.h / 2;
+        for (size_t j = 0; j < ce.size(); j++) {
+            const int ncx = ce[j].x + ce[j].w / 2, ncy = ce[j].y + ce[j].h / 2;
+            const double h2 = std::sqrt(std::pow((double)(ncx - ocx), 2) + std::pow((double)(ncy - ocy), 2));
+            if (h2 < 7) { res.push_back(o); ce.erase(ce.begin() + j); break; }
+        }
+    }
+    res.insert(res.end(), ce.begin(), ce.end());
+}
+
+void to_global(RectV &v, const nvca_rect &face, int scale)
+{   // transform_2_global_coordinates EYE/kmseyedetect.cpp:902-913
+    for (nvca_rect &r : v) { r.x = (face.x + r.x) * scale; r.y = (face.y + r.y) * scale; r.w = (r.w - 1) * scale; r.h = (r.h - 1) * scale; }
+}
+
 
 } // namespace nvca

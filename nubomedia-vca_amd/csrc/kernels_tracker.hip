@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_ccl_collect(const TrkSlot *__restrict__
 }
 
 void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
-                    int *out, int cap, bool run_ccl, uint8_t *flags)
+                    int *out, int cap, bool run_ccl, uint8_t *flags, int order)
 {
     const TrkSlot *slots = (const TrkSlot *)d_slots;
     dim3 gp(((w + 3) / 4 + 255) / 256, h, batch);
@@ -284,7 +284,7 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     NVCA_LAUNCH(k_ccl_init, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
     NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
     NVCA_LAUNCH(k_ccl_flatten, g2, dim3(256), 0, st, labels, (CompAcc *)acc, w, h, (const uint8_t *)flags);
-    static const int order = getenv("NVCA_TRK_ORDER") ? atoi(getenv("NVCA_TRK_ORDER")) : -1;    // -1: decided per frame on the device
+    // order (Switches::trk_order): -1: decided per frame on the device
     NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, order);
     NVCA_LAUNCH(k_ccl_collect, g2, dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, w, h, (const uint8_t *)flags, out, cap);
 }

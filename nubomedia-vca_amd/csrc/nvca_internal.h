@@ -151,6 +151,32 @@ struct ResizeTab {
 void build_resize_tab(int sw, int sh, int dw, int dh, ResizeTab &t);
 
 // --------------------------------------------------------------------------
+// Environment switches: A/B and diagnostic knobs, all off-path by default and none of them changes a
+// result.  The environment is read ONCE per process -- when the first context is created (nvca_ctx_create) -- never on a hot
+// entry point.  A context starts from those process defaults; nvca_ctx_set_option changes one of them for that context.
+// --------------------------------------------------------------------------
+struct Switches {
+    bool group_zero_copy = true;     // NVCA_GROUP_ZEROCOPY=0: box tables through a copy instead of direct stores to the host buffer
+    bool skip_cascade = false;       // NVCA_SKIP_CASCADE: timing experiments on the pre-processing kernels only
+    bool host_group = false;         // NVCA_HOST_GROUP: cv::groupRectangles on the host
+    int  band_map = 0;               // NVCA_BAND_MAP=1/2: frame-major band walk
+    int  band = -1;                  // NVCA_BAND=0/1: force pre-pass + tile kernels / band kernel (-1: by batch size)
+    bool host_profile = false;       // NVCA_HOST_PROFILE: host-side timing prints
+    bool sparse_ingest = true;       // NVCA_SPARSE_INGEST=0: whole host frames in shrink-first mode
+    bool pyr_off = false;            // NVCA_PYR_OFF: per-level launches for SCALE_IMAGE
+    int  part_stats = 0;             // NVCA_PART_STATS[=n]: phase timers of part batches with n (default 8) or more streams; 0: off
+    int  ingest_chunk = 8;           // NVCA_INGEST_CHUNK=n: chunk size of host-frame batches, 0 = no chunking
+    int  deep_stage = 0;             // NVCA_DEEP_STAGE=s: first stage of k_deep (0: the plan's default)
+    bool tiles = true;               // NVCA_TILES=0: row-strip kernel
+    bool plan_debug = false;         // NVCA_PLAN_DEBUG: per-scale tile sizes on stderr
+    bool deep_lds = true;            // NVCA_DEEP_LDS_OFF: k_deep without LDS patches
+    int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
+    bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
+    const char *stamps_out = nullptr;   // NVCA_STAMPS_OUT (diagnostic build only)
+};
+const Switches &switches();
+
+// --------------------------------------------------------------------------
 // Context
 // --------------------------------------------------------------------------
 #define NVCA_HIP_CHECK(ctx, expr)                                                   \
@@ -238,6 +264,7 @@ struct nvca_ctx {
     std::unique_ptr<nvca::Workspace> ws;
     nvca::TrkWorkspace trk;           // tracker buffers live and die with the context
     nvca::PartWorkspace part;
+    nvca::Switches sw;                // this context's switches: the process defaults (environment), nvca_ctx_set_option overrides
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
 #ifdef NVCA_STAMPS
@@ -249,7 +276,15 @@ struct nvca_ctx {
     ~nvca_ctx();
 };
 
-#define NVCA_LOCK_OR_FAIL(ctx) if (!(ctx)) return NVCA_ERR_ARG; std::lock_guard<std::recursive_mutex> nvca_lock__((ctx)->mu)
+// Exception barrier of the ABI.  Every extern "C" entry point is a function-try-block whose handler is one of these macros:
+// nothing thrown below it (std::bad_alloc / std::length_error from the host-side containers, anything else) crosses into the
+// caller's C frames -- the call returns a status code instead, as include/nubovca.h promises.  api_catch() rethrows inside its
+// own try block to tell the cases apart (it never throws itself).
+namespace nvca { int api_catch(nvca_ctx *ctx) noexcept; hipError_t take_launch_error(const char **kernel); }
+#define NVCA_API_CATCH(ctxexpr) catch (...) { return nvca::api_catch(ctxexpr); }
+#define NVCA_API_CATCH_VOID catch (...) { (void)nvca::api_catch(nullptr); }
+
+#define NVCA_LOCK_OR_FAIL(ctx) if (!(ctx)) return NVCA_ERR_ARG; std::lock_guard<std::recursive_mutex> nvca_lock__((ctx)->mu); (void)nvca::take_launch_error(nullptr)   /* a launch failure of an earlier call on this thread has been reported by that call */
 
 namespace nvca {
 
@@ -261,11 +296,26 @@ struct TimedLaunch {
     ~TimedLaunch();
 };
 bool launch_events(hipEvent_t *a, hipEvent_t *b);      // event pair for the next launch of the current scope, if any
+// A refused launch (bad configuration, LDS grant missing) is not sticky: the status is read right behind the launch and the
+// FIRST failure of the calling thread is kept, with the kernel's name, until the entry point's next NVCA_LAUNCH_CHECK turns it
+// into NVCA_ERR_HIP -- a kernel that did not run never hands stale buffers to the host logic as if they were results.
+void note_launch(const char *kernel);                  // reads hipGetLastError()
+hipError_t take_launch_error(const char **kernel);     // returns and clears the thread's first recorded failure
 #define NVCA_LAUNCH(kern, grid, block, shmem, st, ...)                                                            \
     do {                                                                                                          \
         hipEvent_t ea__, eb__;                                                                                    \
         if (nvca::launch_events(&ea__, &eb__)) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, ea__, eb__, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                       \
+        nvca::note_launch(#kern);                                                                                 \
+    } while (0)
+#define NVCA_LAUNCH_CHECK(ctx)                                                                                    \
+    do {                                                                                                          \
+        const char *k__ = nullptr;                                                                                \
+        const hipError_t le__ = nvca::take_launch_error(&k__);                                                    \
+        if (le__ != hipSuccess) {                                                                                 \
+            (ctx)->set_error(std::string("kernel launch failed (") + (k__ ? k__ : "?") + "): " + hipGetErrorString(le__)); \
+            return NVCA_ERR_HIP;                                                                                  \
+        }                                                                                                         \
     } while (0)
 
 // --------------------------------------------------------------------------
@@ -339,7 +389,7 @@ struct CompAcc { int minx, miny, maxx, maxy, seed, pad; };   // per root, stored
 // flags: one byte per 256-pixel row segment and slot, set by the pixel pass where the motion history holds anything -- the
 // component kernels leave the other segments alone (a static scene with a few moving objects is mostly such segments)
 void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
-                    int *out, int cap, bool run_ccl, uint8_t *flags);
+                    int *out, int cap, bool run_ccl, uint8_t *flags, int order /* Switches::trk_order */);
 inline size_t tracker_count_offset(int w, int h, int batch) { return ((size_t)((w + 255) / 256) * h * batch + 63) & ~(size_t)63; }
 inline size_t tracker_flag_bytes(int w, int h, int batch) { return tracker_count_offset(w, h, batch) + sizeof(int) * (size_t)batch; }   // flag bytes, then a live-segment count per slot
 

@@ -7,6 +7,7 @@
 // std::vector idioms of the reference that rely on libstdc++ behaviour (erase through a reverse iterator,
 // erase(end()-i) inside a counting loop) are written out as the index operations they perform.
 #include "nvca_internal.h"
+#include "host_logic.h"
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -91,77 +92,7 @@ RectV roi_result(const RoiJob &r)
     return RectV(v.begin(), v.begin() + std::min<size_t>(v.size(), 256));
 }
 
-void merge_consecutive_nm(RectV &cn, const RectV &old, const nvca_rect &face, int scale, int dis, RectV &res)
-{   // __merge_noses_consecutives_frames NOSE/kmsnosedetect.cpp:745-790 (mouth :750-796 identical but for the distance)
-    res.clear();
-    for (const nvca_rect &o : old) {
-        const int ocx = o.x + o.w / 2, ocy = o.y + o.h / 2;
-        for (size_t j = 0; j < cn.size(); j++) {
-            const int ncx = (cn[j].x + face.x) * scale + ((cn[j].w * scale) / 2);
-            const int ncy = (cn[j].y + face.y) * scale + ((cn[j].h * scale) / 2);
-            const double h2 = std::sqrt(std::pow((double)(ncx - ocx), 2) + std::pow((double)(ncy - ocy), 2));
-            if (h2 < dis) { res.push_back(o); cn.erase(cn.begin() + j); break; }
-        }
-    }
-    for (nvca_rect r : cn) {
-        r.x = cv_round((face.x + r.x) * scale); r.y = cv_round((face.y + r.y) * scale);
-        r.w = (r.w - 1) * scale; r.h = (r.h - 1) * scale;
-        res.push_back(r);
-    }
-}
-
-bool contain_bb(int px, int py, const nvca_rect &r) { return (py >= r.y && py <= r.y + r.h) && (px >= r.x && px <= r.x + r.w); }
-
-void merge_eyes_current(const nvca_rect &face_bb, const RectV &eye_r, RectV &eyes, int scale, bool eye_left)
-{   // __merge_eyes_current_frame EYE/kmseyedetect.cpp:778-862
-    for (int i = (int)eyes.size() - 1; i > 0; i--) {
-        int cx = eyes[i].x + eyes[i].w / 2, cy = eyes[i].y + eyes[i].h / 2;
-        if (contain_bb(cx, cy, eyes[i - 1]) && area(eyes[i]) < area(eyes[i - 1])) eyes.erase(eyes.end() - i - 1);
-        else {
-            cx = eyes[i - 1].x + eyes[i - 1].w / 2; cy = eyes[i - 1].y + eyes[i - 1].h / 2;
-            if (contain_bb(cx, cy, eyes[i]) && area(eyes[i - 1]) < area(eyes[i])) eyes.erase(eyes.end() - i);
-        }
-    }
-    for (int i = (int)eyes.size() - 1; i >= 0; i--) {
-        const int y_aux = face_bb.y * scale + face_bb.h * scale * 60 / 100;
-        if (face_bb.y * scale + eyes[i].y < y_aux) {
-            if (i == 0 && eyes.size() == 1) { if (!eye_r.empty() && eye_left) eyes[i].y = eye_r[0].y; }
-            else eyes.erase(eyes.begin() + i);
-        }
-    }
-    if (eyes.size() > 1) {
-        const int middle_y = face_bb.x * scale + face_bb.h * scale / 2;      // sic (x / y swapped in the reference)
-        const int middle_x = face_bb.y * scale + face_bb.w * scale / 2;
-        for (int i = (int)eyes.size() - 1; i > 0; i--) {
-            const int cy = eyes[i].y + eyes[i].h / 2, cx = eyes[i].x + eyes[i].w / 2;
-            const int cy2 = eyes[i - 1].y + eyes[i - 1].h / 2, cx2 = eyes[i - 1].x + eyes[i - 1].w / 2;
-            const float s1 = (float)std::sqrt(std::pow((double)(middle_x - cx), 2) + std::pow((double)(middle_y - cy), 2));
-            const float s2 = (float)std::sqrt(std::pow((double)(middle_x - cx2), 2) + std::pow((double)(middle_y - cy2), 2));
-            if (s1 < s2) eyes.erase(eyes.end() - i - 1); else eyes.erase(eyes.end() - i);
-        }
-    }
-    if (eye_left && !eye_r.empty() && !eyes.empty()) eyes[0].y = eye_r[0].y;
-}
-
-void merge_eyes_consecutive(RectV &ce, const RectV &old, RectV &res)
-{   // __merge_eyes_consecutives_frames EYE/kmseyedetect.cpp:864-900, DEFAULT_EUCLIDEAN_DIS 7
-    res.clear();
-    for (const nvca_rect &o : old) {
-        const int ocx = o.x + o.w / 2, ocy = o.y + o.h / 2;
-        for (size_t j = 0; j < ce.size(); j++) {
-            const int ncx = ce[j].x + ce[j].w / 2, ncy = ce[j].y + ce[j].h / 2;
-            const double h2 = std::sqrt(std::pow((double)(ncx - ocx), 2) + std::pow((double)(ncy - ocy), 2));
-            if (h2 < 7) { res.push_back(o); ce.erase(ce.begin() + j); break; }
-        }
-    }
-    res.insert(res.end(), ce.begin(), ce.end());
-}
-
-void to_global(RectV &v, const nvca_rect &face, int scale)
-{   // transform_2_global_coordinates EYE/kmseyedetect.cpp:902-913
-    for (nvca_rect &r : v) { r.x = (face.x + r.x) * scale; r.y = (face.y + r.y) * scale; r.w = (r.w - 1) * scale; r.h = (r.h - 1) * scale; }
-}
-
+// the per-frame / frame-to-frame merging heuristics live in host_logic.cpp (pure host code: also built under the sanitizers)
 // kms_ear_detect_find_ears EAR/kmseardetect.cpp:644-729, in two halves around the (queued) ear searches.
 // `profile_faces`: the profile-face pass on this side's image (the image itself / its mirror), :656-659.
 // First half: the bookkeeping the reference does before it searches, and one FIND_BIGGEST job per profile face.
@@ -217,14 +148,15 @@ void find_ears_end(nvca_part_stream *s, const PartWork &w, size_t first, size_t 
 extern "C" {
 
 void nvca_part_params_default(nvca_part_params *p, int kind)
-{
+try {
     if (!p) return;
     p->kind = kind; p->width_to_process = 320; p->process_x_every_4 = 4; p->scale_factor_pct = 25; p->detect_event = 0;
 }
+NVCA_API_CATCH_VOID
 
 int nvca_part_stream_create(nvca_ctx *ctx, const nvca_part_params *params, const nvca_cascade *face, const nvca_cascade *a,
                             const nvca_cascade *b, nvca_part_stream **out)
-{
+try {
     if (!ctx || !params || !face || !a || !out || params->kind < NVCA_PART_EYE || params->kind > NVCA_PART_EAR) return NVCA_ERR_ARG;
     if ((params->kind == NVCA_PART_EYE || params->kind == NVCA_PART_EAR) && !b) return NVCA_ERR_ARG;
     nvca_part_stream *s = new (std::nothrow) nvca_part_stream();
@@ -233,33 +165,38 @@ int nvca_part_stream_create(nvca_ctx *ctx, const nvca_part_params *params, const
     *out = s;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 void nvca_part_stream_destroy(nvca_part_stream *s)
-{
+try {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     delete s;
 }
+NVCA_API_CATCH_VOID
 int nvca_part_stream_set_params(nvca_part_stream *s, const nvca_part_params *params)
-{
+try {
     if (!s || !params || params->kind != s->p.kind) return NVCA_ERR_ARG;
     s->p = *params;
     return NVCA_OK;
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 int nvca_part_stream_push_faces(nvca_part_stream *s, const nvca_rect *faces, int n)
-{
+try {
     if (!s || n < 0 || (n > 0 && !faces)) return NVCA_ERR_ARG;
     if (s->queue.size() < 16) s->queue.emplace_back(faces, faces + n);
     return NVCA_OK;
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 
 int nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, int *n_out)
-{
+try {
     if (!s || !n_out || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     *n_out = (int)s->faces.size();
     for (int i = 0; i < std::min(*n_out, cap); i++) out[i] = s->faces[i];
     return NVCA_OK;
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 
 // One transform_frame_ip of every stream of the batch.  The streams' device work is queued together and waited for three
 // times per call, however many streams there are: (1) the working images of all frames (a launch set per image size) and the
@@ -267,7 +204,7 @@ int nvca_part_stream_faces(const nvca_part_stream *s, nvca_rect *out, int cap, i
 // narrow their scan take one more round), (3) nothing -- the merging heuristics that follow are host code on the collected boxes.
 int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, nvca_rect *out_a, int cap_a,
                             int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (n < 0 || (n > 0 && (!streams || !frames || !n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
     for (int i = 0; i < n; i++) {
@@ -313,12 +250,37 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     // the images are made on one lane; the face passes and the part searches run on the lanes side by side behind them.  Calls with
     // several streams stay off lane 0, where a face detector's batch may be in flight (nvca_face_batch_submit)
     struct LaneGuard { nvca_ctx *c; ~LaneGuard() { c->cur_lane = 0; } } lane_guard{ctx};
+    // The gates of phase 1a (and find_ears_begin in phase 2) advance per-stream state; plans, buffers and launches come after
+    // them and may still fail (too many scales, allocation, a refused launch).  Whatever the error, the call leaves every
+    // stream as it found it -- the GStreamer shim re-runs the streams one by one after a refused batch, and a gate that had
+    // already advanced would then advance twice and drop a queued face event.  Nothing of the call may stay in flight either:
+    // the caller's frames (H2D copies) and the arena are only safe to reuse once the lanes have drained.
+    struct StreamSnap { nvca_part_stream *s; RectV faces, la, lb; int num_frame, to_process, no_a, no_b; bool popped; RectV front; };
+    struct Rollback {
+        nvca_ctx *c; std::vector<StreamSnap> v; bool armed = true;
+        ~Rollback()
+        {
+            if (!armed) return;
+            (void)hipDeviceSynchronize();
+            for (StreamSnap &g : v) {
+                nvca_part_stream *s = g.s;
+                s->faces.swap(g.faces); s->la.swap(g.la); s->lb.swap(g.lb);
+                s->num_frame = g.num_frame; s->num_frames_to_process = g.to_process; s->no_det_a = g.no_a; s->no_det_b = g.no_b;
+                if (g.popped) s->queue.push_front(std::move(g.front));
+            }
+        }
+    } rollback{ctx, {}};
+    rollback.v.reserve(n);
+    for (int i = 0; i < n; i++) {
+        nvca_part_stream *s = streams[i];
+        rollback.v.push_back(StreamSnap{s, s->faces, s->la, s->lb, s->num_frame, s->num_frames_to_process, s->no_det_a, s->no_det_b, false, RectV()});
+    }
     int rc = NVCA_OK;
     const int D = NVCA_MEM_DEVICE;
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
-    static const bool stats = getenv("NVCA_PART_STATS") != nullptr;    // diagnostic: the host's time per phase of calls with 8 or more streams, every 8 such calls
+    const bool stats = ctx->sw.part_stats > 0;    // diagnostic: the host's time per phase of calls with n (default 8) or more streams, every 8 such calls
     static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
-    static const int stats_min = stats && atoi(getenv("NVCA_PART_STATS")) > 0 ? atoi(getenv("NVCA_PART_STATS")) : 8;     // NVCA_PART_STATS=n: calls with n or more streams
+    const int stats_min = stats ? ctx->sw.part_stats : 8;
     const double ts0 = stats ? mono_s() : 0;
     // ---- phase 1a: gating of every stream, in stream order; what the streams that run need is only noted down here
     for (int i = 0; i < n; i++) {
@@ -336,6 +298,7 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
                 received = false;
                 if (!s->queue.empty()) {
                     s->faces = s->queue.front(); s->queue.pop_front();
+                    rollback.v[i].popped = true; rollback.v[i].front = s->faces;
                     received = true;
                     s->num_frames_to_process = 10 / (5 - s->p.process_x_every_4);
                 }
@@ -465,6 +428,14 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         CK(part_images_done(ctx, used_lanes.data(), (int)used_lanes.size()));
     }
     const double ts1 = stats ? mono_s() : 0;
+    // Every face pass waits for the images (part_images_done), so draining the passes' lanes drains the image lane's work
+    // too.  A call without any face pass (detect-event streams: the faces were pushed) has nobody waiting for it: the H2D
+    // copies of the caller's frames and the image kernels are drained here, before the call can return -- the caller may
+    // recycle its buffers, and the next call carves the same arena on another lane.
+    if (jobs.empty() && !groups.empty()) {
+        const hipError_t he = hipStreamSynchronize(ctx->lane_streams[n > 1 ? 1 : 0]);
+        if (he != hipSuccess) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); return NVCA_ERR_HIP; }
+    }
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 1: every face pass
     // a stream's faces: result k of its pass's job
     auto pass_result = [&](const PartWork &w, bool mirrored) -> const std::vector<nvca_rect> & {
@@ -535,6 +506,8 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
         }
     }
 #undef CK
+    rollback.armed = false;                // nothing below can fail short of an exception -- which the containers' strong guarantee
+                                           // and the ABI barrier turn into an error code; the device work is complete
     // ---- phase 3: merging heuristics, hysteresis, emission -- in stream order
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
@@ -589,13 +562,15 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
     }
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *f, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b,
                              int cap_b, int *n_b)
-{
+try {
     if (!s || !f) return NVCA_ERR_ARG;
     nvca_part_stream *arr[1] = {s};
     return nvca_part_batch_process(s->ctx, 1, arr, f, out_a, cap_a, n_a, out_b, cap_b, n_b);
 }
+NVCA_API_CATCH((s ? s->ctx : nullptr))
 
 } // extern "C"

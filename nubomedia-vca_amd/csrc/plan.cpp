@@ -237,6 +237,12 @@ static int build_xcd_order(const std::vector<long long> &weight, std::vector<int
     return 8 * maxlen;
 }
 
+bool DetectPlan::hit_valid(unsigned key) const
+{
+    const size_t s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+    return s < specs.size() && ix < specs[s].xs.size() && iy < specs[s].ys.size();
+}
+
 nvca_rect DetectPlan::hit_rect(unsigned key) const
 {
     const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
@@ -252,10 +258,9 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     specs = std::move(in);
     nstumps = (int)c.cls.size();
     scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); release_tables();
-    if (const char *e = getenv("NVCA_DEEP_STAGE")) deep_stage = std::max(1, atoi(e));
+    if (ctx->sw.deep_stage > 0) deep_stage = ctx->sw.deep_stage;
     // stages 1 .. deep_stage-1 run on LDS lattice tiles (k_tile); NVCA_TILES=0 selects the older row strips (k_strip)
-    bool use_tiles = true;
-    if (const char *e = getenv("NVCA_TILES")) use_tiles = atoi(e) != 0;
+    bool use_tiles = ctx->sw.tiles;
     if (generic) use_tiles = false;              // the LDS tile kernels are built around upright stumps
     (void)allow_tiles;
     tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
@@ -346,7 +351,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                 ok = worst_c <= kTileMaxCols && worst_r <= kTileThreads && worst_r * tile_pitch(worst_c) < 65536 &&
                      tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy) <= kTileLdsBudget;
                 if (ok) {
-                    if (getenv("NVCA_PLAN_DEBUG"))
+                    if (ctx->sw.plan_debug)
                         fprintf(stderr, "[nvca plan] scale %zu factor %.3f windows %d x %d: tile side %d, %d x %d samples, %d B of LDS (budget %d)\n", s, sp.table_factor > 0 ? sp.table_factor : sp.out_factor,
                                 sr.endX, sr.endY, tw, worst_c, worst_r, tile_lds_bytes(worst_c, worst_r, worst_sx, worst_sy), kTileLdsBudget);
                     break;
@@ -402,9 +407,19 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     blocks_per_frame = build_xcd_order(strip_w, order);
     tile_blocks_per_frame = build_xcd_order(tile_w, tile_order);
     if (!strips.empty()) bands.clear();          // the band kernel has no strip counterpart: all scales tiled, or none
+    if (!strips.empty() && use_tiles && !generic && !ctx->sw.quiet) {
+        // a stump cascade some scale of which does not fit the tiles' LDS budget runs on the row-strip kernel: same results,
+        // several times slower on large scans -- said once, not silently
+        static bool noted = false;
+        if (!noted) {
+            noted = true;
+            fprintf(stderr, "nubovca: a scan (%d x %d image, %zu scales) does not fit the LDS tile kernels and runs on the row-strip fallback (k_strip): same results, slower; NVCA_PLAN_DEBUG=1 prints the per-scale tile sizes (this note is printed once)\n",
+                    cols, rows, specs.size());
+        }
+    }
     // late stages: per scale the distinct corner columns / rows of their stumps (k_deep's LDS patch of one window)
     deeprecs.clear(); deep_lds = 0;
-    if (strips.empty() && !tiles.empty() && deep_stage < (int)stages.size() && getenv("NVCA_DEEP_LDS_OFF") == nullptr) {
+    if (strips.empty() && !tiles.empty() && deep_stage < (int)stages.size() && ctx->sw.deep_lds) {
         deeprecs.resize(scales.size());
         std::vector<char> tiled(scales.size(), 0);
         for (const TileRec &t : tiles) tiled[t.scale] = 1;

@@ -75,6 +75,7 @@ struct DetectPlan {
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
     nvca_rect hit_rect(unsigned key) const;
+    bool hit_valid(unsigned key) const;   // the key names a window of this plan's scan grids (a device result is checked before it indexes host tables)
     int build_scale_cascade(nvca_ctx *ctx, const Cascade &c, int cols, int rows, int pitch, double scaleFactor,
                             int minw, int minh, int maxw, int maxh, std::string &err);
     int upload(nvca_ctx *ctx);

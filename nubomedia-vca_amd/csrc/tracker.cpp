@@ -24,7 +24,7 @@ constexpr int kCompCap = 1 << 18;
 extern "C" {
 
 int nvca_tracker_create(nvca_ctx *ctx, const nvca_tracker_params *params, nvca_tracker **out)
-{
+try {
     if (!ctx || !out) return NVCA_ERR_ARG;
     nvca_tracker *t = new (std::nothrow) nvca_tracker();
     if (!t) return NVCA_ERR_NOMEM;
@@ -33,26 +33,29 @@ int nvca_tracker_create(nvca_ctx *ctx, const nvca_tracker_params *params, nvca_t
     *out = t;
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 void nvca_tracker_destroy(nvca_tracker *t)
-{
+try {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
     t->prev.release(); t->mhi.release();
     delete t;
 }
+NVCA_API_CATCH_VOID
 
 int nvca_tracker_set_params(nvca_tracker *t, const nvca_tracker_params *params)
-{
+try {
     if (!t || !params) return NVCA_ERR_ARG;
     t->p = *params;
     return NVCA_OK;
 }
+NVCA_API_CATCH((t ? t->ctx : nullptr))
 
 int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *trackers, const nvca_frame *frames,
                                const double *ts, nvca_rect *out, int cap, int *n_out)
-{
+try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!trackers || !frames || !ts || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
@@ -65,7 +68,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
         for (int j = 0; j < i; j++) if (trackers[j] == trackers[i]) { ctx->set_error("a tracker may appear once per batch"); return NVCA_ERR_ARG; }
     }
     TrkWorkspace &ws = ctx->trk;
-    static const bool hostprof = getenv("NVCA_HOST_PROFILE") != nullptr;
+    const bool hostprof = ctx->sw.host_profile;
     auto tp0 = std::chrono::steady_clock::now(), tp1 = tp0, tp2 = tp0;
     int total_comps = 0;
     std::vector<char> done(n, 0);
@@ -119,8 +122,8 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->stream));
         NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->stream));
         { TimedLaunch tl(ctx, NVCA_K_TRACKER);
-          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>()); }
-        NVCA_HIP_CHECK(ctx, hipGetLastError());
+          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>(), ctx->sw.trk_order); }
+        NVCA_LAUNCH_CHECK(ctx);
         tp1 = std::chrono::steady_clock::now();
         int *ho = ws.h_out.as<int>();
         int total = 0;
@@ -129,6 +132,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
             NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->stream));
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             total = ho[0];
+            if (total < 0) { ctx->set_error("internal: negative component count"); return NVCA_ERR_INTERNAL; }
             if (total > kCompCap) { ctx->set_error("tracker: more motion components than the list holds"); return NVCA_ERR_OVERFLOW; }
             if (total > first) {
                 NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho + 2 + 6 * (size_t)first, ws.out.as<int>() + 2 + 6 * (size_t)first,
@@ -142,6 +146,7 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
         std::vector<std::vector<std::pair<int, nvca_rect>>> comps(batch);
         for (int k = 0; k < total; k++) {
             const int *o = ho + 2 + (size_t)k * 6;
+            if (o[0] < 0 || o[0] >= batch) { ctx->set_error("internal: motion component of an unknown slot (device result rejected)"); return NVCA_ERR_INTERNAL; }
             comps[o[0]].push_back({o[1], nvca_rect{o[2], o[3], o[4], o[5]}});
         }
         for (int b = 0; b < batch; b++) {
@@ -166,12 +171,14 @@ int nvca_tracker_batch_process(nvca_ctx *ctx, int n, nvca_tracker *const *tracke
     }
     return NVCA_OK;
 }
+NVCA_API_CATCH(ctx)
 
 int nvca_tracker_process(nvca_tracker *t, const nvca_frame *f, double ts, nvca_rect *out, int cap, int *n_out)
-{
+try {
     if (!t || !f) return NVCA_ERR_ARG;
     nvca_tracker *arr[1] = {t};
     return nvca_tracker_batch_process(t->ctx, 1, arr, f, &ts, out, cap, n_out);
 }
+NVCA_API_CATCH((t ? t->ctx : nullptr))
 
 } // extern "C"

@@ -213,7 +213,8 @@ static void part_run_round(nvca_ctx *ctx, std::vector<PartReq *> &round)
         std::vector<int> na(n, 0), nb(n, 0);
         for (int i = 0; i < n; i++) { streams[i] = round[i]->stream; frames[i] = round[i]->frame; }
         const int rc = nvca_part_batch_process(ctx, n, streams.data(), frames.data(), a.data(), kPartCap, na.data(), b.data(), kPartCap, nb.data());
-        batched = rc != NVCA_ERR_ARG;                       // refused before any stream was touched: each frame on its own
+        batched = rc == NVCA_OK;                            // any failure leaves every stream of the call as it was (parts.cpp, Rollback):
+                                                            // each frame then runs on its own, so one bad frame does not fail its neighbours
         for (int i = 0; batched && i < n; i++) {
             PartReq *r = round[i];
             r->rc = rc; r->na = rc == NVCA_OK ? na[i] : 0; r->nb = rc == NVCA_OK ? nb[i] : 0;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libnubovca_hip.so")
 
 OK = 0
-ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OVERFLOW, ERR_NOMEM = range(-1, -9, -1)
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OVERFLOW, ERR_NOMEM, ERR_INTERNAL = range(-1, -10, -1)
 MEM_HOST, MEM_DEVICE = 0, 1
 HAAR_DO_CANNY_PRUNING, HAAR_SCALE_IMAGE, HAAR_FIND_BIGGEST_OBJECT, HAAR_DO_ROUGH_SEARCH = 1, 2, 4, 8
 SUM_F32PAIR, SUM_F64 = 0, 1
@@ -76,6 +76,7 @@ SYMBOLS = [
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
     "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count", "nvca_draw_shapes",
+    "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option",
 ]
 
 _lib = None
@@ -121,6 +122,7 @@ def load():
     L.nvca_ctx_destroy.restype = None
     L.nvca_ctx_set_hit_capacity.argtypes = [vp, C.c_int]
     L.nvca_ctx_set_sum_policy.argtypes = [vp, C.c_int]
+    L.nvca_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.nvca_ctx_synchronize.argtypes = [vp]
     L.nvca_ctx_stream.argtypes = [vp]
     L.nvca_host_register.argtypes = [vp, vp, C.c_size_t]
@@ -131,6 +133,8 @@ def load():
     L.nvca_cascade_load_xml.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.nvca_cascade_load_mem.argtypes = [vp, C.c_char_p, C.c_int64, C.POINTER(vp)]
     L.nvca_cascade_free.argtypes = [vp]
+    L.nvca_cascade_validate_mem.argtypes = [C.c_char_p, C.c_int64, ip, ip, ip, ip, C.c_char_p, C.c_int]
+    L.nvca_abi_selftest.argtypes = [C.c_int]
     L.nvca_cascade_free.restype = None
     L.nvca_cascade_info.argtypes = [vp, ip, ip, ip, ip]
     L.nvca_cascade_dump.argtypes = [vp, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -217,6 +221,29 @@ class Context:
 
     def set_sum_policy(self, policy):
         self.check(self.L.nvca_ctx_set_sum_policy(self.h, policy))
+
+    # defaults of the A/B switches when the environment sets none (nvca_ctx_set_option)
+    OPTION_DEFAULTS = {"band": -1, "band_map": 0, "tiles": 1, "deep_stage": 0, "deep_lds": 1, "pyr_off": 0, "host_group": 0,
+                       "group_zerocopy": 1, "sparse_ingest": 1, "ingest_chunk": 8, "skip_cascade": 0, "host_profile": 0,
+                       "part_stats": 0, "trk_order": -1, "plan_debug": 0, "quiet": 0}
+
+    def set_option(self, name, value):
+        self.check(self.L.nvca_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def options(self, **kw):
+        """context manager: the given switches for the duration of a with-block, the defaults afterwards"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            for k, v in kw.items():
+                self.set_option(k, v)
+            try:
+                yield self
+            finally:
+                for k in kw:
+                    self.set_option(k, self.OPTION_DEFAULTS[k])
+        return scope()
 
     def synchronize(self):
         self.check(self.L.nvca_ctx_synchronize(self.h))

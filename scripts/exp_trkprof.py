@@ -23,7 +23,7 @@ for i in range(45, 65): tick(i)
 ctx.synchronize()
 kt = ctx.kernel_timing()
 print({k: (round(v[0] / 20, 3), v[1] / 20) for k, v in kt.items() if v[1]})
-os.environ["NVCA_HOST_PROFILE"] = "1"
+ctx.set_option("host_profile", 1)
 # determinism: two tracker sets, same frames and timestamps -> identical rect lists every tick
 A = [capi.Tracker(ctx) for _ in range(V)]
 B = [capi.Tracker(ctx) for _ in range(V)]

@@ -43,3 +43,100 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".c")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "synth.py" and False, os.path.join(dp, f)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the exception barrier (include/nubovca.h: "never throws"; the reference never lets an error out of the element,
+# FACE/kmsfacedetect.cpp:897) and the loader on hostile input -- all on the host, through the ABI
+def test_exception_barrier_maps_every_kind(lib):
+    NOMEM, INTERNAL = -8, -9
+    assert lib.nvca_abi_selftest(0) == NOMEM          # std::bad_alloc
+    assert lib.nvca_abi_selftest(1) == NOMEM          # std::length_error out of vector::resize
+    assert lib.nvca_abi_selftest(2) == INTERNAL       # std::runtime_error
+    assert lib.nvca_abi_selftest(3) == INTERNAL       # throw 42
+    assert lib.nvca_abi_selftest(4) == INTERNAL       # std::out_of_range out of vector::at
+    assert lib.nvca_abi_selftest(99) == 0
+
+
+def test_every_entry_point_has_the_barrier():
+    """every extern "C" definition with a body of its own is a function-try-block that ends in NVCA_API_CATCH*"""
+    src = os.path.join(ROOT, "nubomedia-vca_amd", "csrc")
+    trivial = {"nvca_version", "nvca_kernel_name", "nvca_last_error", "nvca_ctx_stream", "nvca_face_stream_destroy"}   # one-liners that allocate nothing
+    seen = set()
+    for f in ("api.cpp", "parts.cpp", "tracker.cpp"):
+        lines = open(os.path.join(src, f)).read().split("\n")
+        for i, ln in enumerate(lines):
+            m = re.match(r"^(?:int|void|const char \*|void \*)\s*(nvca_[a-z0-9_]+)\(", ln)
+            if not m or ln.rstrip().endswith(";"):
+                continue
+            name = m.group(1)
+            if name in trivial:
+                seen.add(name)
+                continue
+            j = i
+            while "{" not in lines[j]:
+                j += 1
+            assert lines[j].strip() == "try {", (f, name, lines[j])
+            k = j
+            while lines[k] != "}":
+                k += 1
+            assert lines[k + 1].startswith("NVCA_API_CATCH"), (f, name, lines[k + 1])
+            seen.add(name)
+    from nubovca import capi
+    assert seen == set(capi.SYMBOLS), seen ^ set(capi.SYMBOLS)
+
+
+def _validate(lib, xml):
+    if isinstance(xml, str):
+        xml = xml.encode()
+    err = C.create_string_buffer(256)
+    w, h, ns, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.nvca_cascade_validate_mem(xml, len(xml), C.byref(w), C.byref(h), C.byref(ns), C.byref(nw), err, 256)
+    return rc, (w.value, h.value, ns.value, nw.value), err.value.decode(errors="replace")
+
+
+def test_loader_accepts_the_synthetic_cascades(lib):
+    from nubovca import synth
+    rc, shape, err = _validate(lib, synth.synthetic_cascade_xml())
+    assert rc == 0 and shape[:2] == (20, 20) and shape[2] == 22 and shape[3] == 2135, (rc, shape, err)
+    rc, shape, err = _validate(lib, synth.synthetic_part_cascade_xml("mouth"))
+    assert rc == 0, err
+
+
+def test_loader_refuses_garbage_with_a_code(lib):
+    """hostile / damaged cascade files end as NVCA_ERR_PARSE (or _UNSUPPORTED / _NOMEM), never as a crash"""
+    import numpy as np
+    from nubovca import synth
+    good = synth.synthetic_cascade_xml(seed=7, stages=[3, 4])
+    PARSE, UNSUP = -5, -6
+    cases = {
+        "empty root": "<opencv_storage></opencv_storage>",
+        "not xml": "\x00\x01\x02 garbage <<<>>>",
+        "unterminated": good[: len(good) // 2],
+        "huge size": good.replace("<size>20 20</size>", "<size>2147483647 2147483647</size>"),
+        "negative size": good.replace("<size>20 20</size>", "<size>-5 20</size>"),
+        "deep nesting": "<a>" * 200 + "</a>" * 200,
+        "2^31 in a rect": re.sub(r"<_>(\d+) (\d+) (\d+) (\d+) ", "<_>2147483647 2147483647 2147483647 2147483647 ", good, count=1),
+        "rect beyond the window": re.sub(r"<_>(\d+) (\d+) (\d+) (\d+) ", "<_>19 19 5 5 ", good, count=1),
+        "stage graph": good.replace("<next>-1</next>", "<next>1</next>", 1),
+    }
+    for name, xml in cases.items():
+        rc, _, err = _validate(lib, xml)
+        assert rc in (PARSE, UNSUP), (name, rc, err)
+        assert err, name
+    # a child index that does not follow its parent (the device's tree walk would never end): refused by the loader
+    tree = synth.generic_cascade_xml(seed=3) if hasattr(synth, "generic_cascade_xml") else None
+    if tree and "<left_node>" in tree:
+        bad = re.sub(r"<left_node>\d+</left_node>", "<left_node>0</left_node>", tree, count=1)
+        rc, _, err = _validate(lib, bad)
+        assert rc == PARSE, (rc, err)
+    # random byte damage: any status is fine, returning is the point
+    rng = np.random.default_rng(5)
+    raw = bytearray(good.encode())
+    for _ in range(300):
+        b = bytearray(raw)
+        for _ in range(int(rng.integers(1, 12))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        rc, _, _ = _validate(lib, bytes(b))
+        assert rc in (0, PARSE, UNSUP, -8, -9), rc
+    assert lib.nvca_cascade_validate_mem(None, 5, None, None, None, None, None, 0) == -1

@@ -198,12 +198,9 @@ def test_detect_random_geometries(ctx, casc, casc_small, orc_cascade, orc_small)
         g = orc.equalize_hist(synth.make_gray(w, h, 1000 + it, kinds[it % 3], faces))
         c, oc = (casc_small, orc_small) if it % 5 == 0 else (casc, orc_cascade)
         eraw = orc.detect_raw(oc, g, sf, 0, ms, mx)
-        for band in ("0", "1"):
-            os.environ["NVCA_BAND"] = band
-            try:
+        for band in (0, 1):
+            with ctx.options(band=band):
                 raw = ctx.detect_raw(c, g, sf, 0, ms, mx)
-            finally:
-                del os.environ["NVCA_BAND"]
             assert np.array_equal(raw, eraw), (it, band, w, h, sf, ms, mx, len(raw), len(eraw))
         det = ctx.detect_multiscale(c, g, sf, 2, 0, ms, mx)
         assert np.array_equal(det, orc.detect_multiscale(oc, g, sf, 2, 0, ms, mx)), (it, w, h)
@@ -612,23 +609,28 @@ def test_detect_roi_view(ctx, casc, orc_cascade):
 
 
 # ------------------------------------------------------------------ optional evaluator paths stay correct
-@pytest.mark.parametrize("env", [{"NVCA_TILES": "0"}, {"NVCA_DEEP_STAGE": "1"},
-                                 {"NVCA_DEEP_STAGE": "2"}, {"NVCA_DEEP_STAGE": "30"}, {"NVCA_TILES": "0", "NVCA_DEEP_STAGE": "30"},
-                                 {"NVCA_BAND": "1"}, {"NVCA_BAND": "1", "NVCA_DEEP_STAGE": "30"}, {"NVCA_BAND": "1", "NVCA_DEEP_STAGE": "2"},
-                                 {"NVCA_DEEP_LDS_OFF": "1"}, {"NVCA_DEEP_STAGE": "20"}])
-def test_optional_evaluator_paths(ctx, casc, orc_cascade, env, monkeypatch):
+@pytest.mark.parametrize("opts", [{"tiles": 0}, {"deep_stage": 1},
+                                  {"deep_stage": 2}, {"deep_stage": 30}, {"tiles": 0, "deep_stage": 30},
+                                  {"band": 1}, {"band": 1, "deep_stage": 30}, {"band": 1, "deep_stage": 2},
+                                  {"deep_lds": 0}, {"deep_stage": 20}])
+def test_optional_evaluator_paths(ctx, casc, orc_cascade, opts):
     """k_strip (row strips, global gathers: the fallback of plans without tiles) and other deep-stage splits are kept as
-    measured alternatives; plans read the switches when they are built, so new geometries pick them up"""
+    measured alternatives; nvca_ctx_set_option switches them per context (plan options drop the cached plans)"""
     import orc
     from nubovca import synth
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    tag = sum(ord(c) for c in "".join(sorted(env)) + "".join(env.values())) % 17
-    w, h = 1000 + tag, 600 + tag                      # a geometry no other test uses -> a fresh plan
+    w, h = 1003, 611
     g = orc.equalize_hist(synth.make_gray(w, h, 77, "natural", [(200, 100, 260), (600, 300, 120)]))
-    raw = ctx.detect_raw(casc, g, 1.1, 0, (40, 40))
     eraw = orc.detect_raw(orc_cascade, g, 1.1, 0, (40, 40))
+    with ctx.options(**opts):
+        raw = ctx.detect_raw(casc, g, 1.1, 0, (40, 40))
     assert len(eraw) > 0 and np.array_equal(raw, eraw)
+    assert np.array_equal(ctx.detect_raw(casc, g, 1.1, 0, (40, 40)), eraw)          # and back on the default path
+
+
+def test_unknown_option_is_refused(ctx):
+    from nubovca import capi
+    with pytest.raises(capi.NvcaError):
+        ctx.set_option("no_such_switch", 1)
 
 
 def test_detect_long_scan_rows(ctx, casc, orc_cascade):

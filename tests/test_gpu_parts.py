@@ -222,6 +222,68 @@ def test_part_batch_more_images_than_one_job_carries(env):
     assert capi.part_batch_process(ctx, [], []) == []
 
 
+def test_part_batch_late_failure_leaves_every_stream_untouched(env):
+    """A batched call that fails AFTER the gates have advanced (one eye stream whose face pass has more scales than a plan
+    carries: multi-scale-factor 1 -> 1.01) returns an error and leaves every stream of the call as it found it: frame gates,
+    queued face events (detect-event streams) and result lists.  The streams then run on -- one by one, as the GStreamer shim
+    does after a refused batch -- exactly like streams that never saw the failed call."""
+    from nubovca import capi
+    ctx, dev, cpu = env
+    frames = _scene(640, 480, 6, 5150)
+    fs = capi.FaceStream(ctx, dev["face"])
+    good = [_streams(env, "nose", process_x_every_4_frames=2), _streams(env, "mouth", detect_event=1), _streams(env, "ear")]
+    bad = capi.PartStream(ctx, 0, dev["face"], dev["righteye"], dev["lefteye"], multi_scale_factor=1)
+    tot = 0
+    for t, f in enumerate(frames):
+        boxes, _ = fs.process(f)
+        if len(boxes) and t != 3:
+            good[1][0].push_faces(boxes); good[1][1].push_faces(boxes)
+        if t in (1, 2, 4):          # the refused batch: the bad stream last, so every good gate has advanced before it fails
+            with pytest.raises(capi.NvcaError) as ei:
+                capi.part_batch_process(ctx, [g for g, _ in good] + [bad], [f] * 4)
+            assert ei.value.code in (capi.ERR_ARG, capi.ERR_UNSUPPORTED), ei.value
+        for g, o in good:
+            ga, gb = g.process(f)
+            ea, eb = o.process(f)
+            assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (t, ga, ea, gb, eb)
+            tot += len(ea) + len(eb)
+    assert tot > 0
+
+
+def test_part_batch_without_any_job_returns_drained(env):
+    """detect-event streams whose upstream sent an EMPTY face list: the call queues the frame upload and the working images,
+    but no face pass and no part search -- it must still return with nothing in flight (the caller recycles its buffer; the
+    next single-stream call carves the same arena on another lane).  Checked by overwriting the host frame right after the
+    call and by the following calls' results."""
+    from nubovca import capi
+    ctx, dev, cpu = env
+    pairs = [_streams(env, "nose", detect_event=1), _streams(env, "mouth", detect_event=1)]
+    frames = _scene(640, 480, 4, 6200)
+    fs = capi.FaceStream(ctx, dev["face"])
+    tot = 0
+    for t, f in enumerate(frames):
+        boxes, _ = fs.process(f)
+        handed = f.copy()
+        if t % 2 == 0:
+            for g, o in pairs:
+                g.push_faces(np.zeros((0, 4), np.int32)); o.push_faces(np.zeros((0, 4), np.int32))
+        elif len(boxes):
+            for g, o in pairs:
+                g.push_faces(boxes); o.push_faces(boxes)
+        res = capi.part_batch_process(ctx, [g for g, _ in pairs], [handed, handed])
+        handed[:] = 0                                        # the buffer goes back to its pool
+        for (g, o), (ga, gb) in zip(pairs, res):
+            ea, eb = o.process(f)
+            assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (t, ga, ea)
+            tot += len(ea) + len(eb)
+        one = _streams(env, "nose")                          # a single-stream call right behind it (lane 0, same arena)
+        ga, gb = one[0].process(f)
+        ea, eb = one[1].process(f)
+        assert np.array_equal(ga, ea) and np.array_equal(gb, eb)
+        one[0].close()
+    assert tot >= 0
+
+
 def test_flip_primitive(env):
     import ctypes as C
     import orc

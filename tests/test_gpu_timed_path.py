@@ -160,16 +160,14 @@ def test_face_tracker_batch_8x1080p_vs_oracle(ctx, casc, orc_cascade):
         tr.close()
 
 
-@pytest.mark.parametrize("env,N", [({"NVCA_BAND": "1"}, 5), ({"NVCA_BAND": "1", "NVCA_BAND_MAP": "1"}, 8),
-                                   ({"NVCA_BAND": "1", "NVCA_BAND_MAP": "2"}, 16)])
-def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N, monkeypatch):
+@pytest.mark.parametrize("env,N", [({"band": 1}, 5), ({"band": 1, "band_map": 1}, 8),
+                                   ({"band": 1, "band_map": 2}, 16)])
+def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N):
     """k_band decodes (band, frame slot) from the block index (and NVCA_BAND_MAP remaps it): frames of DIFFERENT content
     in one geometry, forced through the band kernel, each checked against the oracle (a slot / plane mix-up would
     swap or smear boxes between frames)"""
     import orc
     from nubovca import capi, synth
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     W, H = 800, 450
     frames = [synth.make_bgr(W, H, 8100 + 7 * i, ["natural", "gradient", "noise"][i % 3],
                              [(40 + 37 * i % 400, 30 + 11 * i % 150, 120 + 9 * (i % 8))] if i % 4 != 2 else []) for i in range(N)]
@@ -177,7 +175,8 @@ def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N, monkeypatch):
     streams = [capi.FaceStream(ctx, casc, **props) for _ in range(N)]
     keep, fr = _device_frames(frames)          # device frames: one launch set for the whole batch (host frames go in chunks)
     ctx.enable_kernel_timing(1)
-    res = ctx.face_batch_process(streams, fr)
+    with ctx.options(**env):
+        res = ctx.face_batch_process(streams, fr)
     kt = ctx.kernel_timing()
     ctx.enable_kernel_timing(0)
     assert _launched(kt, "cascade_band") == 1 and _launched(kt, "cascade_tile") == 0, kt
