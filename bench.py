@@ -26,8 +26,9 @@ for _p in (ROOT, os.path.join(ROOT, "nubomedia-vca_amd")):
         sys.path.insert(0, _p)
 
 import numpy as np
-import torch
-import torch.distributed as dist
+
+torch = None            # imported by the worker only: the launcher parent of `--gpus N` touches neither torch nor the GPU
+dist = None
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MAX_BOXES = 64
@@ -252,6 +253,38 @@ def boxes_equal(got, exp):
     return True
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` typed as it stands: this process becomes a launcher that makes NO GPU call (it imports neither
+    torch nor the library), starts N ranks of this same script -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what `python -m torch.distributed.run --nproc-per-node N`
+    would give them -- relays rank 0's JSON line and exits with the worst child status.  Under torchrun (WORLD_SIZE already
+    set) the script is a rank itself and never comes here."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    child_cmd = os.environ.get("NVCA_BENCH_CHILD_CMD")          # tests: a stub rank instead of this script
+    cmd = child_cmd.split() if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if line is None and worst == 0:
+        worst = 1                                          # every rank exited cleanly and nobody printed the line: still a failure
+    if worst:
+        print("bench.py launcher: rank exit codes %s" % rcs, file=sys.stderr)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,7 +310,15 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    global torch, dist
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal hook for a one-GPU box: NVCA_BENCH_REHEARSAL=1 runs every rank on device 0 with the gloo backend, so the
@@ -374,7 +415,7 @@ def main():
         if trackers is not None:
             capi.tracker_batch_process(ctx, trackers, bgra_frames[tick[0] % TICKS], [33.3 * tick[0]] * F, cap=256)
         if world > 1:           # result gather (the only collective): fixed-size box table per stream tick, over RCCL;
-            tab = sharding.pack_box_arrays(res.boxes, res.counts) if hasattr(res, "counts") else sharding.pack_boxes(res, MAX_BOXES)
+            tab = sharding.pack_box_arrays(res.boxes, res.counts, rank=rank) if hasattr(res, "counts") else sharding.pack_boxes(res, MAX_BOXES, rank=rank)
             gather.submit(tab)                                      # asynchronous: it overlaps the next tick's kernels
         return res
 
@@ -408,10 +449,17 @@ def main():
     ktimes = ctx.kernel_timing()
     ctx.enable_kernel_timing(False)
     n_boxes = float(np.mean([len(b) for b, _ in as_list(res)]))
+    ranks_seen = [0]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the last gathered box table carries every rank's stamp: N ranks really ran and their rows arrived where they belong
+        g = gather.last()
+        stamps = sharding.table_ranks(g)
+        assert g.shape[0] == world and all((stamps[r] == r).all() for r in range(world)), stamps
+        ranks_seen = sorted(set(int(v) for v in stamps.reshape(-1)))
+        assert ranks_seen == list(range(world)), ranks_seen
 
     if rank == 0:
         total_frames = world * F * args.steps
@@ -491,7 +539,7 @@ def main():
                                     ) % ((W, H) if not multi_stream else ()) +
                                    ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
                        "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
-                       "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world,
+                       "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world, "ranks_seen": ranks_seen,
                        "batches_in_flight": 2 if pipelined else 1},
             "roofline": roofline,
         }

@@ -78,7 +78,11 @@ void nvca_ctx_destroy(nvca_ctx *ctx);
 /* text of the last error on this context (never NULL) */
 const char *nvca_last_error(const nvca_ctx *ctx);
 const char *nvca_version(void);
-/* raw-candidate capacity per frame (default 16384); more -> NVCA_ERR_OVERFLOW */
+/* Raw-candidate capacity per frame the lists start with (default 16384, at most 2^22).  A detectMultiScale call
+ * (nvca_detect_multiscale / _raw, the part detectors' searches) that produces more re-runs its launch set once with lists of
+ * the exact size and answers as the reference does -- a CV_HAAR_FIND_BIGGEST_OBJECT search with a lenient cascade included
+ * (NOSE/kmsnosedetect.cpp:870-873).  The batched face path reports NVCA_ERR_OVERFLOW for the batch that overflowed (never a
+ * truncated list) and sizes the lists of the following batches for what that batch produced. */
 int  nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap);
 int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
 /* Measurement / bisecting switches, per context.  The process-wide defaults come from the environment

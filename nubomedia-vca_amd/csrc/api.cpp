@@ -393,6 +393,7 @@ static int run_tilted(nvca_ctx *ctx, const PreGeom &g, const uint8_t *lut, int b
 // runs on the device (k_group) and raw[b] comes back already grouped -- grouped[b] says which.
 // A job owns a result region (`r0` = index of its first frame in the caller's batch of `total` frames): its candidate
 // list and box table stay untouched while later jobs are enqueued, so several jobs can be queued before one sync.
+static constexpr int kMaxHitCap = 1 << 22;   // raw candidates per frame the lists are ever sized for (nvca_ctx_set_hit_capacity's limit)
 static constexpr int kGroupOutCap = 64;      // final boxes per frame returned by k_group (more -> host grouping)
 struct CascadeJob {
     int r0 = 0, n = 0, total = 0;
@@ -555,6 +556,11 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
         fprintf(stderr, "[nvca host] deep windows (last job) %llu, raw candidates %llu (job of %d)\n", dc, total, batch);
     }
     if (total > job.cap) {
+        // the count is exact (the kernels count every candidate, they only store the first `cap`): remember the capacity per
+        // frame that would have held this launch set.  The detectMultiScale entry points re-run the set once with it
+        // (detect_job_advance); the batched face path starts its next batch with it.
+        const unsigned long long per = (total + (unsigned long long)batch - 1) / (unsigned long long)batch + 64;
+        if (per <= (unsigned long long)kMaxHitCap && (long long)per > ctx->hit_cap_wanted) ctx->hit_cap_wanted = (int)per;
         ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
         return NVCA_ERR_OVERFLOW;
     }
@@ -773,7 +779,7 @@ const char *nvca_last_error(const nvca_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 int nvca_ctx_set_hit_capacity(nvca_ctx *ctx, int cap)
 try {
-    if (!ctx || cap < 1 || cap > (1 << 22)) return NVCA_ERR_ARG;
+    if (!ctx || cap < 1 || cap > kMaxHitCap) return NVCA_ERR_ARG;
     ctx->hit_cap = cap;
     return NVCA_OK;
 }
@@ -1341,6 +1347,7 @@ struct DetectJob {
     // FIND_BIGGEST: the serial loop's state between the two sets
     std::vector<FbStep> ladder; std::vector<std::vector<nvca_rect>> hits; std::vector<char> have; std::vector<int> ladder_of;
     std::vector<nvca_rect> all; nvca_rect scanROI{0, 0, 0, 0}; bool narrowed_done = false; size_t fb_i = 0; int cur_minw = 0, cur_minh = 0;
+    int regrown = 0;                                 // launch sets re-run with a larger candidate list (at most one per set)
 };
 
 static bool fb_make_spec(const DetectJob &j, int spitch, const FbStep &st, int startX, int endX, int startY, int endY, ScaleSpec &sp)
@@ -1692,6 +1699,16 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     std::vector<std::vector<int>> sc;
     if (j.dp) rc = cascade_collect(ctx, *j.dp, j.cj, raw, j.kind == 0 ? &grouped : nullptr, j.kind == 2 ? &sc : nullptr);
     if (j.gp) { j.gp->inflight--; j.gp = nullptr; }
+    if (rc == NVCA_ERR_OVERFLOW && j.regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
+        // More raw candidates than the lists hold.  OpenCV has no such limit (and a FIND_BIGGEST search would have stopped at
+        // its first object long before: NOSE/kmsnosedetect.cpp:870-873, MOUTH/kmsmouthdetect.cpp:870-873, EAR/kmseardetect.cpp:712-715),
+        // so the call must answer, not fail: the same launch set runs once more with lists of exactly the size the exact count
+        // asks for (run_detect_jobs applies hit_cap_wanted before the next round), and the serial logic is replayed on the
+        // complete candidate lists -- the result is what the reference returns.
+        j.regrown++; j.dp = nullptr;
+        if (j.phase == 1) j.phase = 0;              // the first (or only) set again; a narrowed FIND_BIGGEST set stays in phase 2
+        return NVCA_OK;
+    }
     if (rc) { j.phase = 3; return rc; }
     if (j.kind == 0) {
         if (j.dp)
@@ -1823,8 +1840,10 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
 {
     const int lane0 = ctx->cur_lane;
     const bool g_job_stats = ctx->sw.part_stats > 0;
-    struct Restore { nvca_ctx *c; int l; ~Restore() { c->cur_lane = l; } } restore{ctx, lane0};
+    struct Restore { nvca_ctx *c; int l, cap, wanted; ~Restore() { c->cur_lane = l; c->hit_cap = cap; c->hit_cap_wanted = wanted; } } restore{ctx, lane0, ctx->hit_cap, ctx->hit_cap_wanted};
+    ctx->hit_cap_wanted = 0;                 // (what the batched face path may have noted for its next batch is put back at the end)
     for (;;) {
+        if (ctx->hit_cap_wanted > ctx->hit_cap) ctx->hit_cap = ctx->hit_cap_wanted;      // a set overflowed in the last round: it runs again with room (this call only)
         int total = 0;
         for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) total += jobs[i]->slots();
         if (!total) return NVCA_OK;
@@ -2073,6 +2092,11 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     if (n < 0 || (n > 0 && (!streams || !frames))) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     ctx->timer.tick(0);
+    // a batch that overflowed its candidate lists was reported as such (its frames' gates had advanced: there is no re-run on
+    // this path); the streams go on with lists sized for what that batch produced, so the following frames are answered
+    if (ctx->hit_cap_wanted > ctx->hit_cap && !(ctx->face_tickets[1] && ctx->face_tickets[1]->pending) && !(ctx->face_tickets[2] && ctx->face_tickets[2]->pending)) {
+        ctx->hit_cap = ctx->hit_cap_wanted; ctx->hit_cap_wanted = 0;
+    }
     Workspace &ws = *ctx->ws;
     struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);   // every other entry point works on set 0
     tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();

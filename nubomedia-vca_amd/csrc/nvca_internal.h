@@ -34,7 +34,7 @@ struct Cascade {
     std::vector<float> alpha;
     bool stump_based = true;
     bool has_tilted = false; // some feature reads the tilted integral
-    bool generic() const { return !stump_based || has_tilted; }   // evaluated by the general kernels (kernels_generic.hip)
+    bool generic() const { return !stump_based || has_tilted; }   // evaluated by the general kernels (kernels_cascade.hip)
     uint64_t uid = 0;       // identity for plan caching
     mutable std::vector<unsigned char> stage_rec_cache;   // StageRec[] (plan.cpp, built on first use: the summation-order proof is per cascade)
 };
@@ -256,6 +256,7 @@ struct nvca_ctx {
                                               // (internal callers chaining primitives on the context's stream, parts.cpp)
     std::string err;
     int hit_cap = 16384;
+    int hit_cap_wanted = 0;                   // > hit_cap: a launch set produced more raw candidates than its lists hold; the per-frame size that holds it
     int policy = NVCA_SUM_F32PAIR;
     uint64_t next_uid = 1;
     nvca::KernelTimer timer;
@@ -415,7 +416,7 @@ struct CascadeArgs {
     unsigned deep_cap;
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
-    // general cascades (kernels_generic.hip)
+    // general cascades (kernels_cascade.hip)
     const int *tilted;             // tilted integral planes, laid out like sum (null: the cascade has no tilted feature)
     const float *galpha;           // leaf values of every weak classifier, concatenated
     const int *gcls_first;         // first node of weak classifier c

@@ -31,6 +31,17 @@
 #include "nubovca.h"
 
 GST_DEBUG_CATEGORY_STATIC(nubovca_debug);
+// No C++ exception crosses into GLib / GStreamer's C frames: every GObject / GstBaseTransform callback of the elements is a
+// function-try-block ending in one of these.  A frame whose processing failed is passed on untouched with GST_FLOW_OK -- the
+// reference never lets an error out of the element either (FACE/kmsfacedetect.cpp:897).
+static void nvca_gst_caught(const char *where) noexcept
+{
+    try { throw; }
+    catch (const std::exception &e) { g_warning("nubovca: %s: %s (frame / request dropped)", where, e.what()); }
+    catch (...) { g_warning("nubovca: %s: unknown exception (frame / request dropped)", where); }
+}
+#define NVCA_GST_CATCH(where, ret) catch (...) { nvca_gst_caught(where); return ret; }
+#define NVCA_GST_CATCH_VOID(where) catch (...) { nvca_gst_caught(where); }
 #define GST_CAT_DEFAULT nubovca_debug
 
 #define OPENCV_CASCADE_DIR "/usr/share/opencv/haarcascades"     /* FACE/kmsfacedetect.cpp:40 */
@@ -272,10 +283,9 @@ static double now_ms()
 struct Canvas { nvca_ctx *ctx; nvca_frame f; int bpp; };
 static void draw_shape(const Canvas &c, int kind, int x, int y, int w, int h, const guint8 *col)
 {
-    if (!c.ctx) return;
-    nvca_shape sh; sh.kind = kind; sh.x = x; sh.y = y; sh.w = w; sh.h = h;
+    nvca_shape sh;           // host frames need no context (nvca_draw_shapes): outlines are drawn even where no GPU slot came up sh.kind = kind; sh.x = x; sh.y = y; sh.w = w; sh.h = h;
     for (int k = 0; k < 4; k++) sh.bgra[k] = col[k];
-    nvca_draw_shapes(c.ctx, &c.f, c.bpp, &sh, 1);
+    nvca_draw_shapes(c.f.mem == NVCA_MEM_HOST ? NULL : c.ctx, &c.f, c.bpp, &sh, 1);
 }
 // corners (x0, y0) and (x1, y1) inclusive, as cvRectangle takes them
 static void draw_rect3(const Canvas &c, int x0, int y0, int x1, int y1, const guint8 *col) { draw_shape(c, NVCA_SHAPE_RECT3, x0, y0, x1 - x0, y1 - y0, col); }
@@ -316,7 +326,7 @@ static guint face_signal = 0;
 static void face_sync_params(NvcaFace *f) { if (f->stream) nvca_face_stream_set_params(f->stream, &f->p); }
 
 static void nvca_face_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
-{
+try {
     NvcaFace *f = (NvcaFace *)o;
     g_rec_mutex_lock(&f->mutex);
     switch (id) {
@@ -340,8 +350,9 @@ static void nvca_face_set_property(GObject *o, guint id, const GValue *v, GParam
     face_sync_params(f);
     g_rec_mutex_unlock(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_face_set_property")
 static void nvca_face_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
-{
+try {
     NvcaFace *f = (NvcaFace *)o;
     g_rec_mutex_lock(&f->mutex);
     switch (id) {
@@ -361,6 +372,7 @@ static void nvca_face_get_property(GObject *o, guint id, GValue *v, GParamSpec *
     }
     g_rec_mutex_unlock(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_face_get_property")
 
 // a queued upstream "message": does it carry a "motion" structure?  (FACE/kmsfacedetect.cpp:680-712)
 static bool message_has_motion(const GstStructure *m)
@@ -374,7 +386,7 @@ static bool message_has_motion(const GstStructure *m)
 }
 
 static gboolean nvca_face_sink_event(GstBaseTransform *trans, GstEvent *event)
-{
+try {
     NvcaFace *f = (NvcaFace *)trans;
     if (GST_EVENT_TYPE(event) == GST_EVENT_CUSTOM_DOWNSTREAM) {
         const GstStructure *s = gst_event_get_structure(event);
@@ -382,6 +394,7 @@ static gboolean nvca_face_sink_event(GstBaseTransform *trans, GstEvent *event)
     }
     return GST_BASE_TRANSFORM_CLASS(nvca_face_parent_class)->sink_event(trans, event);
 }
+NVCA_GST_CATCH("nvca_face_sink_event", FALSE)
 
 static void face_lazy_init(NvcaFace *f)
 {
@@ -401,7 +414,7 @@ static void face_lazy_init(NvcaFace *f)
 }
 
 static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
-{
+try {
     NvcaFace *f = (NvcaFace *)filter;
     g_rec_mutex_lock(&f->mutex);
     face_lazy_init(f);
@@ -465,9 +478,10 @@ static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVid
     g_rec_mutex_unlock(&f->mutex);
     return GST_FLOW_OK;                                     /* always: FACE/kmsfacedetect.cpp:897 */
 }
+NVCA_GST_CATCH("nvca_face_transform_frame_ip", GST_FLOW_OK)
 
 static void nvca_face_finalize(GObject *o)
-{
+try {
     NvcaFace *f = (NvcaFace *)o;
     if (getenv("NVCA_GST_STATS") && f->slot) {
         std::lock_guard<std::mutex> lk(f->slot->face_q.m);
@@ -481,15 +495,17 @@ static void nvca_face_finalize(GObject *o)
     g_rec_mutex_clear(&f->mutex);
     G_OBJECT_CLASS(nvca_face_parent_class)->finalize(o);
 }
+NVCA_GST_CATCH_VOID("nvca_face_finalize")
 
 static void nvca_face_init(NvcaFace *f)
-{
+try {
     nvca_face_params_default(&f->p);                        /* defaults of FACE/kmsfacedetect.cpp:979-999 */
     f->view_faces = 0; f->send_meta_data = 0; f->server_events = 0; f->events_ms = 30001; f->time_events_ms = 0;
     f->cascade = nullptr; f->stream = nullptr; f->image_to_overlay = nullptr;
     f->events_queue = g_queue_new();
     g_rec_mutex_init(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_face_init")
 
 #define INT_PROP(klass, id, name, nick, blurb, lo, hi) \
     g_object_class_install_property(klass, id, g_param_spec_int(name, nick, blurb, lo, hi, 0, (GParamFlags)G_PARAM_READWRITE))
@@ -543,7 +559,7 @@ enum { TP_0, TP_THRESHOLD, TP_MIN_AREA, TP_MAX_AREA, TP_DISTANCE, TP_VISUAL, TP_
 static guint trk_signal = 0;
 
 static void nvca_trk_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
-{
+try {
     NvcaTrk *t = (NvcaTrk *)o;
     g_rec_mutex_lock(&t->mutex);
     switch (id) {
@@ -559,8 +575,9 @@ static void nvca_trk_set_property(GObject *o, guint id, const GValue *v, GParamS
     if (t->trk) nvca_tracker_set_params(t->trk, &t->p);
     g_rec_mutex_unlock(&t->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_trk_set_property")
 static void nvca_trk_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
-{
+try {
     NvcaTrk *t = (NvcaTrk *)o;
     g_rec_mutex_lock(&t->mutex);
     switch (id) {
@@ -575,9 +592,10 @@ static void nvca_trk_get_property(GObject *o, guint id, GValue *v, GParamSpec *p
     }
     g_rec_mutex_unlock(&t->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_trk_get_property")
 
 static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
-{
+try {
     NvcaTrk *t = (NvcaTrk *)filter;
     g_rec_mutex_lock(&t->mutex);
     if (!t->trk) { if (!t->slot) t->slot = take_slot(); nvca_ctx *ctx = t->slot->ctx; if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
@@ -619,9 +637,10 @@ static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVide
     g_rec_mutex_unlock(&t->mutex);
     return GST_FLOW_OK;
 }
+NVCA_GST_CATCH("nvca_trk_transform_frame_ip", GST_FLOW_OK)
 
 static void nvca_trk_finalize(GObject *o)
-{
+try {
     NvcaTrk *t = (NvcaTrk *)o;
     if (getenv("NVCA_GST_STATS") && t->slot) {
         std::lock_guard<std::mutex> lk(t->slot->trk_q.m);
@@ -631,12 +650,14 @@ static void nvca_trk_finalize(GObject *o)
     g_rec_mutex_clear(&t->mutex);
     G_OBJECT_CLASS(nvca_trk_parent_class)->finalize(o);
 }
+NVCA_GST_CATCH_VOID("nvca_trk_finalize")
 static void nvca_trk_init(NvcaTrk *t)
-{
+try {
     nvca_tracker_params_default(&t->p);                     /* TRK/gstnubotracker.cpp:457-466 */
     t->visual_mode = 0; t->server_events = 0; t->events_ms = 30001; t->time_events_ms = 0; t->trk = nullptr;
     g_rec_mutex_init(&t->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_trk_init")
 static void nvca_trk_class_init(NvcaTrkClass *klass)
 {
     GObjectClass *go = G_OBJECT_CLASS(klass);
@@ -694,7 +715,7 @@ struct NvcaPartClass { GstVideoFilterClass parent; PartDesc *desc; };
 enum { PP_0, PP_VIEW, PP_DETECT_EVENT, PP_META, PP_WIDTH, PP_X_EVERY_4, PP_SCALE, PP_EVENTS, PP_EVENTS_MS, PP_OVERLAY };
 
 static void nvca_part_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
-{
+try {
     NvcaPart *f = (NvcaPart *)o;
     g_rec_mutex_lock(&f->mutex);
     switch (id) {
@@ -715,8 +736,9 @@ static void nvca_part_set_property(GObject *o, guint id, const GValue *v, GParam
     if (f->stream) nvca_part_stream_set_params(f->stream, &f->p);
     g_rec_mutex_unlock(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_part_set_property")
 static void nvca_part_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
-{
+try {
     NvcaPart *f = (NvcaPart *)o;
     g_rec_mutex_lock(&f->mutex);
     switch (id) {
@@ -733,6 +755,7 @@ static void nvca_part_get_property(GObject *o, guint id, GValue *v, GParamSpec *
     }
     g_rec_mutex_unlock(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_part_get_property")
 
 static void part_lazy_init(NvcaPart *f)
 {
@@ -755,7 +778,7 @@ static void part_lazy_init(NvcaPart *f)
 
 // faces handed over by an upstream element (EYE/kmseyedetect.cpp:680-724): sub-structures whose type == "face"
 static gboolean nvca_part_sink_event(GstBaseTransform *trans, GstEvent *event)
-{
+try {
     NvcaPart *f = (NvcaPart *)trans;
     if (GST_EVENT_TYPE(event) == GST_EVENT_CUSTOM_DOWNSTREAM && f->desc->kind != NVCA_PART_EAR) {
         const GstStructure *m = gst_event_get_structure(event);
@@ -783,6 +806,7 @@ static gboolean nvca_part_sink_event(GstBaseTransform *trans, GstEvent *event)
     }
     return GST_BASE_TRANSFORM_CLASS(f->desc->parent_class)->sink_event(trans, event);
 }
+NVCA_GST_CATCH("nvca_part_sink_event", FALSE)
 
 static void add_box(GstStructure *message, const char *sname, const char *type, int idx, const nvca_rect &r, int mul)
 {
@@ -799,7 +823,7 @@ static std::string box_str(const nvca_rect &r)
 }
 
 static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
-{
+try {
     NvcaPart *f = (NvcaPart *)filter;
     g_rec_mutex_lock(&f->mutex);
     part_lazy_init(f);
@@ -884,9 +908,10 @@ static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVid
     g_rec_mutex_unlock(&f->mutex);
     return GST_FLOW_OK;
 }
+NVCA_GST_CATCH("nvca_part_transform_frame_ip", GST_FLOW_OK)
 
 static void nvca_part_finalize(GObject *o)
-{
+try {
     NvcaPart *f = (NvcaPart *)o;
     if (getenv("NVCA_GST_STATS") && f->slot) {
         std::lock_guard<std::mutex> lk(f->slot->part_q.m);
@@ -900,8 +925,9 @@ static void nvca_part_finalize(GObject *o)
     g_rec_mutex_clear(&f->mutex);
     G_OBJECT_CLASS(f->desc->parent_class)->finalize(o);
 }
+NVCA_GST_CATCH_VOID("nvca_part_finalize")
 static void nvca_part_instance_init(GTypeInstance *inst, gpointer klass)
-{
+try {
     NvcaPart *f = (NvcaPart *)inst;
     f->desc = ((NvcaPartClass *)klass)->desc;
     nvca_part_params_default(&f->p, f->desc->kind);      /* width-to-process 320, process 4 of 4, scale factor 25 */
@@ -909,6 +935,7 @@ static void nvca_part_instance_init(GTypeInstance *inst, gpointer klass)
     f->cf = f->ca = f->cb = nullptr; f->stream = nullptr; f->image_to_overlay = nullptr;
     g_rec_mutex_init(&f->mutex);
 }
+NVCA_GST_CATCH_VOID("nvca_part_instance_init")
 static void nvca_part_class_init(gpointer klass, gpointer class_data)
 {
     PartDesc *d = (PartDesc *)class_data;

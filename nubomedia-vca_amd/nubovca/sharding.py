@@ -12,30 +12,39 @@ def streams_of_rank(n_streams, world, rank):
     return [s for s in range(n_streams) if s % world == rank]
 
 
-def pack_boxes(results, max_boxes):
-    """results: list of (boxes[n,4], ids[n]) per local stream -> int32 [n_local, 1 + 4*max_boxes]"""
+RANK_SHIFT = 16          # column 0 of a row: box count in the low 16 bits, the producing rank above them
+
+
+def pack_boxes(results, max_boxes, rank=0):
+    """results: list of (boxes[n,4], ids[n]) per local stream -> int32 [n_local, 1 + 4*max_boxes]; every row is stamped with
+    the rank that produced it (the gathered table then shows which ranks took part)"""
     tab = np.zeros((len(results), 1 + 4 * max_boxes), np.int32)
     for i, (b, _) in enumerate(results):
         n = min(len(b), max_boxes)
-        tab[i, 0] = n
+        tab[i, 0] = n | (rank << RANK_SHIFT)
         tab[i, 1:1 + 4 * n] = np.asarray(b[:n], np.int32).reshape(-1)
     return tab
 
 
-def pack_box_arrays(boxes, counts, out=None):
+def pack_box_arrays(boxes, counts, out=None, rank=0):
     """the same table from the batched call's raw result arrays (boxes int32 [n, cap, 4], counts int32 [n]) without
     per-stream python work; entries past a stream's count are zeroed like pack_boxes leaves them"""
     n, cap = boxes.shape[0], boxes.shape[1]
     tab = out if out is not None else np.empty((n, 1 + 4 * cap), np.int32)
     k = np.minimum(counts, cap)
-    tab[:, 0] = k
+    tab[:, 0] = k | (rank << RANK_SHIFT)
     live = (np.arange(cap, dtype=np.int32)[None, :] < k[:, None])
     np.multiply(boxes, live[:, :, None], out=tab[:, 1:].reshape(n, cap, 4))
     return tab
 
 
 def unpack_boxes(tab):
-    return [np.asarray(row[1:1 + 4 * int(row[0])], np.int32).reshape(-1, 4) for row in np.asarray(tab)]
+    return [np.asarray(row[1:1 + 4 * (int(row[0]) & 0xffff)], np.int32).reshape(-1, 4) for row in np.asarray(tab)]
+
+
+def table_ranks(gathered):
+    """the rank stamp of every row of a gathered [world, n_local, cols] table"""
+    return np.asarray(gathered)[..., 0] >> RANK_SHIFT
 
 
 def gather_tables(local_tab, device=None):

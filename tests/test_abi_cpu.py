@@ -140,3 +140,13 @@ def test_loader_refuses_garbage_with_a_code(lib):
         rc, _, _ = _validate(lib, bytes(b))
         assert rc in (0, PARSE, UNSUP, -8, -9), rc
     assert lib.nvca_cascade_validate_mem(None, 5, None, None, None, None, None, 0) == -1
+
+
+def test_loader_reads_the_handwritten_oldformat_files(lib):
+    """tests/golden/oldformat_*.xml are written by hand in cvSave's layout (every other XML the loader sees comes out of
+    synth.cascade_to_xml): shapes through the ABI on the host; the values are compared on the GPU box (nvca_cascade_dump)"""
+    gold = os.path.join(ROOT, "tests", "golden")
+    rc, shape, err = _validate(lib, open(os.path.join(gold, "oldformat_stumps_24x24.xml")).read())
+    assert rc == 0 and shape == (24, 24, 3, 7), (rc, shape, err)
+    rc, shape, err = _validate(lib, open(os.path.join(gold, "oldformat_trees_tilted_20x20.xml")).read())
+    assert rc == 0 and shape == (20, 20, 2, 4), (rc, shape, err)

@@ -39,8 +39,9 @@ def _worker(rank, world, port, xml, q):
     merged = []
     tg = sharding.TableGather()            # the asynchronous gather bench.py uses: tick k completes when tick k+1 is handed in
     for i in range(N_FRAMES):
-        tab = sharding.pack_boxes([res[s][i] for s in mine], MAXB)
+        tab = sharding.pack_boxes([res[s][i] for s in mine], MAXB, rank=rank)
         g = sharding.gather_tables(tab)
+        assert all((sharding.table_ranks(g)[r] == r).all() for r in range(world))       # every rank's rows arrived, stamped, in rank order
         merged.append(sharding.merge_by_stream(g, N_STREAMS, world))
         tg.submit(tab)
         if i > 0:
@@ -102,3 +103,65 @@ def test_pack_box_arrays_equals_pack_boxes():
     counts = np.array([0, 3, 8, 12, 1, 7], np.int32)                 # 12 > cap: clipped like the C call reports it
     res = [(boxes[i, :min(counts[i], cap)].copy(), None) for i in range(n)]
     assert np.array_equal(sharding.pack_boxes(res, cap), sharding.pack_box_arrays(boxes, counts))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` as the driver types it: a launcher parent that starts N ranks (one process per GPU)
+_STUB = """
+import json, os, sys
+d = os.environ["NVCA_STUB_DIR"]
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+open(os.path.join(d, "rank%d.json" % r), "w").write(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"argv": sys.argv[1:]}))
+if r == 0:
+    print("noise before the line")
+    print(json.dumps({"metric": "stub", "n_gpus": w, "ranks_seen": list(range(w))}))
+sys.exit(int(os.environ.get("NVCA_STUB_FAIL_RANK", "-1")) == r and 3 or 0)
+"""
+
+
+def _launch(tmp_path, n, extra_env=None):
+    import json
+    import subprocess
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB)
+    env = dict(os.environ, NVCA_BENCH_CHILD_CMD="%s %s" % (sys.executable, stub), NVCA_STUB_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    ranks = [json.loads((tmp_path / ("rank%d.json" % k)).read_text()) for k in range(n) if (tmp_path / ("rank%d.json" % k)).exists()]
+    return r, ranks
+
+
+def test_bench_gpus_n_launches_n_ranks(tmp_path):
+    import json
+    r, ranks = _launch(tmp_path, 4)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE JSON line: rank 0's, relayed; nothing else on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["ranks_seen"] == [0, 1, 2, 3]
+    assert len(ranks) == 4 and sorted(int(k["RANK"]) for k in ranks) == [0, 1, 2, 3]
+    assert all(k["WORLD_SIZE"] == "4" and k["MASTER_ADDR"] == "127.0.0.1" and k["LOCAL_RANK"] == k["RANK"] for k in ranks)
+    assert len(set(k["MASTER_PORT"] for k in ranks)) == 1
+    assert all(k["argv"] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] for k in ranks)      # the ranks get the same command line
+
+
+def test_bench_launcher_reports_the_worst_rank(tmp_path):
+    r, ranks = _launch(tmp_path, 3, {"NVCA_STUB_FAIL_RANK": "2"})
+    assert r.returncode == 3 and len(ranks) == 3
+    assert "rank exit codes" in r.stderr
+
+
+def test_bench_launcher_parent_touches_no_gpu_stack(tmp_path):
+    """the parent of `--gpus N` must not initialise the GPU (a forked / exec'ing process that has would take the box down):
+    it does not even import torch or the library"""
+    code = ("import sys, runpy, os\n"
+            "sys.argv = ['bench.py', '--gpus', '2']\n"
+            "os.environ['NVCA_BENCH_CHILD_CMD'] = sys.executable + ' -c pass'\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit:\n    pass\n"
+            "assert 'torch' not in sys.modules and 'nubovca.capi' not in sys.modules, sorted(m for m in sys.modules if 'torch' in m)[:5]\n" % os.path.join(ROOT, "bench.py"))
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr

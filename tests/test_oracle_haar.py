@@ -203,3 +203,43 @@ def test_generic_cascade_all_scan_variants_run():
     assert len(raw) > 5 and st.stumps > 10 * st.windows
     assert len(orc.detect_raw(oc, img, 1.2, orc.HAAR_SCALE_IMAGE)) > 5
     assert len(orc.detect_multiscale(oc, img, 1.2, 2, orc.HAAR_FIND_BIGGEST_OBJECT, (1, 1))) == 1
+
+
+# ------------------------------------------------------------------ hand-written old-format files (tests/golden/oldformat_*.xml)
+def _golden(name):
+    import os
+    return open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)).read()
+
+
+def test_oldformat_stump_file_known_answers():
+    """a file in cvSave's exact layout (comment block ahead of the root, closing tags glued to the last child, "-1." / "3."
+    weights, three-digit exponents) -- not one written by synth.cascade_to_xml: what the loader must read out of it"""
+    import orc
+    c = orc.parse_cascade_xml(_golden("oldformat_stumps_24x24.xml"))
+    assert (c.ow, c.oh) == (24, 24)
+    assert list(c.stage_ncls) == [2, 3, 2] and list(c.cls_nnodes) == [1] * 7
+    assert np.allclose(c.stage_thr, np.float32([-0.6000000238418579, -0.8125, -0.5625]), rtol=0, atol=0)
+    assert np.array_equal(c.rects[0], [[4, 6, 16, 6], [4, 9, 16, 3], [0, 0, 0, 0]]) and list(c.rweights[0]) == [-1.0, 2.0, 0.0]
+    assert np.array_equal(c.rects[2], [[2, 4, 20, 12], [2, 4, 10, 6], [12, 10, 10, 6]]) and list(c.rweights[2]) == [-1.0, 2.0, 2.0]
+    assert list(c.rweights[1]) == [-1.0, 3.0, 0.0]
+    assert c.node_thr[0] == np.float32(2.5e-3) and c.node_thr[1] == np.float32(-1.25e-2) and c.node_thr[5] == np.float32(1.0000000474974513e-3)
+    assert list(c.left) == [0] * 7 and list(c.right) == [-1] * 7                 # leaves: alpha[0], alpha[1] of each stump
+    assert list(c.alpha[:4]) == [-0.75, 0.625, 0.5, -0.375] and len(c.alpha) == 14
+    assert not c.tilted.any()
+
+
+def test_oldformat_tree_file_known_answers():
+    """<left_node> / <right_node> trees and <tilted>1</tilted>: child indices and leaf numbering as icvReadHaarClassifier
+    assigns them (a leaf becomes alpha[last++] with child index -last)"""
+    import orc
+    c = orc.parse_cascade_xml(_golden("oldformat_trees_tilted_20x20.xml"))
+    assert (c.ow, c.oh) == (20, 20) and list(c.stage_ncls) == [2, 2] and list(c.cls_nnodes) == [2, 1, 3, 2]
+    assert list(c.tilted) == [0, 1, 1, 0, 0, 1, 0, 0]
+    assert list(c.left) == [1, -1, 0, 1, 0, -2, 0, -1] and list(c.right) == [0, -2, -1, 2, -1, -3, 1, -2]
+    assert list(c.alpha) == [0.5, -0.625, 0.125, 0.375, -0.375, -0.4375, 0.3125, 0.5625, -0.1875, 0.25, -0.3125, 0.4375]
+    assert np.array_equal(c.rects[1][:2], [[8, 2, 6, 3], [8, 2, 3, 3]])
+    # and it evaluates: every scan variant runs, the lenient two-stage cascade lets windows through
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(120, 90, 5, "natural"))
+    assert len(orc.detect_raw(c, g, 1.2, 0, (0, 0))) > 0
+    assert len(orc.detect_raw(c, g, 1.2, orc.HAAR_SCALE_IMAGE, (0, 0))) > 0
