@@ -179,6 +179,20 @@ int nvca_flip_horizontal(nvca_ctx *ctx, const void *src_gray, int w, int h, int 
 #define NVCA_SHAPE_RING4 1
 typedef struct { int kind; int x, y, w, h; uint8_t bgra[4]; } nvca_shape;
 int nvca_draw_shapes(nvca_ctx *ctx, const nvca_frame *frame, int channels, const nvca_shape *shapes, int n);
+/* image-to-overlay: kms_face_detect_display_detections_overlay_img, FACE/kmsfacedetect.cpp:427-502 -- for every
+ * box, in order, the overlay image is scaled (cvResize, CV_INTER_LINEAR) to (box.w * width_percent) x (box.h * height_percent),
+ * placed at box.x + box.w * offset_x_percent, box.y + box.h * offset_y_percent (truncated as the reference's int arithmetic does)
+ * and written onto the BGR frame where it lies inside it: 1 channel -> copied to B, G and R; 3 channels -> copied; 4 channels ->
+ * blended per pixel with weight alpha / 255 in double arithmetic, truncated to 8 bits.  Boxes are frame pixels (the reference
+ * passes box * scale, :840-844).  The image (what cvLoadImage(..., CV_LOAD_IMAGE_UNCHANGED) returned: fetching and decoding it
+ * stay with the element) is host memory; the frame may be host memory (plain loops, ctx may be NULL) or device memory (one kernel
+ * per box; a viewed stream that stays in HBM makes no round trip).  A box whose scaled size is not positive is skipped (the
+ * reference's cvCreateImage would throw there). */
+typedef struct nvca_overlay {
+    const void *data; int width, height, stride, channels;       /* 8-bit, 1 / 3 / 4 interleaved channels, host memory */
+    double offset_x_percent, offset_y_percent, width_percent, height_percent;   /* the image-to-overlay structure's fields, :351-367 */
+} nvca_overlay;
+int nvca_overlay_blend(nvca_ctx *ctx, const nvca_frame *frame_bgr, const nvca_rect *boxes, int n, const nvca_overlay *overlay);
 /* cv::integral as used inside detectMultiScale: sum int32 and sqsum float64,
  * both dense (h+1)*(w+1) */
 int nvca_integral(nvca_ctx *ctx, const void *src_gray, int w, int h, int stride, int mem,

@@ -719,6 +719,7 @@ nvca_ctx::~nvca_ctx()
     trk.release_all();
     part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
+    overlay_img.release();
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
@@ -1246,6 +1247,39 @@ try {
     if ((rc = part_table(ctx, shapes, (size_t)n * sizeof(nvca_shape), &d_shapes))) return rc;
     launch_draw_shapes(ctx->cs(), (uint8_t *)frame->data, frame->width, frame->height, frame->stride, channels, (const nvca_shape *)d_shapes, n, bx0, by0, bx1, by1);
     return finish_device_op(ctx);
+}
+NVCA_API_CATCH(ctx)
+
+int nvca_overlay_blend(nvca_ctx *ctx, const nvca_frame *frame, const nvca_rect *boxes, int n, const nvca_overlay *ov)
+try {
+    const bool host = frame && frame->mem == NVCA_MEM_HOST;
+    if (!frame || !ov || (!ctx && !host) || n < 0 || (n > 0 && !boxes) || n > 1024) return NVCA_ERR_ARG;
+    if (!frame->data || frame->width <= 0 || frame->height <= 0 || frame->stride < frame->width * 3 || (frame->mem != NVCA_MEM_HOST && frame->mem != NVCA_MEM_DEVICE)) return NVCA_ERR_ARG;
+    if (!ov->data || ov->width <= 0 || ov->height <= 0 || (ov->channels != 1 && ov->channels != 3 && ov->channels != 4) || ov->stride < ov->width * ov->channels ||
+        ov->width > 8192 || ov->height > 8192) return NVCA_ERR_ARG;
+    if (!(std::fabs(ov->offset_x_percent) <= 64 && std::fabs(ov->offset_y_percent) <= 64 && ov->width_percent >= 0 && ov->width_percent <= 64 && ov->height_percent >= 0 && ov->height_percent <= 64)) return NVCA_ERR_ARG;
+    for (int i = 0; i < n; i++)
+        if (std::abs((long long)boxes[i].x) > (1 << 20) || std::abs((long long)boxes[i].y) > (1 << 20) || boxes[i].w < 0 || boxes[i].h < 0 || boxes[i].w > (1 << 14) || boxes[i].h > (1 << 14)) return NVCA_ERR_ARG;
+    if (!n || ov->height_percent == 0 || ov->width_percent == 0) return NVCA_OK;           // FACE/kmsfacedetect.cpp:436-439
+    if (host) { overlay_blend_host((uint8_t *)frame->data, frame->width, frame->height, frame->stride, boxes, n, *ov); return NVCA_OK; }
+    NVCA_LOCK_OR_FAIL(ctx);
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    const size_t bytes = (size_t)ov->stride * (ov->height - 1) + (size_t)ov->width * ov->channels;
+    if (ctx->overlay_img.ensure(bytes + 64)) { ctx->set_error("allocation failed (overlay image)"); return NVCA_ERR_NOMEM; }
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->overlay_img.p, ov->data, bytes, hipMemcpyHostToDevice, ctx->cs()));
+    for (int b = 0; b < n; b++) {            // in order: a later box overwrites an earlier one where they overlap
+        const OverlayPlace p = overlay_place(boxes[b], *ov);
+        if (p.w <= 0 || p.h <= 0) continue;
+        GeomPlan *gp = nullptr;
+        if ((rc = get_resize_plan(ctx, ov->width, ov->height, p.w, p.h, &gp))) return rc;
+        launch_overlay(ctx->cs(), (uint8_t *)frame->data, frame->width, frame->height, frame->stride, p, ctx->overlay_img.as<uint8_t>(), ov->height, ov->stride, ov->channels,
+                       gp->tab.mode, gp->d_xofs.as<int>(), gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(), gp->tab.xmax);
+    }
+    // the image is the caller's: the upload must have left it before the call returns
+    NVCA_LAUNCH_CHECK(ctx);
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+    return NVCA_OK;
 }
 NVCA_API_CATCH(ctx)
 

@@ -275,4 +275,29 @@ void to_global(RectV &v, const nvca_rect &face, int scale)
 }
 
 
+// ------------------------------------------------------------ image-to-overlay on a host frame
+// kms_face_detect_display_detections_overlay_img (FACE/kmsfacedetect.cpp:427-502) for every box in order; the arithmetic
+// is nvca_internal.h's resize_sample_cn / overlay_pixel, shared with the kernel
+void overlay_blend_host(uint8_t *frame, int W, int H, int stride, const nvca_rect *boxes, int n, const nvca_overlay &ov)
+{
+    if (ov.height_percent == 0 || ov.width_percent == 0) return;           // :436-439
+    const uint8_t *img = (const uint8_t *)ov.data;
+    for (int b = 0; b < n; b++) {
+        const OverlayPlace p = overlay_place(boxes[b], ov);
+        if (p.w <= 0 || p.h <= 0) continue;
+        ResizeTab tab;
+        build_resize_tab(ov.width, ov.height, p.w, p.h, tab);
+        for (int h = 0; h < p.h; h++) {
+            if (h + p.y < 0 || h + p.y >= H) continue;
+            for (int w = 0; w < p.w; w++) {
+                if (w + p.x < 0 || w + p.x >= W) continue;
+                int v[4] = {0, 0, 0, 0};
+                for (int k = 0; k < ov.channels; k++)
+                    v[k] = resize_sample_cn(img, ov.height, ov.stride, ov.channels, tab.mode, tab.xofs.data(), tab.ialpha.data(), tab.yofs.data(), tab.ibeta.data(), tab.xmax, w, h, k);
+                overlay_pixel(frame + (size_t)(h + p.y) * stride + (size_t)(w + p.x) * 3, v, ov.channels);
+            }
+        }
+    }
+}
+
 } // namespace nvca

@@ -668,10 +668,30 @@ __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, 
 // deep list / the candidates.  VNF_LDS: the variance normaliser comes from L.vnf_s (band kernel, which also has to
 // publish it for k_deep) instead of the stage-0 pre-pass's global array.  Ends with every thread past its last LDS use
 // of the queues only after the caller's next barrier.
+// Integer-vote stages (StageRec flag bit 2: every vote an exact multiple of 2^vote_exp, every sum below 2^31 of them -- proven
+// per stage in plan.cpp -- so any order and any grouping of the additions is bit for bit the f64 sum OpenCV forms).
+//   * The stage's work is the nw x C grid (64-window groups of the padded queue) x (stumps); it is dealt to the 16 waves
+//     as equal contiguous runs of (group, stump) items, whatever n and C are: no wave idles while another walks a longer
+//     partition (split-K by whole partitions left 4 of 16 waves idle at 374 windows, and ran 6 / 5 / 5 / 5 stumps at 21).
+//   * A wave adds its run's sum to the window's accumulator in LDS (ds_add: integer, hence exact in any order): no partial-sum
+//     table, no serial add-up by one thread.
+//   * Two consecutive such stages are evaluated in ONE pass (stage s + 1 speculatively for the windows that stage s will turn
+//     out to reject -- no side effects, the same pass / fail per stage) when the previous tile of the band saw at least 3/4 of
+//     stage s's windows survive it: the re-queue, its barrier and the wait for the slowest wave are paid once for both.
+//     Which stages are fused never changes a result.
+// acc: 2 ints per queue slot in the (otherwise partial-sum) region at the start of the tile's LDS, all zero outside a stage.
+// Survivor counts per stage live in two sets of kStatStages words behind the queue counters (qn[4 ..]): a tile reads the set
+// the previous tile of its band wrote (par) and writes the other one, which the band kernel zeroes at the top of the tile --
+// every wave therefore takes the same fusion decisions from words nobody writes during the tile.
+static constexpr int kStatStages = 6;         // stages 0 .. 5: the early stages of the default split (deep_stage 6)
 template <bool VNF_LDS>
-__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0)
+__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0, int par = 0)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int *stat_r = L.qn + 4 + par * kStatStages;       // what the previous tile saw
+    int *stat_w = L.qn + 4 + (par ^ 1) * kStatStages;       // what this tile sees
+    constexpr int NW = kTileThreads / 64;
     const TStumpRec *urecs = sc.trecs;
     const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
     const double *__restrict__ vnfp = a.vnf + vbase;
@@ -680,12 +700,14 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         const int ix = t.ix0 + (w & 31);
         return vnfp[((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
     };
+    int *acc = (int *)L.psum;
     int cur = 0;
-    // queue counters rotate over three words: stage s reads qn[cin], appends to qn[cout] and clears the third one, which
+    // queue counters rotate over three words: a stage reads qn[cin], appends to qn[cout] and clears the third one, which
     // nobody touches during this stage and which the next stage appends to -- one barrier per stage instead of two
     int cin = 0;
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    for (int s = 1; s < last; s++) {
+    int s = 1;
+    while (s < last) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
         NVCA_STAMP(a, ti, 8 + 8 * s);
         const int n = L.qn[cin];
@@ -699,63 +721,80 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         unsigned short *qo = L.q0 + (cur ^ 1) * kTileWin * kTileWin;
         const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
-        if ((st.flags & 2) && n <= kTileThreads / 2) {
-            // few survivors and an order-free stage sum: thread = (window slot i, stump partition p).  A partition is a
-            // whole number of waves (the queue padded to a multiple of 64), so stump records stay wave-uniform (scalar loads)
-            const int nw = (n + 63) >> 6, npad = nw << 6;
-            int P = (kTileThreads / 64) / nw;
-            if (P > st.count) P = st.count;
-            if (P > 16) P = 16;              // the partial sums of a window are added up by one thread
-            const int p = __builtin_amdgcn_readfirstlane((tid >> 6) / nw), i = tid - p * npad;
-            const bool ivote = (st.flags & 4) != 0;          // integer votes: the partial sums travel as 32-bit integers
-            double part = 0.0; int parti = 0;
-            if (i < n && p < P) {
-                const int w = qi[i];
-                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
-                const double vnf = vnf_of(w);
-                const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
-                if (ivote) parti = pair ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + st.first, p, st.count, P) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + st.first, p, st.count, P);
-                else part = pair ? tile_stage_sum<true>(cm, rm, vnf, urecs + st.first, p, st.count, P) : tile_stage_sum<false>(cm, rm, vnf, urecs + st.first, p, st.count, P);
+        int adv = 1;
+        if (st.flags & 4) {
+            // ---- integer votes: balanced runs over (window group, stump), LDS accumulators, optional fusion with stage s + 1
+            bool fuse = false;
+            int first2 = 0, count2 = 0, thr2 = 0; bool pair2 = false;
+            if (s + 1 < last && s + 1 < kStatStages) {
+                const int seen_s = stat_r[s], seen_n = stat_r[s + 1];          // 0: no tile yet
+                if (seen_s > 0 && 4 * seen_n >= 3 * seen_s) {
+                    const StageRec st2 = load_const(a.stages + s + 1);
+                    fuse = (st2.flags & 4) != 0;
+                    first2 = st2.first; count2 = st2.count; thr2 = st2.thr_i; pair2 = a.pair_policy && (st2.flags & 1);
+                }
+            }
+            const int Ca = st.count, C = fuse ? Ca + count2 : Ca;
+            const int nw = (n + 63) >> 6, items = nw * C, K = (items + NW - 1) / NW;
+            int e = wave * K;
+            const int e1 = e + K < items ? e + K : items;
+            while (e < e1) {                       // at most two window groups per wave (K <= C), wave-uniform
+                const int wg = e / C, c0 = e - wg * C, c1 = (C - c0 < e1 - e) ? C : c0 + (e1 - e);
+                const int i = wg * 64 + lane;
+                if (i < n) {
+                    const int w = qi[i];
+                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                    const double vnf = vnf_of(w);
+                    const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
+                    if (c0 < Ca) {
+                        const int hi = c1 < Ca ? c1 : Ca;
+                        const int v = pair ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + st.first, c0, hi, 1) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + st.first, c0, hi, 1);
+                        atomicAdd(&acc[2 * i], v);
+                    }
+                    if (c1 > Ca) {
+                        const int lo = c0 > Ca ? c0 - Ca : 0;
+                        const int v = pair2 ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + first2, lo, c1 - Ca, 1) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + first2, lo, c1 - Ca, 1);
+                        atomicAdd(&acc[2 * i + 1], v);
+                    }
+                }
+                e += c1 - c0;
             }
             NVCA_STAMP(a, ti, 8 + 8 * s + 1);
-            int *psi = (int *)L.psum;
-            if (ivote) psi[tid] = parti; else L.psum[tid] = part;
             __syncthreads();
             NVCA_STAMP(a, ti, 8 + 8 * s + 2);
-            bool pass = false; int w = 0;
+            bool pass = false, pass_a = false; int w = 0;
             if (tid < n) {
-                if (ivote) {
-                    int tot = 0, pp = 0;
-                    for (; pp + 4 <= P; pp += 4) tot += psi[pp * npad + tid] + psi[(pp + 1) * npad + tid] + psi[(pp + 2) * npad + tid] + psi[(pp + 3) * npad + tid];
-                    for (; pp < P; pp++) tot += psi[pp * npad + tid];
-                    pass = tot >= st.thr_i;
-                } else {
-                    double tot = 0.0;
-                    int pp = 0;
-                    for (; pp + 4 <= P; pp += 4) {       // four independent reads in flight; any order of the adds is exact here
-                        const double d0 = L.psum[pp * npad + tid], d1 = L.psum[(pp + 1) * npad + tid], d2 = L.psum[(pp + 2) * npad + tid], d3 = L.psum[(pp + 3) * npad + tid];
-                        tot += d0; tot += d1; tot += d2; tot += d3;
-                    }
-                    for (; pp < P; pp++) tot += L.psum[pp * npad + tid];
-                    pass = !(tot < (double)st.thr);
-                }
+                const int sa = acc[2 * tid], sb = acc[2 * tid + 1];
+                acc[2 * tid] = 0; acc[2 * tid + 1] = 0;
+                pass_a = sa >= st.thr_i;
+                pass = pass_a && (!fuse || sb >= thr2);
                 w = qi[tid];
             }
-            queue_push(pass, w, qo, &L.qn[cout]);
-            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
-        } else
-        for (int base = 0; base < n; base += kTileThreads) {
-            const int i = base + tid;
-            bool pass = false; int w = 0;
-            if (i < n) {
-                w = qi[i];
-                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
-                const double vnf = vnf_of(w);
-                pass = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, urecs, st, pair);
+            if (s < kStatStages && tid == 0) stat_w[s] = n;
+            if (fuse && s + 1 < kStatStages) {     // stage s + 1 has no queue of its own this time: count who would have entered it
+                const unsigned long long am = __ballot(pass_a);
+                if (lane == 0 && am) atomicAdd(&stat_w[s + 1], (int)__popcll(am));
             }
             queue_push(pass, w, qo, &L.qn[cout]);
+            if (fuse) adv = 2;
+            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
+        } else {
+            // votes that are not exact integers of a common unit (StageRec flag bit 2 clear: not seen with f32 votes below 128
+            // stumps a stage): window per thread, the stage's stumps in OpenCV's order
+            for (int base = 0; base < n; base += kTileThreads) {
+                const int i = base + tid;
+                bool pass = false; int w = 0;
+                if (i < n) {
+                    w = qi[i];
+                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                    const double vnf = vnf_of(w);
+                    pass = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, urecs, st, pair);
+                }
+                queue_push(pass, w, qo, &L.qn[cout]);
+            }
+            if (tid == 0 && s < kStatStages) stat_w[s] = n;
         }
-        cur ^= 1; cin = cout;
+        cur ^= 1; cin = cout; s += adv;
     }
     __syncthreads();
     NVCA_STAMP(a, ti, 6);
@@ -789,6 +828,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileLds L = carve_tile(lds, t);
     const TileCoords tc = tile_coords(a, t, sc);
     tile_commit(a, t, sc, slot, L, tc);
+    { int *acc = (int *)L.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0; if (tid < 2 * kStatStages) L.qn[4 + tid] = 0; }     // stage accumulators, no band history
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
     __syncthreads();                 // qn zeroed, maps and samples staged
@@ -837,6 +877,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         const TileRec t0 = load_const(a.tiles + b.first_tile);
         const TileLds L0 = carve_tile(lds, t0);
         if (tid < kTileWin) L0.carry[tid] = 0;
+        int *acc = (int *)L0.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;          // stage accumulators (tile_stages)
+        if (tid < 2 * kStatStages) L0.qn[4 + tid] = 0;                                  // no tile seen yet
     }
     static_assert(kTileWin * kTileWin == kTileThreads, "one window per thread and tile");
     const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band
@@ -861,6 +903,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         }
         NVCA_STAMP(a, ti, 1);
         tile_commit(a, t, sc, slot, L, tc);
+        if (tid < kStatStages) L.qn[4 + ((ti + 1) & 1) * kStatStages + tid] = 0;       // the survivor counts this tile will write
         NVCA_STAMP(a, ti, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
         __syncthreads();
@@ -919,7 +962,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             L.carry[tid] = ones == t.nx ? ((t.nx + L.carry[tid]) & 1) : (ones & 1);
         }
         NVCA_STAMP(a, ti, 5);
-        tile_stages<true>(a, t, sc, slot, L, ti);
+        tile_stages<true>(a, t, sc, slot, L, ti, ti & 1);
     }
 }
 

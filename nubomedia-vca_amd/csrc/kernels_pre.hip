@@ -256,6 +256,23 @@ void launch_resize3(hipStream_t st, const uint8_t *src, int sw, int sh, int sstr
                        dst, dw, dh, dstride);
 }
 
+// ---- image-to-overlay on a device frame: one thread per pixel of the scaled overlay image of one box
+__global__ __launch_bounds__(256) void k_overlay(uint8_t *__restrict__ frame, int W, int H, int stride, OverlayPlace p, const uint8_t *__restrict__ img,
+                                                 int ih, int istride, int cn, int mode, const int *__restrict__ xofs, const short *__restrict__ ialpha,
+                                                 const int *__restrict__ yofs, const short *__restrict__ ibeta, int xmax)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+    if (w >= p.w || h >= p.h || w + p.x < 0 || w + p.x >= W || h + p.y < 0 || h + p.y >= H) return;
+    int v[4] = {0, 0, 0, 0};
+    for (int k = 0; k < cn; k++) v[k] = resize_sample_cn(img, ih, istride, cn, mode, xofs, ialpha, yofs, ibeta, xmax, w, h, k);
+    overlay_pixel(frame + (size_t)(h + p.y) * stride + (size_t)(w + p.x) * 3, v, cn);
+}
+void launch_overlay(hipStream_t st, uint8_t *frame, int W, int H, int stride, const OverlayPlace &p, const uint8_t *img, int ih, int istride, int cn,
+                    int mode, const int *xofs, const short *ialpha, const int *yofs, const short *ibeta, int xmax)
+{
+    NVCA_LAUNCH(k_overlay, dim3((p.w + 255) / 256, p.h), dim3(256), 0, st, frame, W, H, stride, p, img, ih, istride, cn, mode, xofs, ialpha, yofs, ibeta, xmax);
+}
+
 void launch_resize1(hipStream_t st, const uint8_t *src, int sw, int sh, int sstride, int mode,
                     const int *d_xofs, const short *d_ialpha, const int *d_yofs, const short *d_ibeta,
                     int xmax, uint8_t *dst, int dw, int dh, int dstride, unsigned *hist, int batch, size_t src_slot, size_t dst_slot)

@@ -268,6 +268,7 @@ struct nvca_ctx {
     nvca::Switches sw;                // this context's switches: the process defaults (environment), nvca_ctx_set_option overrides
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
+    nvca::DevBuf overlay_img;         // the caller's overlay image on the device (nvca_overlay_blend on device frames)
 #ifdef NVCA_STAMPS
     unsigned long long *stamps = nullptr;
 #endif
@@ -454,6 +455,52 @@ NVCA_HD inline bool shape_covers(const nvca_shape &sh, int px, int py)
     return mx + my == 1;
 }
 void draw_shapes_host(uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *shapes, int n);
+
+// ---- image-to-overlay (nvca_overlay_blend): kms_face_detect_display_detections_overlay_img, FACE/kmsfacedetect.cpp:427-502.
+// One arithmetic for the host loop and the kernel (as for the outlines above).
+// Channel k of output pixel (x, y) of cvResize(costume, costumeAux, CV_INTER_LINEAR) on an 8-bit image with cn interleaved
+// channels: cv::resize's fixed-point bilinear path (11-bit coefficients, tables from build_resize_tab), its 2 x 2 area
+// shortcut, or the identity.
+NVCA_HD inline int resize_sample_cn(const uint8_t *src, int sh, int sstride, int cn, int mode, const int *xofs, const short *ialpha,
+                                    const int *yofs, const short *ibeta, int xmax, int x, int y, int k)
+{
+    if (mode == 0) return src[(size_t)y * sstride + (size_t)x * cn + k];
+    if (mode == 2) {
+        const uint8_t *s0 = src + (size_t)(2 * y) * sstride + (size_t)(2 * x) * cn + k, *s1 = s0 + sstride;
+        return (s0[0] + s0[cn] + s1[0] + s1[cn] + 2) >> 2;
+    }
+    int sy0 = yofs[y], sy1 = sy0 + 1;
+    sy0 = sy0 >= 0 ? (sy0 < sh ? sy0 : sh - 1) : 0;
+    sy1 = sy1 >= 0 ? (sy1 < sh ? sy1 : sh - 1) : 0;
+    const uint8_t *s0 = src + (size_t)sy0 * sstride + (size_t)xofs[x] * cn + k, *s1 = src + (size_t)sy1 * sstride + (size_t)xofs[x] * cn + k;
+    const bool inner = x < xmax;
+    const int a0 = inner ? ialpha[2 * x] : 2048, a1 = inner ? ialpha[2 * x + 1] : 0;
+    const int h0 = s0[0] * a0 + (inner ? s0[cn] * a1 : 0), h1 = s1[0] * a0 + (inner ? s1[cn] * a1 : 0);
+    return (((ibeta[2 * y] * (h0 >> 4)) >> 16) + ((ibeta[2 * y + 1] * (h1 >> 4)) >> 16) + 2) >> 2;
+}
+// the write of one overlay pixel v[0 .. cn) onto a BGR pixel of the frame (:467-490; SRC_OVERLAY is 1)
+NVCA_HD inline void overlay_pixel(uint8_t *px, const int *v, int cn)
+{
+    if (cn == 1) { px[0] = px[1] = px[2] = (uint8_t)v[0]; return; }
+    if (cn == 3) { px[0] = (uint8_t)v[0]; px[1] = (uint8_t)v[1]; px[2] = (uint8_t)v[2]; return; }
+    const double proportion = (double)v[3] / (double)255;
+    const double overlay = 1.0 * proportion, original = 1 - overlay;
+    for (int k = 0; k < 3; k++) px[k] = (uint8_t)((v[k] * overlay) + (px[k] * original));
+}
+// where the reference puts the scaled image for a box, and how large (:441-444: the sums are truncated, not the products)
+struct OverlayPlace { int x, y, w, h; };
+inline OverlayPlace overlay_place(const nvca_rect &b, const nvca_overlay &ov)
+{
+    OverlayPlace p;
+    p.x = (int)(b.x + (b.w * ov.offset_x_percent));
+    p.y = (int)(b.y + (b.h * ov.offset_y_percent));
+    p.h = (int)(b.h * ov.height_percent);
+    p.w = (int)(b.w * ov.width_percent);
+    return p;
+}
+void overlay_blend_host(uint8_t *frame, int W, int H, int stride, const nvca_rect *boxes, int n, const nvca_overlay &ov);
+void launch_overlay(hipStream_t st, uint8_t *frame, int W, int H, int stride, const OverlayPlace &p, const uint8_t *img, int ih, int istride, int cn,
+                    int mode, const int *xofs, const short *ialpha, const int *yofs, const short *ibeta, int xmax);
 void launch_draw_shapes(hipStream_t st, uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *d_shapes, int n,
                         int bx0, int by0, int bx1, int by1);
 

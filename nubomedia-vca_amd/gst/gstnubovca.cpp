@@ -283,7 +283,8 @@ static double now_ms()
 struct Canvas { nvca_ctx *ctx; nvca_frame f; int bpp; };
 static void draw_shape(const Canvas &c, int kind, int x, int y, int w, int h, const guint8 *col)
 {
-    nvca_shape sh;           // host frames need no context (nvca_draw_shapes): outlines are drawn even where no GPU slot came up sh.kind = kind; sh.x = x; sh.y = y; sh.w = w; sh.h = h;
+    // host frames need no context (nvca_draw_shapes): outlines are drawn even where no GPU slot came up
+    nvca_shape sh; sh.kind = kind; sh.x = x; sh.y = y; sh.w = w; sh.h = h;
     for (int k = 0; k < 4; k++) sh.bgra[k] = col[k];
     nvca_draw_shapes(c.f.mem == NVCA_MEM_HOST ? NULL : c.ctx, &c.f, c.bpp, &sh, 1);
 }

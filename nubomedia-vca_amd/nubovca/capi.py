@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libnubovca_hip.so")
+LIB_PATH = os.environ.get("NVCA_LIB") or os.path.join(os.path.dirname(_HERE), "libnubovca_hip.so")      # NVCA_LIB: A/B runs of kernel variants (scripts/)
 
 OK = 0
 ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OVERFLOW, ERR_NOMEM, ERR_INTERNAL = range(-1, -10, -1)
@@ -35,6 +35,11 @@ class Shape(C.Structure):
 
 
 SHAPE_RECT3, SHAPE_RING4 = 0, 1
+
+
+class Overlay(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("channels", C.c_int),
+                ("offset_x_percent", C.c_double), ("offset_y_percent", C.c_double), ("width_percent", C.c_double), ("height_percent", C.c_double)]
 
 
 class Frame(C.Structure):
@@ -76,7 +81,7 @@ SYMBOLS = [
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
     "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count", "nvca_draw_shapes",
-    "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option",
+    "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option", "nvca_overlay_blend",
 ]
 
 _lib = None
@@ -123,6 +128,7 @@ def load():
     L.nvca_ctx_set_hit_capacity.argtypes = [vp, C.c_int]
     L.nvca_ctx_set_sum_policy.argtypes = [vp, C.c_int]
     L.nvca_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.nvca_overlay_blend.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, C.POINTER(Overlay)]
     L.nvca_ctx_synchronize.argtypes = [vp]
     L.nvca_ctx_stream.argtypes = [vp]
     L.nvca_host_register.argtypes = [vp, vp, C.c_size_t]
@@ -455,6 +461,23 @@ class Cascade:
             if self.ctx.h:
                 self.ctx.L.nvca_cascade_free(self.h)
             self.h = None
+
+
+def overlay_blend(ctx, frame, boxes, image, offset_x=0.0, offset_y=0.0, width=1.0, height=1.0):
+    """nvca_overlay_blend: image (HxW, HxWx3 or HxWx4 uint8, host) scaled onto every box of the BGR frame, in place.
+    frame: a writable numpy image (host: ctx may be None) or a Frame (device memory)"""
+    L = load()
+    fr = frame if isinstance(frame, Frame) else make_frame(frame)
+    image = np.ascontiguousarray(image, np.uint8)
+    cn = 1 if image.ndim == 2 else image.shape[2]
+    ov = Overlay(image.ctypes.data, image.shape[1], image.shape[0], image.strides[0], cn, offset_x, offset_y, width, height)
+    boxes = np.asarray(boxes, np.int32).reshape(-1, 4)
+    buf = (Rect * max(len(boxes), 1))()
+    for i, r in enumerate(boxes):
+        buf[i] = Rect(*[int(v) for v in r])
+    rc = L.nvca_overlay_blend(ctx.h if ctx is not None else None, C.byref(fr), buf, len(boxes), C.byref(ov))
+    if rc != 0:
+        raise NvcaError(rc, L.nvca_last_error(ctx.h).decode() if ctx is not None else "nvca_overlay_blend")
 
 
 def draw_shapes_host(img, channels, shapes):

@@ -247,6 +247,18 @@ static int run_glue(const char *cases_path)
         merge_consecutive_nm(cn, old, face, scale, rnd_in(1, 12), res);
         for (const nvca_rect &r : res) sum += (unsigned)(r.x + r.y + r.w + r.h);
     }
+    // image-to-overlay on host frames: boxes that stick out of the frame on every side, every channel count, tiny and huge scales
+    for (int t = 0; t < 300; t++) {
+        const int W = rnd_in(1, 90), H = rnd_in(1, 70), stride = W * 3 + rnd_in(0, 5), cn = (int[]){1, 3, 4}[rnd() % 3], iw = rnd_in(1, 40), ih = rnd_in(1, 30);
+        std::vector<uint8_t> frame((size_t)stride * H), img((size_t)iw * cn * ih);
+        for (uint8_t &b : frame) b = (uint8_t)rnd();
+        for (uint8_t &b : img) b = (uint8_t)rnd();
+        nvca_overlay ov{img.data(), iw, ih, iw * cn, cn, (rnd_in(-20, 20)) / 10.0, (rnd_in(-20, 20)) / 10.0, rnd_in(0, 30) / 10.0, rnd_in(0, 30) / 10.0};
+        std::vector<nvca_rect> bx(rnd_in(0, 3));
+        for (nvca_rect &r : bx) { r.x = rnd_in(-60, 100); r.y = rnd_in(-60, 80); r.w = rnd_in(0, 120); r.h = rnd_in(0, 100); }
+        overlay_blend_host(frame.data(), W, H, stride, bx.data(), (int)bx.size(), ov);
+        for (uint8_t b : frame) sum += b;
+    }
     printf("{\"merges_checksum\": %llu}\n", sum);
     return 0;
 }
@@ -258,5 +270,13 @@ int main(int argc, char **argv)
     if (mode == "loader") return run_loader(argc - 2, argv + 2);
     if (mode == "plans") return run_plans(argv[2]);
     if (mode == "glue") return run_glue(argv[2]);
+    if (mode == "stages") {            // the per-stage summation-order proof of a cascade (StageRec flags), for DESIGN / experiments
+        const std::string xml = slurp(argv[2]);
+        Cascade c; std::string err;
+        if (parse_cascade_xml(xml.data(), xml.size(), c, err)) return fail(err.c_str());
+        std::vector<StageRec> st; build_stage_recs(c, st);
+        for (size_t i = 0; i < st.size(); i++) printf("{\"stage\": %zu, \"count\": %d, \"flags\": %d, \"thr_i\": %d, \"vote_exp\": %d}\n", i, st[i].count, st[i].flags, st[i].thr_i, st[i].vote_exp);
+        return 0;
+    }
     return 2;
 }

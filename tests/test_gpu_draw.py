@@ -51,3 +51,26 @@ def test_padded_rows_and_bad_arguments(ctx):
         ctx.draw_shapes(np.zeros((8, 8, 3), np.uint8), 3, [(7, 0, 0, 1, 1, (0, 0, 0, 0))])
     with pytest.raises(capi.NvcaError):
         ctx.draw_shapes(np.zeros((8, 8, 3), np.uint8), 2, [])
+
+
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_overlay_on_device_frames(ctx, cn):
+    """nvca_overlay_blend on a frame that lives in HBM (k_overlay, one launch per box): the pixels of the host loop / of the
+    numpy statement of FACE/kmsfacedetect.cpp:427-502, bit for bit (the blend is f64 arithmetic, truncated)"""
+    import torch
+    from nubovca import capi
+    from overlay_reference import overlay_blend as ref_blend
+    rng = np.random.default_rng(20 + cn)
+    img = rng.integers(0, 256, (45, 70) if cn == 1 else (45, 70, cn)).astype(np.uint8)
+    W, H = 640, 360
+    for boxes, ox, oy, wp, hp in [([(100, 60, 200, 160), (220, 120, 180, 200)], -0.1, -0.3, 1.2, 1.4), ([(560, 300, 160, 120), (-40, -30, 120, 90)], 0.0, 0.0, 1.0, 1.0),
+                                  ([(10, 10, 140, 90)], 0.0, 0.0, 1.0, 1.0), ([(300, 100, 35, 22)], 0.0, 0.0, 1.0, 1.03)]:
+        frame = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        exp = ref_blend(frame.copy(), boxes, img, ox, oy, wp, hp)
+        host = frame.copy()
+        capi.overlay_blend(None, host, boxes, img, ox, oy, wp, hp)
+        dev = torch.from_numpy(frame.copy()).cuda()
+        torch.cuda.synchronize()
+        capi.overlay_blend(ctx, capi.make_frame(dev.data_ptr(), W, H, W * 3, capi.MEM_DEVICE), boxes, img, ox, oy, wp, hp)
+        got = dev.cpu().numpy()
+        assert np.array_equal(host, exp) and np.array_equal(got, exp), (cn, boxes, int((got != exp).sum()))

@@ -281,15 +281,29 @@ def test_detect_degenerate_images(ctx, casc, orc_cascade):
         assert np.array_equal(ctx.detect_raw(casc, img, 1.1, 0, (0, 0)), orc.detect_raw(orc_cascade, img, 1.1, 0, (0, 0)))
 
 
-def test_hit_capacity_overflow_is_loud(ctx, casc_small):
+def test_hit_capacity_overflow_is_answered_or_loud(ctx, casc_small, orc_small):
+    """more raw candidates than the lists hold: a detectMultiScale call re-runs its launch set with lists of the exact size and
+    answers like the reference (every scan variant); the batched face path reports NVCA_ERR_OVERFLOW for that batch -- never a
+    truncated list -- and answers the following batches, whose lists it sizes for what the refused one produced"""
     import orc
     from nubovca import capi, synth
     g = orc.equalize_hist(synth.make_gray(400, 300, 8, "gradient", [(50, 40, 150)]))
     ctx.set_hit_capacity(16)
     try:
+        eraw = orc.detect_raw(orc_small, g, 1.1, 0, (0, 0))
+        assert len(eraw) > 16
+        assert np.array_equal(ctx.detect_raw(casc_small, g, 1.1, 0, (0, 0)), eraw)
+        assert np.array_equal(ctx.detect_raw(casc_small, g, 1.1, capi.HAAR_SCALE_IMAGE, (0, 0)), orc.detect_raw(orc_small, g, 1.1, orc.HAAR_SCALE_IMAGE, (0, 0)))
+        for fl in (0, capi.HAAR_SCALE_IMAGE, capi.HAAR_FIND_BIGGEST_OBJECT):
+            assert np.array_equal(ctx.detect_multiscale(casc_small, g, 1.1, 2, fl, (0, 0)), orc.detect_multiscale(orc_small, g, 1.1, 2, fl, (0, 0))), fl
+        bgr = synth.make_bgr(400, 300, 8, "gradient", [(50, 40, 150)])
+        fs = capi.FaceStream(ctx, casc_small, width_to_process=400, multi_scale_factor=10)
         with pytest.raises(capi.NvcaError) as e:
-            ctx.detect_raw(casc_small, g, 1.1, 0, (0, 0))
+            fs.process(bgr)
         assert e.value.code == capi.ERR_OVERFLOW
+        b1, i1 = fs.process(bgr)                          # lists sized for what the refused batch produced: the stream goes on
+        eb, _ = orc.FaceStream(orc_small, width_to_process=400, scale_factor_pct=10).process(bgr)
+        assert len(eb) >= 1 and np.array_equal(b1, eb)    # (first tracked frame of either stream: the detections themselves)
     finally:
         ctx.set_hit_capacity(16384)
 
