@@ -204,13 +204,15 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
     f720, ms720 = multi(1280, 720, 32, False)
     ftrk, mstrk = multi(1920, 1080, 8, True)
     # BASELINE configs[2]: the face -> eye / nose / mouth / ear chain on V concurrent 1080p streams, batched entry points
-    def roi_chain(V=8, ticks=3, reps=4):
+    def roi_chain(V=8, ticks=4, reps=6):
         pcs = {nm: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(nm)) for nm in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
         fcs = [capi.FaceStream(ctx, casc, width_to_process=1920, multi_scale_factor=props["multi_scale_factor"]) for _ in range(V)]
         kinds = [(0, "righteye", "lefteye"), (1, "nose", None), (2, "mouth", None), (3, "leftear", "rightear")]
         parts = [capi.PartStream(ctx, k, casc, pcs[a], pcs[b] if b else None) for _ in range(V) for k, a, b in kinds]
-        base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
-        keep = [[torch.from_numpy(synth.make_bgr(1920, 1080, 40 + 5 * t + v, "natural", [(x + 8 * (t + v), y, sz) for x, y, sz in base])).to(dev) for v in range(V)]
+        # two faces per frame, large enough that their parts (a quarter of the face wide, synth.part_template) reach the part
+        # cascades' 20-pixel windows on the 320-pixel working image: the search phase is loaded, not idle
+        base = [(150, 200, 560), (1100, 260, 620)]
+        keep = [[torch.from_numpy(synth.make_bgr(1920, 1080, 40 + 5 * t + v, "natural", [(x + 8 * t + 6 * v, y + 3 * v, sz + 4 * ((t + v) % 3)) for x, y, sz in base])).to(dev) for v in range(V)]
                 for t in range(ticks)]
         torch.cuda.synchronize()
         frs = [[capi.make_frame(x.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for x in row] for row in keep]
@@ -222,22 +224,37 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
             res = capi.part_batch_process(ctx, parts, [fb[v] for v in range(V) for _ in range(4)])
             ctx.face_batch_collect(tk)
             found[0] += sum(len(a) + len(b) for a, b in res)
-        for i in range(ticks):
+        for i in range(2 * ticks):                         # two turns through the frame sets: plans, tables and buffers are in place
             tick(i)
         ctx.synchronize()
         found[0] = 0
         t0 = time.perf_counter()
-        for i in range(ticks, ticks + reps * ticks):
+        for i in range(2 * ticks, 2 * ticks + reps * ticks):
             tick(i)
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        nparts = found[0] / (V * reps * ticks)
+        # launches per tick: a separate pass with an event pair on every launch (they serialise the launches: not the rate above)
+        ctx.enable_kernel_timing(1)
+        for i in range(ticks):
+            tick(i)
+        ctx.synchronize()
+        kt = ctx.kernel_timing()
+        ctx.enable_kernel_timing(0)
+        launches = sum(v[1] for v in kt.values()) / ticks
         for st in fcs:
             st.close()
         for pt in parts:
             pt.close()
-        return V * reps * ticks / dt, dt / (reps * ticks) * 1e3, found[0] / (V * reps * ticks)
-    froi, msroi, nparts = roi_chain() if (W, H) == (1920, 1080) else (None, None, None)
-    tab["workloads"] = {"roi_chain": {"frames_per_s": froi, "ms_per_tick": msroi, "streams": 8, "parts_per_frame": nparts,
+        # algorithmic bytes per video frame (SURVEY.md 8d's formula per working image): the face detector's 60.21 MB plus, per part
+        # detector, BGR in + gray out / in, plus the small working images' integral pairs written and read
+        alg = 60.21e6 + 4 * (3 * 1920 * 1080 + 2 * 1920 * 1080) + 4 * 25 * (320 * 180 + 160 * 90)
+        ach = alg * V * reps * ticks / dt / 1e9
+        return V * reps * ticks / dt, dt / (reps * ticks) * 1e3, nparts, {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                                                           "launches_per_tick": launches, "alg_bytes_per_frame": alg,
+                                                                           "note": "launch- and latency-bound small-image work next to one 8-frame face-detector batch"}
+    froi, msroi, nparts, roiroof = roi_chain() if (W, H) == (1920, 1080) else (None, None, None, None)
+    tab["workloads"] = {"roi_chain": {"frames_per_s": froi, "ms_per_tick": msroi, "streams": 8, "parts_per_frame": nparts, "roofline": roiroof,
                                       "note": "BASELINE configs[2]: 8 x 1080p streams x (face detector + eye + nose + mouth + ear, own face pass each), nvca_face_batch_submit/collect around nvca_part_batch_process; scripts/bench_roi_chain.py gives the breakdown"},
                         "streams720p": {"frames_per_s": f720, "ms_per_tick": ms720, "streams": 32, "note": "BASELINE configs[3] per GPU: 32 independent 1280x720 streams, one frame each per call"},
                         "face_tracker": {"frames_per_s": ftrk, "ms_per_tick": mstrk, "streams": 8, "note": "BASELINE configs[4] per GPU: 8 x 1080p streams through NuboFaceDetector + NuboTracker per tick"}}
@@ -467,7 +484,7 @@ def main():
         ab = algorithmic_bytes(W, H, w, h, n_boxes)
         groups = {"gray_resize_hist": ["gray_resize_hist"], "equalize_lut": ["equalize_lut"],
                   "integral": ["integral_colsum", "integral_bandscan", "integral_rows"],
-                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep", "cascade_tile", "cascade_band", "group_rects"],
+                  "cascade": ["cascade_stage0", "cascade_strip", "cascade_deep", "cascade_tile", "cascade_band", "cascade_roi", "group_rects"],
                   "tracker": ["tracker"]}
         kern = {}
         for gname, members in groups.items():

@@ -88,7 +88,7 @@ int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
 /* Measurement / bisecting switches, per context.  The process-wide defaults come from the environment
  * (NVCA_BAND, NVCA_TILES, ... read once, when the first context is created); this sets one for this context.  Names: "band"
  * (-1 / 0 / 1), "band_map", "tiles", "deep_stage", "deep_lds", "pyr_off", "host_group", "group_zerocopy", "sparse_ingest",
- * "ingest_chunk", "skip_cascade", "host_profile", "part_stats", "trk_order", "plan_debug", "quiet".  None of them changes a
+ * "ingest_chunk", "skip_cascade", "host_profile", "part_stats", "trk_order", "plan_debug", "quiet", "roi", "stage_fuse".  None of them changes a
  * result.  Switches that shape plans drop the context's cached plans (not while a submitted batch is in flight). */
 int  nvca_ctx_set_option(nvca_ctx *ctx, const char *name, int value);
 /* block until everything queued on the context's HIP stream has finished */
@@ -121,7 +121,8 @@ int  nvca_host_unregister(nvca_ctx *ctx, void *ptr);
 #define NVCA_K_RESIZE1  10  /* 8UC1 resize (pyramid / parts)            */
 #define NVCA_K_TILE     11  /* cascade: early stages from LDS-staged tiles */
 #define NVCA_K_BAND     12  /* cascade: variance + stage 0 + early stages, one row of tiles per workgroup */
-#define NVCA_K_COUNT    13
+#define NVCA_K_ROI     13  /* cascade: a whole detectMultiScale on a small image (a face region) per workgroup */
+#define NVCA_K_COUNT    14
 int  nvca_ctx_enable_kernel_timing(nvca_ctx *ctx, int on);
 /* total_ms[NVCA_K_COUNT], launches[NVCA_K_COUNT]; resets the accumulators */
 int  nvca_ctx_kernel_timing(nvca_ctx *ctx, double *total_ms, int64_t *launches);

@@ -145,6 +145,8 @@ static Switches read_switches()
     w.plan_debug = set("NVCA_PLAN_DEBUG");
     w.deep_lds = !set("NVCA_DEEP_LDS_OFF");
     w.trk_order = num("NVCA_TRK_ORDER", -1);
+    w.roi = num("NVCA_ROI", 1) != 0;
+    w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
     w.quiet = set("NVCA_QUIET");
     w.stamps_out = getenv("NVCA_STAMPS_OUT");
     return w;
@@ -475,7 +477,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
         a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
-        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0;
         a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
@@ -720,6 +722,8 @@ nvca_ctx::~nvca_ctx()
     part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     overlay_img.release();
+    for (auto &kv : roi_stage_recs) { kv.second->release(); delete kv.second; }
+    roi_tables.release(); roi_hits.release(); roi_h_tables.release(); roi_h_hits.release();
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
@@ -805,6 +809,8 @@ try {
     else if (n == "part_stats") w.part_stats = value;
     else if (n == "trk_order") w.trk_order = value;
     else if (n == "quiet") w.quiet = value != 0;
+    else if (n == "roi") w.roi = value != 0;
+    else if (n == "stage_fuse") w.stage_fuse = value != 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
     else if (n == "tiles") { w.tiles = value != 0; replan = true; }
@@ -894,7 +900,7 @@ const char *nvca_kernel_name(int k)
 {
     static const char *names[NVCA_K_COUNT] = {"gray_resize_hist", "equalize_lut", "integral_colsum", "integral_bandscan",
                                               "integral_rows", "cascade_stage0", "cascade_strip", "cascade_deep",
-                                              "group_rects", "tracker", "resize_gray", "cascade_tile", "cascade_band"};
+                                              "group_rects", "tracker", "resize_gray", "cascade_tile", "cascade_band", "cascade_roi"};
     return (k >= 0 && k < NVCA_K_COUNT) ? names[k] : "?";
 }
 
@@ -975,6 +981,8 @@ try {
             if (k.find(pre) != std::string::npos && it->second->inflight == 0) { (void)hipDeviceSynchronize(); it = c->ctx->plans.erase(it); }
             else ++it;
         }
+        { auto sr = c->ctx->roi_stage_recs.find((uint64_t)c->c.uid);
+          if (sr != c->ctx->roi_stage_recs.end()) { (void)hipDeviceSynchronize(); sr->second->release(); delete sr->second; c->ctx->roi_stage_recs.erase(sr); } }
         for (auto it = c->ctx->scale_tables.begin(); it != c->ctx->scale_tables.end();) {      // and its stump tables
             if (it->first.first == (uint64_t)c->c.uid && it->second->refs == 0) { (void)hipDeviceSynchronize(); delete it->second; it = c->ctx->scale_tables.erase(it); }
             else ++it;
@@ -1382,6 +1390,13 @@ struct DetectJob {
     std::vector<FbStep> ladder; std::vector<std::vector<nvca_rect>> hits; std::vector<char> have; std::vector<int> ladder_of;
     std::vector<nvca_rect> all; nvca_rect scanROI{0, 0, 0, 0}; bool narrowed_done = false; size_t fb_i = 0; int cur_minw = 0, cur_minh = 0;
     int regrown = 0;                                 // launch sets re-run with a larger candidate list (at most one per set)
+    // small-image path (kernels_roi.hip): the job's steps of the queued launch and the candidates that came back
+    struct RoiStepInfo { double ystep, out_factor; int winw, winh, ladder; };
+    bool small = false;                              // the job runs on the small-image path (decided at its first round)
+    int roi_prev_phase = 0;                          // its phase before the queued set (a set that overflowed the list is queued again)
+    bool fused = false;                              // the queued set went into the round's k_roi launch
+    std::vector<RoiStepInfo> rinfo;
+    std::vector<unsigned> rkeys[kJobImages];         // per image: step << 26 | iy << 13 | ix, ascending (= OpenCV's serial order)
 };
 
 static bool fb_make_spec(const DetectJob &j, int spitch, const FbStep &st, int startX, int endX, int startY, int endY, ScaleSpec &sp)
@@ -1646,6 +1661,7 @@ static int fb_enqueue_narrowed(nvca_ctx *ctx, DetectJob &j, int r0, int total)
     return NVCA_OK;
 }
 
+static bool roi_grid(int cols, int rows, double ystep, int winw, int winh, int startX, int endX, int startY, int endY, RoiStep &st);
 // the serial loop of cvHaarDetectObjectsForROC on the scan results at hand; returns 1 when it needs the narrowed set first
 static int fb_replay(nvca_ctx *ctx, DetectJob &j)
 {
@@ -1667,11 +1683,16 @@ static int fb_replay(nvca_ctx *ctx, DetectJob &j)
                 if (sk.winw < j.cur_minw || sk.winh < j.cur_minh) break;
                 if (sk.winw > j.maxw || sk.winh > j.maxh) continue;
                 ScaleSpec sp;
-                if (fb_make_spec(j, spitch, sk, cv_round(j.scanROI.x / sk.ystep), cv_round((j.scanROI.x + j.scanROI.w - sk.winw) / sk.ystep),
-                                 cv_round(j.scanROI.y / sk.ystep), cv_round((j.scanROI.y + j.scanROI.h - sk.winh) / sk.ystep), sp)) {
+                const int sx0 = cv_round(j.scanROI.x / sk.ystep), sx1 = cv_round((j.scanROI.x + j.scanROI.w - sk.winw) / sk.ystep);
+                const int sy0 = cv_round(j.scanROI.y / sk.ystep), sy1 = cv_round((j.scanROI.y + j.scanROI.h - sk.winh) / sk.ystep);
+                if (j.small) {                    // small-image path: no plan, the narrowed grids go into the next round's launch as they are
+                    RoiStep tmp;
+                    if (roi_grid(cols, rows, sk.ystep, sk.winw, sk.winh, sx0, sx1, sy0, sy1, tmp)) { j.ladder_of.push_back((int)k); j.have[k] = 0; }
+                } else if (fb_make_spec(j, spitch, sk, sx0, sx1, sy0, sy1, sp)) {
                     specs.push_back(std::move(sp)); j.ladder_of.push_back((int)k); j.have[k] = 0;
                 }
             }
+            if (j.small && !j.ladder_of.empty()) { j.fb_i = i; return 1; }
             if (!specs.empty()) {
                 j.own.reset(new DetectPlan()); std::string err;
                 int rc;
@@ -1709,6 +1730,237 @@ static int fb_replay(nvca_ctx *ctx, DetectJob &j)
     return 0;
 }
 
+// ---- small images: one launch for every such job of a round (kernels_roi.hip) -----------------------------------------------
+// A job qualifies when its image's integral pair fits the workgroup's LDS, the cascade is a stump cascade with upright
+// features, and the ladder fits the candidate key.  No plan is built: the launch gets, per job, a handful of step records
+// (the cached stump table of the step's factor, the variance rectangle, the grid limits) -- so a face region of a size never
+// seen before costs no table work, and all regions of all streams of a round share ONE launch.
+static constexpr int kRoiMaxWords = 14848;          // (cols + 1) * (rows + 2) words per plane: the part detectors' 160 x 90 face-pass image still fits (two planes + queues + a level image = 157 KB of the 160 KB of LDS)
+struct RoiBatch {
+    std::vector<RoiJobDev> jobs; std::vector<RoiStep> steps; std::vector<unsigned char> tabs; std::vector<DetectJob *> owners; std::vector<int> owner_img;
+    std::vector<ScaleTable *> held;                 // stump tables of the launch: kept from eviction until it has been collected
+    int plane_words = 0, lev_bytes = 0, lane = 0; unsigned cap = 0;
+    ~RoiBatch() { for (ScaleTable *t : held) if (t->refs > 0) t->refs--; }
+};
+static bool roi_eligible(const nvca_ctx *ctx, const DetectJob &j, int njobs_in_round)
+{
+    const Cascade &c = j.casc->c;
+    if (!ctx->sw.roi) return false;
+    if (!c.stump_based || c.has_tilted || (j.nimg != 1 && j.mem != NVCA_MEM_DEVICE)) return false;
+    if ((long long)(j.cols + 1) * (j.rows + 2) > kRoiMaxWords || j.cols < 1 || j.rows < 1) return false;
+    if (j.mem != NVCA_MEM_DEVICE && njobs_in_round != 1) return false;       // a host image is staged in the lane's one gray buffer
+    return true;
+}
+static const StageRec *roi_stage_recs(nvca_ctx *ctx, const Cascade &c)
+{
+    auto it = ctx->roi_stage_recs.find(c.uid);
+    if (it != ctx->roi_stage_recs.end()) return it->second->as<StageRec>();
+    std::vector<StageRec> st; build_stage_recs(c, st);
+    std::unique_ptr<DevBuf> d(new DevBuf());
+    if (d->ensure(st.size() * sizeof(StageRec) + 8) || hipMemcpy(d->p, st.data(), st.size() * sizeof(StageRec), hipMemcpyHostToDevice) != hipSuccess) {
+        d->release(); ctx->set_error("allocation failed (stage records)"); return nullptr;
+    }
+    const StageRec *p = d->as<StageRec>();
+    ctx->roi_stage_recs[c.uid] = d.release();
+    return p;
+}
+static ScaleTable *roi_table(nvca_ctx *ctx, RoiBatch &rb, const Cascade &c, double factor)
+{
+    ScaleTable *t = get_scale_table(ctx, c, factor);
+    if (t) { t->refs++; rb.held.push_back(t); }
+    return t;
+}
+static void roi_step_common(RoiStep &st, const ScaleTable &t)
+{
+    memset(&st, 0, sizeof(st));
+    st.trecs = t.dev.as<TStumpRec>(); st.ex = t.ex; st.ey = t.ey; st.ew = t.ew; st.eh = t.eh; st.inv_area = t.inv_area; st.step = 1;
+}
+// scale-cascade grid of one ladder step, limits as indices: false = nothing to scan (fb_make_spec's rules: grid points whose
+// window would leave the image -- cvRunHaarClassifierCascadeSum returns -1 there -- are dropped from the end, a negative origin voids the step)
+static bool roi_grid(int cols, int rows, double ystep, int winw, int winh, int startX, int endX, int startY, int endY, RoiStep &st)
+{
+    if (!(endX > startX && endY > startY)) return false;
+    while (endX > startX && cv_round((endX - 1) * ystep) + winw >= cols + 1) endX--;
+    while (endY > startY && cv_round((endY - 1) * ystep) + winh >= rows + 1) endY--;
+    if (!(endX > startX && endY > startY)) return false;
+    if (cv_round(startX * ystep) < 0 || cv_round(startY * ystep) < 0 || endX > 8191 || endY > 8191) return false;
+    st.startX = startX; st.endX = endX; st.startY = startY; st.endY = endY; st.ystep = ystep; st.adaptive = 1;
+    return true;
+}
+// returns NVCA_OK with j.fused set when the job's next set went into the batch, NVCA_OK with j.fused clear when it has to take
+// the large-image path after all (too many steps), or an error
+static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
+{
+    const Cascade &c = j.casc->c;
+    const int cols = j.cols, rows = j.rows;
+    j.fused = false;
+    const StageRec *d_stages = roi_stage_recs(ctx, c);
+    if (!d_stages) return NVCA_ERR_NOMEM;
+    std::vector<RoiStep> steps; std::vector<DetectJob::RoiStepInfo> info; std::vector<unsigned char> tabs;
+    const size_t tab0 = rb.tabs.size();
+    int lev_bytes = 0;
+    if (j.phase == 0) for (int k = 0; k < kJobImages; k++) j.out[k].clear();
+    if (j.kind == 1) {
+        // the pyramid levels of si_plan, each with its cv::resize tables
+        ScaleTable *t1 = nullptr;
+        for (double factor = 1;; factor *= j.sf) {
+            const int winw = cv_round(c.ow * factor), winh = cv_round(c.oh * factor);
+            const int szw = cv_round(cols / factor), szh = cv_round(rows / factor);
+            if (szw - c.ow + 1 <= 0 || szh - c.oh + 1 <= 0) break;
+            if (winw > j.maxw || winh > j.maxh) break;
+            if (winw < j.minw || winh < j.minh) continue;
+            if (szw + 1 <= 1 + c.ow) continue;
+            if (!t1 && !(t1 = roi_table(ctx, rb, c, 1.))) return NVCA_ERR_NOMEM;
+            RoiStep st; roi_step_common(st, *t1);
+            st.szw = szw; st.szh = szh; st.step = factor > 2 ? 1 : 2; st.startX = 0; st.endX = szw - c.ow; st.startY = 0; st.endY = szh - c.oh;
+            if (st.endX <= 0 || st.endY <= 0) continue;
+            ResizeTab tab; build_resize_tab(cols, rows, szw, szh, tab);
+            st.mode = tab.mode; st.xmax = tab.xmax;
+            auto put = [&](const void *p, size_t n) { const size_t at = (tab0 + tabs.size() + 15) & ~(size_t)15; tabs.resize(at - tab0 + n); if (n) memcpy(tabs.data() + at - tab0, p, n); return (int)at; };
+            st.xofs_off = put(tab.xofs.data(), tab.xofs.size() * 4); st.yofs_off = put(tab.yofs.data(), tab.yofs.size() * 4);
+            st.ialpha_off = put(tab.ialpha.data(), tab.ialpha.size() * 2); st.ibeta_off = put(tab.ibeta.data(), tab.ibeta.size() * 2);
+            steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{0., factor, winw, winh, -1});
+            lev_bytes = std::max(lev_bytes, szw * szh);
+        }
+        j.phase = 1;
+    } else if (j.kind == 0) {
+        std::vector<double> factors;
+        scale_grid(c.ow, c.oh, cols, rows, j.sf, j.minw, j.minh, j.maxw, j.maxh, false, factors);
+        for (double factor : factors) {
+            const double ystep = std::max(2., factor);
+            ScaleTable *t = roi_table(ctx, rb, c, factor);
+            if (!t) return NVCA_ERR_NOMEM;
+            RoiStep st; roi_step_common(st, *t);
+            if (!roi_grid(cols, rows, ystep, t->winw, t->winh, 0, cv_round((cols - t->winw) / ystep), 0, cv_round((rows - t->winh) / ystep), st)) continue;
+            steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{ystep, 0., t->winw, t->winh, -1});
+        }
+        j.gthr = (!j.raw_only && j.min_neighbors != 0) ? std::max(j.min_neighbors, 1) : 0;
+        j.phase = 1;
+    } else {
+        if (j.phase == 0) {
+            // the ladder of factors, largest first, exactly as the serial loop walks it (fb_enqueue_first)
+            j.ladder.clear();
+            int n_factors = 0; double factor;
+            for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= j.sf)
+                ;
+            const double inv = 1. / j.sf; factor *= inv;
+            for (; n_factors-- > 0; factor *= inv) j.ladder.push_back(FbStep{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
+            j.hits.assign(j.ladder.size(), {}); j.have.assign(j.ladder.size(), 1);
+            j.all.clear(); j.scanROI = nvca_rect{0, 0, 0, 0}; j.narrowed_done = false; j.fb_i = 0; j.cur_minw = j.minw; j.cur_minh = j.minh;
+            j.ladder_of.clear();
+            for (size_t i = 0; i < j.ladder.size(); i++) {
+                const FbStep &fs = j.ladder[i];
+                if (fs.winw < j.minw || fs.winh < j.minh) break;
+                if (fs.winw > j.maxw || fs.winh > j.maxh) continue;
+                ScaleTable *t = roi_table(ctx, rb, c, fs.factor);
+                if (!t) return NVCA_ERR_NOMEM;
+                RoiStep st; roi_step_common(st, *t);
+                if (!roi_grid(cols, rows, fs.ystep, fs.winw, fs.winh, 0, cv_round((cols - fs.winw) / fs.ystep), 0, cv_round((rows - fs.winh) / fs.ystep), st)) continue;
+                steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{fs.ystep, 0., fs.winw, fs.winh, (int)i}); j.ladder_of.push_back((int)i);
+            }
+            j.phase = 1;
+        } else {
+            // the narrowed set fb_replay asked for: steps fb_i .. on their narrowed grids (j.ladder_of / j.have were set by the replay)
+            for (int li : j.ladder_of) {
+                const FbStep &fs = j.ladder[li];
+                ScaleTable *t = roi_table(ctx, rb, c, fs.factor);
+                if (!t) return NVCA_ERR_NOMEM;
+                RoiStep st; roi_step_common(st, *t);
+                if (!roi_grid(cols, rows, fs.ystep, fs.winw, fs.winh, cv_round(j.scanROI.x / fs.ystep), cv_round((j.scanROI.x + j.scanROI.w - fs.winw) / fs.ystep),
+                              cv_round(j.scanROI.y / fs.ystep), cv_round((j.scanROI.y + j.scanROI.h - fs.winh) / fs.ystep), st)) continue;
+                steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{fs.ystep, 0., fs.winw, fs.winh, li});
+            }
+        }
+    }
+    bool fits = steps.size() <= 63;                                  // the key holds 6 bits of step
+    for (RoiStep &st : steps) {
+        const int nx = (st.endX - st.startX + st.step - 1) / st.step, ny = (st.endY - st.startY + st.step - 1) / st.step;
+        if (nx > kRoiMaxWin) fits = false;                           // (a grid row longer than the queues: not with images this small)
+        st.key_x0 = st.startX; st.key_dx = st.step; st.key_y0 = st.startY; st.key_dy = st.step;
+    }
+    if (!fits && j.roi_prev_phase == 2) { ctx->set_error("internal: a narrowed search outgrew the small-image path"); return NVCA_ERR_INTERNAL; }   // (its full grids fitted)
+    if (!fits) { j.phase = j.roi_prev_phase; return NVCA_OK; }       // this one takes the large-image path
+    j.fused = true; j.rinfo.swap(info); j.dp = nullptr;
+    for (int k = 0; k < kJobImages; k++) j.rkeys[k].clear();
+    if (steps.empty()) return NVCA_OK;                               // nothing to scan: the job completes with what it has
+    rb.tabs.insert(rb.tabs.end(), tabs.begin(), tabs.end());
+    for (int k = 0; k < j.nimg; k++) {            // every image of the job: its own records (the steps name their image), the same tables
+        RoiJobDev d; memset(&d, 0, sizeof(d));
+        d.w = cols; d.h = rows; d.stride = j.stride; d.img = (const uint8_t *)j.img[k];
+        if (j.mem != NVCA_MEM_DEVICE) {
+            PreGeom g; make_geom(g, cols, rows, j.stride, 1, cols, rows);
+            int rc;
+            if ((rc = ensure_ws(ctx, g, 1))) return rc;
+            if ((rc = stage_2d(ctx, ctx->ws->ln().gray.p, g.gpitch, j.img[0], j.stride, cols, rows, j.mem))) return rc;
+            d.img = ctx->ws->ln().gray.as<uint8_t>(); d.stride = g.gpitch;
+        }
+        d.first_step = (int)rb.steps.size(); d.nsteps = (int)steps.size(); d.scale_image = j.kind == 1;
+        d.stages = d_stages; d.nstages = (int)c.stages.size(); d.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; d.slot = (int)rb.jobs.size();
+        for (RoiStep &st : steps) st.job = d.slot;
+        rb.steps.insert(rb.steps.end(), steps.begin(), steps.end());
+        rb.jobs.push_back(d); rb.owners.push_back(&j); rb.owner_img.push_back(k);
+    }
+    rb.plane_words = std::max(rb.plane_words, (cols + 1) * (rows + 2));
+    rb.lev_bytes = std::max(rb.lev_bytes, lev_bytes);
+    return NVCA_OK;
+}
+// upload the round's tables and launch k_roi on the current lane
+static int roi_launch(nvca_ctx *ctx, RoiBatch &rb, bool full_cap)
+{
+    const int nj = (int)rb.jobs.size();
+    const size_t jb = (size_t)nj * sizeof(RoiJobDev), sb = rb.steps.size() * sizeof(RoiStep);
+    const size_t o_steps = (jb + 255) & ~(size_t)255, o_tabs = (o_steps + sb + 255) & ~(size_t)255, total = o_tabs + rb.tabs.size() + 64;
+    // the list starts at a quarter of a million candidates for the whole launch however many jobs share it; a launch that
+    // overflows it is queued again with the exact size (run_detect_jobs raises hit_cap for the rest of the call)
+    const long long want = (long long)ctx->hit_cap * nj;
+    rb.cap = (unsigned)std::min<long long>(want, full_cap ? (1ll << 26) : (1ll << 18));
+    const size_t first = std::min<size_t>(rb.cap, 8192);
+    if (ctx->roi_tables.ensure(total) || ctx->roi_h_tables.ensure(total) || ctx->roi_hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->roi_h_hits.ensure(((size_t)rb.cap + 1) * 8)) {
+        ctx->set_error("allocation failed (small-image detector)"); return NVCA_ERR_NOMEM;
+    }
+    unsigned char *h = ctx->roi_h_tables.as<unsigned char>();
+    memcpy(h, rb.jobs.data(), jb); memcpy(h + o_steps, rb.steps.data(), sb);
+    if (!rb.tabs.empty()) memcpy(h + o_tabs, rb.tabs.data(), rb.tabs.size());
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->roi_tables.p, h, total - 64, hipMemcpyHostToDevice, ctx->cs()));
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ctx->roi_hits.p, 0, sizeof(unsigned long long), ctx->cs()));
+    const int lds = rb.plane_words * 8 + kRoiMaxWin * (8 + 2 + 2) + 16 + ((rb.lev_bytes + 15) & ~15) + 64;      // k_roi's carve-up
+    if (const int e = roi_grant_lds(lds)) { ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e)); return NVCA_ERR_HIP; }
+    const unsigned char *d = ctx->roi_tables.as<unsigned char>();
+    { TimedLaunch t(ctx, NVCA_K_ROI);
+      launch_roi(ctx->cs(), (const RoiJobDev *)d, (int)rb.steps.size(), (const RoiStep *)(d + o_steps), d + o_tabs, ctx->roi_hits.as<unsigned long long>(), rb.cap, rb.plane_words, lds); }
+    NVCA_LAUNCH_CHECK(ctx);
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->roi_h_hits.p, ctx->roi_hits.p, (first + 1) * 8, hipMemcpyDeviceToHost, ctx->cs()));
+    return NVCA_OK;
+}
+// after the lane has drained: hand every job its candidates; NVCA_ERR_OVERFLOW (with hit_cap_wanted set) when the list was too short
+static int roi_collect(nvca_ctx *ctx, RoiBatch &rb)
+{
+    unsigned long long *hh = ctx->roi_h_hits.as<unsigned long long>();
+    const unsigned long long total = hh[0];
+    const int nj = (int)rb.jobs.size();
+    if (total > rb.cap) {
+        const unsigned long long per = (total + (unsigned long long)nj - 1) / (unsigned long long)nj + 64;
+        if (per <= (unsigned long long)kMaxHitCap && (long long)per > ctx->hit_cap_wanted) ctx->hit_cap_wanted = (int)per;
+        ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
+        return NVCA_ERR_OVERFLOW;
+    }
+    const size_t first = std::min<size_t>(rb.cap, 8192);
+    if (total > first) {
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ctx->roi_hits.as<unsigned long long>() + 1 + first, (total - first) * 8, hipMemcpyDeviceToHost, ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+    }
+    std::sort(hh + 1, hh + 1 + total);
+    for (unsigned long long i = 0; i < total; i++) {
+        const unsigned long long slot = hh[1 + i] >> 32;
+        const unsigned key = (unsigned)hh[1 + i];
+        if (slot >= (unsigned long long)nj || (key >> 26) >= rb.owners[slot]->rinfo.size()) {
+            ctx->set_error("internal: candidate of an unknown job / step (device result rejected)"); return NVCA_ERR_INTERNAL;
+        }
+        rb.owners[slot]->rkeys[rb.owner_img[slot]].push_back(key);
+    }
+    return NVCA_OK;
+}
+
 // queue the job's next launch set; its candidates go to result slots [r0, r0 + slots()) of `total`
 static int detect_job_enqueue(nvca_ctx *ctx, DetectJob &j, int r0, int total)
 {
@@ -1731,6 +1983,24 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     std::vector<std::vector<nvca_rect>> raw;
     std::vector<char> grouped;
     std::vector<std::vector<int>> sc;
+    bool have = j.dp != nullptr;
+    const bool was_fused = j.fused;
+    if (j.fused) {
+        // candidates of the round's k_roi launch, already in serial order: step, row, column -> rectangle
+        raw.assign(j.nimg, {}); sc.assign(j.nimg, {}); grouped.assign(j.nimg, 0);
+        for (int k = 0; k < j.nimg; k++) {
+            for (unsigned key : j.rkeys[k]) {
+                const DetectJob::RoiStepInfo &ri = j.rinfo[key >> 26];
+                const int iy = (key >> 13) & 8191, ix = key & 8191;
+                if (ri.out_factor != 0) raw[k].push_back(nvca_rect{cv_round(ix * ri.out_factor), cv_round(iy * ri.out_factor), ri.winw, ri.winh});
+                else raw[k].push_back(nvca_rect{cv_round(ix * ri.ystep), cv_round(iy * ri.ystep), ri.winw, ri.winh});
+                sc[k].push_back(ri.ladder);
+            }
+            j.rkeys[k].clear();
+        }
+        j.fused = false;
+        have = true;
+    } else
     if (j.dp) rc = cascade_collect(ctx, *j.dp, j.cj, raw, j.kind == 0 ? &grouped : nullptr, j.kind == 2 ? &sc : nullptr);
     if (j.gp) { j.gp->inflight--; j.gp = nullptr; }
     if (rc == NVCA_ERR_OVERFLOW && j.regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
@@ -1745,21 +2015,24 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     }
     if (rc) { j.phase = 3; return rc; }
     if (j.kind == 0) {
-        if (j.dp)
+        if (have)
             for (int k = 0; k < j.nimg; k++) {
                 if (j.gthr && !grouped[k]) group_rectangles(raw[k], j.gthr, 0.2);
                 j.out[k].swap(raw[k]);
             }
         j.phase = 3;
     } else if (j.kind == 1) {
-        if (j.dp) { if (!j.raw_only) group_all(raw, j.min_neighbors); for (int k = 0; k < j.nimg; k++) j.out[k].swap(raw[k]); }
+        if (have) { if (!j.raw_only) group_all(raw, j.min_neighbors); for (int k = 0; k < j.nimg; k++) j.out[k].swap(raw[k]); }
         j.phase = 3;
     } else {
-        if (j.dp) {
+        if (have) {
             for (size_t k = 0; k < raw[0].size(); k++) {
-                const size_t si = (size_t)sc[0][k];
-                if (si >= j.ladder_of.size() || (size_t)j.ladder_of[si] >= j.hits.size()) { ctx->set_error("internal: candidate of an unknown ladder step"); j.phase = 3; return NVCA_ERR_INTERNAL; }
-                j.hits[j.ladder_of[si]].push_back(raw[0][k]);
+                // the large-image path numbers a candidate by its scale inside the plan (ladder_of maps it back), the small-image
+                // path by its ladder step directly
+                size_t li = (size_t)sc[0][k];
+                if (!was_fused) { if (li >= j.ladder_of.size()) li = (size_t)-1; else li = (size_t)j.ladder_of[li]; }
+                if (li >= j.hits.size()) { ctx->set_error("internal: candidate of an unknown ladder step"); j.phase = 3; return NVCA_ERR_INTERNAL; }
+                j.hits[li].push_back(raw[0][k]);
             }
             for (int li : j.ladder_of) j.have[li] = 1;
         }
@@ -1876,21 +2149,39 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
     const bool g_job_stats = ctx->sw.part_stats > 0;
     struct Restore { nvca_ctx *c; int l, cap, wanted; ~Restore() { c->cur_lane = l; c->hit_cap = cap; c->hit_cap_wanted = wanted; } } restore{ctx, lane0, ctx->hit_cap, ctx->hit_cap_wanted};
     ctx->hit_cap_wanted = 0;                 // (what the batched face path may have noted for its next batch is put back at the end)
+    int roi_regrown = 0;
     for (;;) {
         if (ctx->hit_cap_wanted > ctx->hit_cap) ctx->hit_cap = ctx->hit_cap_wanted;      // a set overflowed in the last round: it runs again with room (this call only)
-        int total = 0;
-        for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) total += jobs[i]->slots();
-        if (!total) return NVCA_OK;
-        int r0 = 0, rc = NVCA_OK;
+        int pending = 0;
+        for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) pending++;
+        if (!pending) return NVCA_OK;
+        int rc = NVCA_OK;
         bool used[kLanes] = {false};
         const double t0 = g_job_stats ? mono_s() : 0;
+        // small images first: every such job of the round goes into ONE k_roi launch (no plan, no per-job launches)
+        RoiBatch rb;
         for (int i = 0; i < n && !rc; i++) {
-            if (jobs[i]->phase == 3) continue;
+            DetectJob &j = *jobs[i];
+            if (j.phase == 3) continue;
+            if (j.phase == 0 && j.regrown == 0) j.small = roi_eligible(ctx, j, n);
+            if (!j.small) continue;
+            ctx->cur_lane = lanes ? lanes[i] : lane0;
+            if (rb.jobs.empty()) rb.lane = ctx->cur_lane;
+            j.roi_prev_phase = j.phase;
+            rc = roi_add_job(ctx, rb, j);
+            if (!rc && !j.fused) j.small = false;          // more ladder steps than the key holds: the large-image path takes it
+            else used[ctx->cur_lane] = true;
+        }
+        int total = 0, r0 = 0;
+        for (int i = 0; i < n; i++) if (jobs[i]->phase != 3 && !jobs[i]->small) total += jobs[i]->slots();
+        for (int i = 0; i < n && !rc; i++) {
+            if (jobs[i]->phase == 3 || jobs[i]->small) continue;
             ctx->cur_lane = lanes ? lanes[i] : lane0;
             used[ctx->cur_lane] = true;
             rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
             r0 += jobs[i]->slots();
         }
+        if (!rc && !rb.jobs.empty()) { ctx->cur_lane = rb.lane; used[rb.lane] = true; rc = roi_launch(ctx, rb, roi_regrown > 0); }
         const double t1 = g_job_stats ? mono_s() : 0;
         if (g_job_stats) g_jobs_enqueue_s += t1 - t0;
         for (int l = 0; l < kLanes; l++) {
@@ -1903,9 +2194,21 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         if (g_job_stats) g_jobs_wait_s += t2 - t1;
         struct Adv { double t; bool on; ~Adv() { if (on) g_jobs_advance_s += mono_s() - t; } } adv{t2, g_job_stats};
         drain_timer(ctx);
+        bool roi_again = false;
+        if (!rc && !rb.jobs.empty()) {
+            ctx->cur_lane = rb.lane;
+            const int r = roi_collect(ctx, rb);
+            ctx->cur_lane = lane0;
+            if (r == NVCA_ERR_OVERFLOW && roi_regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
+                // the round's candidate list was too short: its jobs are queued again, with room (see detect_job_advance)
+                roi_regrown++; roi_again = true;
+                for (DetectJob *o : rb.owners) { o->phase = o->roi_prev_phase; o->fused = false; for (int k = 0; k < kJobImages; k++) o->rkeys[k].clear(); }
+            } else if (r) rc = r;
+        }
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
             if (rc) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; continue; }
+            if (roi_again && std::find(rb.owners.begin(), rb.owners.end(), jobs[i]) != rb.owners.end()) continue;
             ctx->cur_lane = lanes ? lanes[i] : lane0;
             const int r = detect_job_advance(ctx, *jobs[i]);
             if (r) rc = r;

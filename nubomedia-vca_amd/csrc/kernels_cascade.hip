@@ -675,7 +675,8 @@ __device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, 
 //     partition (split-K by whole partitions left 4 of 16 waves idle at 374 windows, and ran 6 / 5 / 5 / 5 stumps at 21).
 //   * A wave adds its run's sum to the window's accumulator in LDS (ds_add: integer, hence exact in any order): no partial-sum
 //     table, no serial add-up by one thread.
-//   * Two consecutive such stages are evaluated in ONE pass (stage s + 1 speculatively for the windows that stage s will turn
+//   * (switch "stage_fuse", off by default: measured 2 % SLOWER on the headline workload -- the stump phases are bound by the LDS
+//     pipe, so the speculative evaluations cost more than the barrier they save)  Two consecutive such stages are evaluated in ONE pass (stage s + 1 speculatively for the windows that stage s will turn
 //     out to reject -- no side effects, the same pass / fail per stage) when the previous tile of the band saw at least 3/4 of
 //     stage s's windows survive it: the re-queue, its barrier and the wait for the slowest wave are paid once for both.
 //     Which stages are fused never changes a result.
@@ -728,7 +729,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
             int first2 = 0, count2 = 0, thr2 = 0; bool pair2 = false;
             if (s + 1 < last && s + 1 < kStatStages) {
                 const int seen_s = stat_r[s], seen_n = stat_r[s + 1];          // 0: no tile yet
-                if (seen_s > 0 && 4 * seen_n >= 3 * seen_s) {
+                if (a.stage_fuse && seen_s > 0 && 4 * seen_n >= 3 * seen_s) {
                     const StageRec st2 = load_const(a.stages + s + 1);
                     fuse = (st2.flags & 4) != 0;
                     first2 = st2.first; count2 = st2.count; thr2 = st2.thr_i; pair2 = a.pair_policy && (st2.flags & 1);

@@ -171,6 +171,8 @@ struct Switches {
     bool plan_debug = false;         // NVCA_PLAN_DEBUG: per-scale tile sizes on stderr
     bool deep_lds = true;            // NVCA_DEEP_LDS_OFF: k_deep without LDS patches
     int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
+    bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
+    bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
     const char *stamps_out = nullptr;   // NVCA_STAMPS_OUT (diagnostic build only)
 };
@@ -269,6 +271,9 @@ struct nvca_ctx {
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
     nvca::DevBuf overlay_img;         // the caller's overlay image on the device (nvca_overlay_blend on device frames)
+    // small-image detector (kernels_roi.hip): per-cascade stage records on the device, the tables / candidate list of a launch
+    std::map<uint64_t, nvca::DevBuf *> roi_stage_recs;
+    nvca::DevBuf roi_tables, roi_hits; nvca::PinnedBuf roi_h_tables, roi_h_hits;
 #ifdef NVCA_STAMPS
     unsigned long long *stamps = nullptr;
 #endif
@@ -411,6 +416,7 @@ struct CascadeArgs {
     unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
+    int stage_fuse;                // Switches::stage_fuse
     int deep_stage;                // first stage evaluated by k_deep
     int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key
@@ -539,6 +545,28 @@ void launch_generic(hipStream_t st, const CascadeArgs &a, int batch, int which);
 void launch_tilted(hipStream_t st, const uint8_t *gray, const uint8_t *lut, int lut_stride, const PreGeom &g, int *tilted, int batch);
 void launch_pyr_tilted(hipStream_t st, const uint8_t *aux, size_t aux_slot, const PyrLevelDev *levels, int nlev, int nimg,
                        int *tilted, size_t sum_slot, int P, int maxw, int maxh);
+// ---- detectMultiScale on a small image in one workgroup (kernels_roi.hip)
+struct RoiStep {                  // one ladder step (scale-cascade scan) or one pyramid level (CV_HAAR_SCALE_IMAGE) of a job
+    const TStumpRec *trecs;       // the cascade's stumps at this step's factor (levels: factor 1)
+    int ex, ey, ew, eh;           // variance rectangle (window-relative)
+    int startX, endX, startY, endY;   // scale-cascade: grid indices, window origin = cvRound(i * ystep); levels: origins 0 .. end, every `step` pixels
+    int step, adaptive, job, pad_s;       // job: index of the step's job in the launch
+    int key_x0, key_dx, key_y0, key_dy;   // a candidate's key: column key_x0 + gx * key_dx, row key_y0 + gy * key_dy (grid indices, or level origins)
+    int szw, szh;                 // level size
+    int mode, xmax, xofs_off, yofs_off, ialpha_off, ibeta_off;      // the level's cv::resize tables (byte offsets into the launch's table blob)
+    double inv_area, ystep;
+};
+struct RoiJobDev {
+    const uint8_t *img; int w, h, stride;
+    int first_step, nsteps, scale_image;
+    const StageRec *stages; int nstages, pair_policy;
+    int slot, pad;
+};
+static constexpr int kRoiMaxWin = 2048;           // windows of one ladder step / pyramid level of a small-image job
+void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep *steps, const unsigned char *tabs, unsigned long long *hits,
+                unsigned hit_cap, int plane_words, int lds_bytes);
+int roi_grant_lds(int bytes);     // dynamic LDS above 64 KiB is granted per function and device (monotonic, process-wide); returns a hipError_t as int
+
 // groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
 void launch_group(hipStream_t st, const CascadeArgs &a, const int *group_thr, int *out, int out_cap, int batch);
 

@@ -16,7 +16,7 @@ parts = {"eye": capi.PartStream(ctx, 0, face_c, pc["righteye"], pc["lefteye"], d
          "nose": capi.PartStream(ctx, 1, face_c, pc["nose"], None, detect_event=1),
          "mouth": capi.PartStream(ctx, 2, face_c, pc["mouth"], None, detect_event=1),
          "ear": capi.PartStream(ctx, 3, face_c, pc["leftear"], pc["rightear"], detect_event=1)}
-base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
+base = [(150, 200, 560), (1100, 260, 620)]          # as bench.py's roi_chain: faces whose parts reach the part cascades' windows on the 320-pixel working image
 JITTER = "--jitter" in sys.argv          # faces change size from frame to frame: the part detectors meet new ROI sizes all the time
 N = 48 if JITTER else N
 frames = [synth.make_bgr(W, H, 40 + i, "natural", [(x + 8 * (i % 16), y, s + ((7 * i) % 23 if JITTER else 0)) for x, y, s in base]) for i in range(N)]

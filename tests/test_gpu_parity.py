@@ -579,29 +579,62 @@ VARIANT_CASES = [
 ]
 
 
+# images whose integral pair fits a workgroup's LDS take the one-launch small-image path (kernels_roi.hip); roi=0 sends them
+# through the large-image path (plan, pre-pass, tiles) like every bigger image: both must agree with the oracle
+@pytest.mark.parametrize("roi", [1, 0])
 @pytest.mark.parametrize("w,h,kind,faces,sf,ms,seed", VARIANT_CASES)
-def test_detect_scale_image(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed):
+def test_detect_scale_image(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed, roi):
     import orc
     from nubovca import capi, synth
     g = orc.equalize_hist(synth.make_gray(w, h, seed, kind, faces))
-    raw = ctx.detect_raw(casc, g, sf, capi.HAAR_SCALE_IMAGE, ms)
-    eraw = orc.detect_raw(orc_cascade, g, sf, orc.HAAR_SCALE_IMAGE, ms)
-    assert np.array_equal(raw, eraw), (len(raw), len(eraw))
-    for mn in (2, 3):
-        det = ctx.detect_multiscale(casc, g, sf, mn, capi.HAAR_SCALE_IMAGE, ms)
-        assert np.array_equal(det, orc.detect_multiscale(orc_cascade, g, sf, mn, orc.HAAR_SCALE_IMAGE, ms))
+    with ctx.options(roi=roi):
+        raw = ctx.detect_raw(casc, g, sf, capi.HAAR_SCALE_IMAGE, ms)
+        eraw = orc.detect_raw(orc_cascade, g, sf, orc.HAAR_SCALE_IMAGE, ms)
+        assert np.array_equal(raw, eraw), (len(raw), len(eraw))
+        for mn in (2, 3):
+            det = ctx.detect_multiscale(casc, g, sf, mn, capi.HAAR_SCALE_IMAGE, ms)
+            assert np.array_equal(det, orc.detect_multiscale(orc_cascade, g, sf, mn, orc.HAAR_SCALE_IMAGE, ms))
 
 
+@pytest.mark.parametrize("roi", [1, 0])
 @pytest.mark.parametrize("w,h,kind,faces,sf,ms,seed", VARIANT_CASES)
-def test_detect_find_biggest(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed):
+def test_detect_find_biggest(ctx, casc, orc_cascade, w, h, kind, faces, sf, ms, seed, roi):
     import orc
     from nubovca import capi, synth
     g = orc.equalize_hist(synth.make_gray(w, h, seed, kind, faces))
-    for flags in (capi.HAAR_FIND_BIGGEST_OBJECT, capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_DO_ROUGH_SEARCH,
-                  capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_SCALE_IMAGE):
-        det = ctx.detect_multiscale(casc, g, sf, 3, flags, ms)
-        exp = orc.detect_multiscale(orc_cascade, g, sf, 3, flags, ms)
-        assert np.array_equal(det, exp), (flags, det, exp)
+    with ctx.options(roi=roi):
+        for flags in (capi.HAAR_FIND_BIGGEST_OBJECT, capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_DO_ROUGH_SEARCH,
+                      capi.HAAR_FIND_BIGGEST_OBJECT | capi.HAAR_SCALE_IMAGE):
+            det = ctx.detect_multiscale(casc, g, sf, 3, flags, ms)
+            exp = orc.detect_multiscale(orc_cascade, g, sf, 3, flags, ms)
+            assert np.array_equal(det, exp), (flags, det, exp)
+
+
+def test_small_image_path_random_geometries(ctx, casc, orc_cascade, casc_small, orc_small):
+    """the one-launch small-image detector on random sizes up to its limit ((w + 1)(h + 2) <= 10240 words), every scan variant,
+    raw lists in OpenCV's order: windows at the image border, rows longer and shorter than a 64-window chunk (the adaptive x
+    step's parity is carried across chunks), pyramid levels down to one window"""
+    import orc
+    from nubovca import capi, synth
+    rng = np.random.RandomState(99)
+    launched = 0
+    ctx.enable_kernel_timing(1)
+    for it in range(40):
+        w = int(rng.randint(21, 200))
+        h = int(rng.randint(21, min(200, 10240 // (w + 1) - 2) + 1))
+        s = int(min(w, h) * rng.uniform(0.4, 0.9))
+        faces = [(int(rng.randint(0, max(1, w - s))), int(rng.randint(0, max(1, h - s))), s)] if s >= 24 else []
+        g = orc.equalize_hist(synth.make_gray(w, h, 3000 + it, ["natural", "noise", "gradient"][it % 3], faces))
+        c, oc = (casc_small, orc_small) if it % 2 else (casc, orc_cascade)
+        sf = float(rng.choice([1.1, 1.2, 1.25]))
+        ms = (int(rng.randint(0, 30)), int(rng.randint(0, 30))) if it % 3 else (0, 0)
+        assert np.array_equal(ctx.detect_raw(c, g, sf, 0, ms), orc.detect_raw(oc, g, sf, 0, ms)), (it, w, h, sf, ms)
+        assert np.array_equal(ctx.detect_raw(c, g, sf, capi.HAAR_SCALE_IMAGE, ms), orc.detect_raw(oc, g, sf, orc.HAAR_SCALE_IMAGE, ms)), (it, w, h, sf, ms)
+        for fl in (0, capi.HAAR_SCALE_IMAGE, capi.HAAR_FIND_BIGGEST_OBJECT):
+            assert np.array_equal(ctx.detect_multiscale(c, g, sf, 2, fl, ms), orc.detect_multiscale(oc, g, sf, 2, fl, ms)), (it, w, h, sf, ms, fl)
+    kt = ctx.kernel_timing()
+    ctx.enable_kernel_timing(0)
+    assert kt.get("cascade_roi", (0, 0))[1] >= 150 and "cascade_tile" not in kt, kt          # every one of these calls was ONE k_roi launch per round
 
 
 def test_detect_roi_view(ctx, casc, orc_cascade):
