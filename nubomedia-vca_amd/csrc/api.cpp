@@ -13,6 +13,9 @@
 #include <chrono>
 #include <stdexcept>
 #include <new>
+#include <thread>
+#include <condition_variable>
+#include <atomic>
 
 using namespace nvca;
 
@@ -125,6 +128,54 @@ int api_catch(nvca_ctx *ctx) noexcept
     return code;
 }
 
+struct WorkPool {
+    std::vector<std::thread> th;
+    std::mutex m; std::condition_variable cv, done;
+    void (*fn)(void *, int) = nullptr; void *arg = nullptr;
+    int n = 0; std::atomic<int> next{0}; int busy = 0, acked = 0; uint64_t gen = 0; bool stop = false;
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen; busy++; acked++;
+            lk.unlock();
+            for (int i; (i = next.fetch_add(1)) < n;) fn(arg, i);
+            lk.lock();
+            if (--busy == 0) done.notify_all();
+        }
+    }
+};
+WorkPool *work_pool_create(int threads)
+{
+    if (threads <= 0) return nullptr;
+    WorkPool *p = new (std::nothrow) WorkPool();
+    if (!p) return nullptr;
+    try { for (int i = 0; i < threads; i++) p->th.emplace_back([p] { p->worker(); }); }
+    catch (...) { }                                     // fewer threads than asked for (or none): the caller works anyway
+    return p;
+}
+void work_pool_destroy(WorkPool *p)
+{
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->m); p->stop = true; }
+    p->cv.notify_all();
+    for (std::thread &t : p->th) t.join();
+    delete p;
+}
+void work_pool_run(WorkPool *p, int n, void (*fn)(void *, int), void *arg)
+{
+    if (!p || p->th.empty() || n < 4) { for (int i = 0; i < n; i++) fn(arg, i); return; }
+    { std::lock_guard<std::mutex> lk(p->m); p->fn = fn; p->arg = arg; p->n = n; p->next.store(0); p->acked = 0; p->gen++; }
+    p->cv.notify_all();
+    for (int i; (i = p->next.fetch_add(1)) < n;) fn(arg, i);          // the caller takes part
+    std::unique_lock<std::mutex> lk(p->m);
+    // every helper has woken for this generation and left its loop: none can still be reading fn / arg / n when the next run sets them
+    p->done.wait(lk, [&] { return p->busy == 0 && p->acked == (int)p->th.size(); });
+}
+
 static Switches read_switches()
 {
     Switches w;
@@ -145,6 +196,7 @@ static Switches read_switches()
     w.plan_debug = set("NVCA_PLAN_DEBUG");
     w.deep_lds = !set("NVCA_DEEP_LDS_OFF");
     w.trk_order = num("NVCA_TRK_ORDER", -1);
+    w.host_threads = num("NVCA_HOST_THREADS", -1);
     w.roi = num("NVCA_ROI", 1) != 0;
     w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
     w.quiet = set("NVCA_QUIET");
@@ -721,6 +773,7 @@ nvca_ctx::~nvca_ctx()
     trk.release_all();
     part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
+    nvca::work_pool_destroy(pool); pool = nullptr;
     overlay_img.release();
     for (auto &kv : roi_stage_recs) { kv.second->release(); delete kv.second; }
     roi_tables.release(); roi_hits.release(); roi_h_tables.release(); roi_h_hits.release();
@@ -810,6 +863,7 @@ try {
     else if (n == "trk_order") w.trk_order = value;
     else if (n == "quiet") w.quiet = value != 0;
     else if (n == "roi") w.roi = value != 0;
+    else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "stage_fuse") w.stage_fuse = value != 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
@@ -2205,10 +2259,38 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
                 for (DetectJob *o : rb.owners) { o->phase = o->roi_prev_phase; o->fused = false; for (int k = 0; k < kJobImages; k++) o->rkeys[k].clear(); }
             } else if (r) rc = r;
         }
+        // the small-path jobs' candidates are turned into rectangles, replayed (FIND_BIGGEST) and grouped job by job: independent
+        // host work, shared with the context's helper threads (a job touches nothing but itself; set_error is locked)
+        std::vector<DetectJob *> par;
+        if (!rc && !roi_again)
+            for (int i = 0; i < n; i++) if (jobs[i]->phase != 3 && jobs[i]->fused) par.push_back(jobs[i]);
+        if (par.size() >= 4) {
+            // the jobs with the most candidates first: the helpers take indices in order, the long ones must not come last
+            auto weight = [](const DetectJob *j) { size_t w = 0; for (int k = 0; k < j->nimg; k++) w += j->rkeys[k].size(); return w; };
+            std::stable_sort(par.begin(), par.end(), [&](const DetectJob *x, const DetectJob *y) { return weight(x) > weight(y); });
+            if (!ctx->pool && !ctx->pool_tried) {
+                ctx->pool_tried = true;
+                int t = ctx->sw.host_threads;
+                if (t < 0) { const int hc = (int)std::thread::hardware_concurrency(); t = std::min(8, hc / 2) - 1; }
+                ctx->pool = work_pool_create(t);
+            }
+            struct Arg { nvca_ctx *ctx; DetectJob **jobs; std::atomic<int> rc; } arg{ctx, par.data(), {0}};
+            work_pool_run(ctx->pool, (int)par.size(), [](void *a, int i) {
+                Arg *g = (Arg *)a;
+                int r;
+                try { r = detect_job_advance(g->ctx, *g->jobs[i]); }
+                catch (const std::bad_alloc &) { r = NVCA_ERR_NOMEM; }
+                catch (...) { r = NVCA_ERR_INTERNAL; }
+                if (r) { g->jobs[i]->phase = 3; int z = 0; g->rc.compare_exchange_strong(z, r); }
+            }, &arg);
+            if (arg.rc.load()) rc = arg.rc.load();
+            for (DetectJob *j : par) j->roi_prev_phase = -1;          // handled
+        }
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
             if (rc) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; continue; }
             if (roi_again && std::find(rb.owners.begin(), rb.owners.end(), jobs[i]) != rb.owners.end()) continue;
+            if (par.size() >= 4 && jobs[i]->roi_prev_phase == -1) { jobs[i]->roi_prev_phase = 0; continue; }
             ctx->cur_lane = lanes ? lanes[i] : lane0;
             const int r = detect_job_advance(ctx, *jobs[i]);
             if (r) rc = r;

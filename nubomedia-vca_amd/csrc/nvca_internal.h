@@ -171,6 +171,7 @@ struct Switches {
     bool plan_debug = false;         // NVCA_PLAN_DEBUG: per-scale tile sizes on stderr
     bool deep_lds = true;            // NVCA_DEEP_LDS_OFF: k_deep without LDS patches
     int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
+    int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
     bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
@@ -216,6 +217,14 @@ struct PartWorkspace {
     hipEvent_t images_done = nullptr;
     void release_all() { arena.release(); tables.release(); hist.release(); luts.release(); h_tables.release(); if (images_done) { (void)hipEventDestroy(images_done); images_done = nullptr; } }
 };
+
+// A few helper threads for host work that is independent per job (the candidate lists of a round's face-region searches are
+// converted, replayed and grouped job by job: 96 jobs of ~50 us on the calling thread were most of a loaded part batch).
+// The caller takes part; run() returns when every index has been handled.  Created on first use, joined with the context.
+struct WorkPool;
+WorkPool *work_pool_create(int threads);
+void work_pool_destroy(WorkPool *p);
+void work_pool_run(WorkPool *p, int n, void (*fn)(void *arg, int i), void *arg);     // p == nullptr: serial
 
 struct DetectPlan;   // plan.cpp
 struct ScaleTable;   // plan.cpp: one cascade at one scale factor (geometry-independent stump records), cached in the context
@@ -274,11 +283,13 @@ struct nvca_ctx {
     // small-image detector (kernels_roi.hip): per-cascade stage records on the device, the tables / candidate list of a launch
     std::map<uint64_t, nvca::DevBuf *> roi_stage_recs;
     nvca::DevBuf roi_tables, roi_hits; nvca::PinnedBuf roi_h_tables, roi_h_hits;
+    nvca::WorkPool *pool = nullptr; bool pool_tried = false;
+    std::mutex err_mu;                // set_error may be called from the helper threads
 #ifdef NVCA_STAMPS
     unsigned long long *stamps = nullptr;
 #endif
     std::recursive_mutex mu;          // serialises entry points: elements on different streaming threads share one context
-    void set_error(const std::string &s) { err = s; }
+    void set_error(const std::string &s) { std::lock_guard<std::mutex> lk(err_mu); err = s; }
     nvca_ctx();
     ~nvca_ctx();
 };

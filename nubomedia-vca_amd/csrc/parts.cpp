@@ -206,6 +206,9 @@ int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *strea
                             int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
 try {
     NVCA_LOCK_OR_FAIL(ctx);
+    // diagnostic (NVCA_PART_STATS): the whole call, entry to the last destructor, next to the phase timers below
+    static double total_acc = 0, phase3_acc = 0;
+    struct Whole { bool on; double t0; ~Whole() { if (on) total_acc += mono_s() - t0; } } whole{ctx->sw.part_stats > 0 && n >= ctx->sw.part_stats, ctx->sw.part_stats > 0 ? mono_s() : 0};
     if (n < 0 || (n > 0 && (!streams || !frames || !n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
     for (int i = 0; i < n; i++) {
         const nvca_part_stream *s = streams[i]; const nvca_frame *f = &frames[i];
@@ -500,15 +503,17 @@ try {
         if (n >= stats_min) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
         else g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
         if (n >= stats_min && ++calls % 8 == 0) {
-            fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f\n",
-                    acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3);
-            acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
+            fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f | merging (previous calls) %.3f, whole call (previous 8) %.3f\n",
+                    acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3,
+                    phase3_acc / 8 * 1e3, total_acc / 8 * 1e3);
+            acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; phase3_acc = 0; total_acc = 0;
         }
     }
 #undef CK
     rollback.armed = false;                // nothing below can fail short of an exception -- which the containers' strong guarantee
                                            // and the ABI barrier turn into an error code; the device work is complete
     // ---- phase 3: merging heuristics, hysteresis, emission -- in stream order
+    struct P3 { bool on; double t0; ~P3() { if (on) phase3_acc += mono_s() - t0; } } p3{whole.on, whole.on ? mono_s() : 0};
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
         nvca_part_stream *s = w.s;

@@ -107,6 +107,22 @@ def tick_event(i):
     return sum(len(a) + len(b) for a, b in res)
 
 
+# where a pipelined tick's wall time goes (the three calls timed separately over a few ticks)
+for i in range(3):
+    tick_pipelined(i)
+acc3 = [0.0, 0.0, 0.0]
+for i in range(3, 15):
+    fb = [fr[(i + 3 * v) % N] for v in range(V)]
+    t0 = time.perf_counter()
+    tk = ctx.face_batch_submit(faces_v, fb)
+    t1 = time.perf_counter()
+    res = capi.part_batch_process(ctx, flat, [fb[v] for v in range(V) for _ in range(4)])
+    t2 = time.perf_counter()
+    ctx.face_batch_collect(tk)
+    t3 = time.perf_counter()
+    acc3[0] += t1 - t0; acc3[1] += t2 - t1; acc3[2] += t3 - t2
+print(json.dumps({"tick_breakdown_ms": {"face_batch_submit": acc3[0] / 12 * 1e3, "part_batch_process": acc3[1] / 12 * 1e3, "face_batch_collect": acc3[2] / 12 * 1e3}}))
+
 K2 = 24
 for name, fn in (("pipelined", tick_pipelined), ("detect_event_pipelined", tick_event)):
     for i in range(3):

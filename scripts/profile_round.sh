@@ -15,5 +15,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc$i.log 2>&1
 done
 python3 $GRAFT_REPO_ROOT/scripts/pmc_summarize.py $OUT > $OUT/pmc_summary.txt 2>&1
+# BASELINE config 3 with its breakdown, and the N > 1 command line as the driver types it (two ranks rehearsed on this one GPU, gloo)
+python3 $GRAFT_REPO_ROOT/scripts/bench_roi_chain.py > $OUT/roi_chain.txt 2> $OUT/roi_chain.err
+NVCA_BENCH_REHEARSAL=1 python3 $GRAFT_REPO_ROOT/bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_gpus2_rehearsal.json 2> $OUT/bench_gpus2_rehearsal.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 cat $OUT/bench.json
