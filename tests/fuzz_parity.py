@@ -99,7 +99,7 @@ while time.time() < t_end:
         g = orc.equalize_hist(synth.make_gray(w, h, int(rng.randint(1 << 30)), str(rng.choice(["natural", "noise", "gradient"]))))
         # a random cascade may let (nearly) every window through: the call re-runs its launch set with lists of the exact size
         # and must still return the reference's boxes (counted: how often the first set would not have fitted)
-        a = ctx.detect_multiscale(gc, g, sf, mn, flags, (ow, oh))
+        a = ctx.detect_multiscale(gc, g, sf, mn, flags, (ow, oh), cap=1 << 16)
         if not (flags & capi.HAAR_FIND_BIGGEST_OBJECT) and len(orc.detect_raw(oc, g, sf, flags & capi.HAAR_SCALE_IMAGE, (ow, oh), cap=1 << 20)) > 16384:
             rounds["overflow_answered"] = rounds.get("overflow_answered", 0) + 1
         b = orc.detect_multiscale(oc, g, sf, mn, flags, (ow, oh), cap=1 << 16)

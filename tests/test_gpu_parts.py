@@ -132,6 +132,35 @@ def test_roi_chain_1080p_batched(env):
     assert tot > 0
 
 
+@pytest.mark.parametrize("opts", [{"host_threads": 0}, {"roi": 0}, {"roi": 0, "host_threads": 0}])
+def test_roi_chain_batched_on_the_other_paths(env, opts):
+    """the batched chain with the per-job host work on the calling thread only (no helper threads), and with the face-region
+    searches on the large-image path (plan + pre-pass + tiles per region) instead of the one-launch small-image detector:
+    the same lists either way"""
+    import torch
+    from nubovca import capi, synth
+    ctx = env[0]
+    V, T = 3, 3
+    kinds = ("eye", "nose", "mouth", "ear")
+    pairs = [[_streams(env, k) for k in kinds] for _ in range(V)]
+    tot = 0
+    with ctx.options(**opts):
+        for t in range(T):
+            frames = [synth.make_bgr(1920, 1080, 160 + 10 * v + t, "natural", [(200 + 150 * v + 10 * t, 150 + 20 * v, 520 + 30 * v), (1150, 300 + 10 * t, 480)] if (v + t) % 4 else [])
+                      for v in range(V)]
+            keep = [torch.from_numpy(f).cuda() for f in frames]
+            torch.cuda.synchronize()
+            fr = [capi.make_frame(k.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for k in keep]
+            res = capi.part_batch_process(ctx, [pairs[v][j][0] for v in range(V) for j in range(4)], [fr[v] for v in range(V) for j in range(4)])
+            for v in range(V):
+                for j in range(4):
+                    ea, eb = pairs[v][j][1].process(frames[v])
+                    ga, gb = res[v * 4 + j]
+                    assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (opts, t, v, kinds[j], ga, ea, gb, eb)
+                    tot += len(ea) + len(eb)
+    assert tot > 20
+
+
 def test_part_batch_mixed_sizes_and_event_mode(env):
     """one batched call with streams of different kinds, frame sizes and modes (own face pass / faces pushed by an upstream
     face detector / gated by process-x-every-4), host frames; five ticks so the merging state takes part"""
