@@ -1444,10 +1444,6 @@ struct DetectJob {
     std::vector<FbStep> ladder; std::vector<std::vector<nvca_rect>> hits; std::vector<char> have; std::vector<int> ladder_of;
     std::vector<nvca_rect> all; nvca_rect scanROI{0, 0, 0, 0}; bool narrowed_done = false; size_t fb_i = 0; int cur_minw = 0, cur_minh = 0;
     int regrown = 0;                                 // launch sets re-run with a larger candidate list (at most one per set)
-    // small-image FIND_BIGGEST: the ladder's full grids are scanned in chunks, largest windows first -- the serial search nearly
-    // always finds its object among the first (large, cheap) steps and never looks at the many small windows behind them
-    size_t fb_have = 0, roi_prev_have = 0;           // ladder steps [0, fb_have) have been scanned on their full grids (or need no scan)
-    long long fb_budget = 0;                         // windows of the next chunk
     // small-image path (kernels_roi.hip): the job's steps of the queued launch and the candidates that came back
     struct RoiStepInfo { double ystep, out_factor; int winw, winh, ladder; };
     bool small = false;                              // the job runs on the small-image path (decided at its first round)
@@ -1760,7 +1756,6 @@ static int fb_replay(nvca_ctx *ctx, DetectJob &j)
                 return 1;                                    // come back with the narrowed scans
             }
         }
-        if (j.small && !narrowed && i >= j.fb_have) { j.fb_i = i; return 2; }      // this step's full grid has not been scanned yet: the next chunk
         j.all.insert(j.all.end(), j.hits[i].begin(), j.hits[i].end());
         if (!j.all.empty() && j.scanROI.w * j.scanROI.h == 0) {
             std::vector<nvca_rect> tmp(j.all);
@@ -1896,40 +1891,27 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
         j.gthr = (!j.raw_only && j.min_neighbors != 0) ? std::max(j.min_neighbors, 1) : 0;
         j.phase = 1;
     } else {
-        if (j.phase == 0 || j.phase == 4) {
-            if (j.phase == 0) {
-                // the ladder of factors, largest first, exactly as the serial loop walks it (fb_enqueue_first)
-                j.ladder.clear();
-                int n_factors = 0; double factor;
-                for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= j.sf)
-                    ;
-                const double inv = 1. / j.sf; factor *= inv;
-                for (; n_factors-- > 0; factor *= inv) j.ladder.push_back(FbStep{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
-                j.hits.assign(j.ladder.size(), {}); j.have.assign(j.ladder.size(), 1);
-                j.all.clear(); j.scanROI = nvca_rect{0, 0, 0, 0}; j.narrowed_done = false; j.fb_i = 0; j.cur_minw = j.minw; j.cur_minh = j.minh;
-                j.fb_have = 0;
-                // the first chunk: about an eighth of the ladder's windows (the large steps are the cheap ones); later chunks double
-                long long total_w = 0;
-                for (const FbStep &fs : j.ladder) total_w += (long long)std::max(0, cv_round((cols - fs.winw) / fs.ystep)) * std::max(0, cv_round((rows - fs.winh) / fs.ystep));
-                j.fb_budget = std::max<long long>(256, total_w / 8);
-            }
-            j.roi_prev_have = j.fb_have;
+        if (j.phase == 0) {
+            // the ladder of factors, largest first, exactly as the serial loop walks it (fb_enqueue_first)
+            j.ladder.clear();
+            int n_factors = 0; double factor;
+            for (n_factors = 0, factor = 1; factor * c.ow < cols - 10 && factor * c.oh < rows - 10; n_factors++, factor *= j.sf)
+                ;
+            const double inv = 1. / j.sf; factor *= inv;
+            for (; n_factors-- > 0; factor *= inv) j.ladder.push_back(FbStep{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
+            j.hits.assign(j.ladder.size(), {}); j.have.assign(j.ladder.size(), 1);
+            j.all.clear(); j.scanROI = nvca_rect{0, 0, 0, 0}; j.narrowed_done = false; j.fb_i = 0; j.cur_minw = j.minw; j.cur_minh = j.minh;
             j.ladder_of.clear();
-            long long used = 0;
-            size_t i = j.fb_have;
-            for (; i < j.ladder.size(); i++) {
+            for (size_t i = 0; i < j.ladder.size(); i++) {
                 const FbStep &fs = j.ladder[i];
-                if (fs.winw < j.minw || fs.winh < j.minh) { i = j.ladder.size(); break; }        // the serial loop ends here
+                if (fs.winw < j.minw || fs.winh < j.minh) break;
                 if (fs.winw > j.maxw || fs.winh > j.maxh) continue;
-                if (used >= j.fb_budget && !steps.empty()) break;
                 ScaleTable *t = roi_table(ctx, rb, c, fs.factor);
                 if (!t) return NVCA_ERR_NOMEM;
                 RoiStep st; roi_step_common(st, *t);
                 if (!roi_grid(cols, rows, fs.ystep, fs.winw, fs.winh, 0, cv_round((cols - fs.winw) / fs.ystep), 0, cv_round((rows - fs.winh) / fs.ystep), st)) continue;
-                used += (long long)(st.endX - st.startX) * (st.endY - st.startY);
                 steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{fs.ystep, 0., fs.winw, fs.winh, (int)i}); j.ladder_of.push_back((int)i);
             }
-            j.fb_have = i; j.fb_budget *= 2;
             j.phase = 1;
         } else {
             // the narrowed set fb_replay asked for: steps fb_i .. on their narrowed grids (j.ladder_of / j.have were set by the replay)
@@ -1950,7 +1932,7 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
         if (nx > kRoiMaxWin) fits = false;                           // (a grid row longer than the queues: not with images this small)
         st.key_x0 = st.startX; st.key_dx = st.step; st.key_y0 = st.startY; st.key_dy = st.step;
     }
-    if (!fits && j.roi_prev_phase != 0) { ctx->set_error("internal: a later round of a search outgrew the small-image path"); return NVCA_ERR_INTERNAL; }   // (its first round fitted)
+    if (!fits && j.roi_prev_phase == 2) { ctx->set_error("internal: a narrowed search outgrew the small-image path"); return NVCA_ERR_INTERNAL; }   // (its full grids fitted)
     if (!fits) { j.phase = j.roi_prev_phase; return NVCA_OK; }       // this one takes the large-image path
     j.fused = true; j.rinfo.swap(info); j.dp = nullptr;
     for (int k = 0; k < kJobImages; k++) j.rkeys[k].clear();
@@ -2111,7 +2093,7 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
         j.dp = nullptr;
         const int r = fb_replay(ctx, j);
         if (r < 0) { j.phase = 3; return r; }
-        j.phase = r == 1 ? 2 : (r == 2 ? 4 : 3);     // 2: the narrowed set, 4: the next chunk of full grids, 3: done
+        j.phase = r == 1 ? 2 : 3;
     }
     j.dp = nullptr;
     return NVCA_OK;
@@ -2274,7 +2256,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             if (r == NVCA_ERR_OVERFLOW && roi_regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
                 // the round's candidate list was too short: its jobs are queued again, with room (see detect_job_advance)
                 roi_regrown++; roi_again = true;
-                for (DetectJob *o : rb.owners) { o->phase = o->roi_prev_phase; o->fb_have = o->roi_prev_have; if (o->phase != 0 && o->fb_budget > 1) o->fb_budget /= 2; o->fused = false; for (int k = 0; k < kJobImages; k++) o->rkeys[k].clear(); }
+                for (DetectJob *o : rb.owners) { o->phase = o->roi_prev_phase; o->fused = false; for (int k = 0; k < kJobImages; k++) o->rkeys[k].clear(); }
             } else if (r) rc = r;
         }
         // the small-path jobs' candidates are turned into rectangles, replayed (FIND_BIGGEST) and grouped job by job: independent
