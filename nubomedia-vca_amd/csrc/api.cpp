@@ -197,6 +197,7 @@ static Switches read_switches()
     w.deep_lds = !set("NVCA_DEEP_LDS_OFF");
     w.trk_order = num("NVCA_TRK_ORDER", -1);
     w.host_threads = num("NVCA_HOST_THREADS", -1);
+    w.two_lanes = num("NVCA_TWO_LANES", 1) != 0;
     w.roi = num("NVCA_ROI", 1) != 0;
     w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
     w.quiet = set("NVCA_QUIET");
@@ -476,7 +477,8 @@ static int cascade_counters(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job
     return NVCA_OK;
 }
 
-static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, CascadeJob &job, const int *group_thr, bool want_group)
+static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int spitch, CascadeJob &job, const int *group_thr, bool want_group,
+                           hipEvent_t early_done = nullptr /* recorded behind the band / tile kernels, ahead of the late stages */)
 {
     Workspace &ws = *ctx->ws;
     ResultBufs &rb = ws.res[ws.cur_res];
@@ -571,6 +573,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
             { TimedLaunch t(ctx, NVCA_K_TILE); if (launch(3)) return NVCA_ERR_HIP; }
             { TimedLaunch t(ctx, NVCA_K_STRIP); if (launch(1)) return NVCA_ERR_HIP; }
         }
+        if (early_done) NVCA_HIP_CHECK(ctx, hipEventRecord(early_done, ctx->cs()));
         { TimedLaunch t(ctx, NVCA_K_DEEP); if (launch(2)) return NVCA_ERR_HIP; }
         }
         // the box tables are small (a few KB per frame): the grouping kernel stores them straight into the page-locked host
@@ -863,6 +866,7 @@ try {
     else if (n == "trk_order") w.trk_order = value;
     else if (n == "quiet") w.quiet = value != 0;
     else if (n == "roi") w.roi = value != 0;
+    else if (n == "two_lanes") w.two_lanes = value != 0;
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "stage_fuse") w.stage_fuse = value != 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
@@ -892,6 +896,7 @@ try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane_streams[kFaceLane2]));      // a submitted batch may run there
 #ifdef NVCA_STAMPS
     if (ctx->stamps && switches().stamps_out) {
         std::vector<unsigned long long> h(64 * 16 * 64);
@@ -2502,6 +2507,11 @@ struct FaceTicket {
     struct Group { GeomPlan *gp; std::vector<int> idx, gthr; std::vector<CascadeJob> jobs; };
     std::vector<Group> groups;
     hipEvent_t done = nullptr;
+    // Two batches in flight run on two lanes (stream + planes each).  The second one's pre-processing (gray, LUT, integral:
+    // bandwidth-bound) waits for the first one's band kernel and then runs beside its late-stage and grouping kernels (a few
+    // hundred small workgroups that leave most of the GPU idle) -- not beside the band kernel itself, which wants every wave slot.
+    int lane = 0;
+    hipEvent_t band_done = nullptr;
 };
 }
 
@@ -2518,6 +2528,16 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     }
     Workspace &ws = *ctx->ws;
     struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);   // every other entry point works on set 0
+    // the lane of this batch: the synchronous call and the first submitted batch on lane 0, the second submitted batch on its own
+    tk.lane = (res == 2 && ctx->sw.two_lanes) ? kFaceLane2 : 0;
+    struct UseLane { nvca_ctx *c; int old; UseLane(nvca_ctx *x, int l) : c(x), old(x->cur_lane) { c->cur_lane = l; } ~UseLane() { c->cur_lane = old; } } use_lane(ctx, tk.lane);
+    if (!tk.band_done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.band_done, hipEventDisableTiming));
+    for (int o = 1; o < 3; o++) {
+        // a batch in flight on the other lane: this one's kernels start behind its band kernel (see FaceTicket)
+        FaceTicket *ot = ctx->face_tickets[o];
+        if (o != res && ot && ot->pending && ot->lane != tk.lane && ot->band_done) NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->cs(), ot->band_done, 0));
+    }
+    bool band_recorded = false;
     tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();
     std::vector<FrameWork> &work = tk.work;
     // ---- pass 1: geometry + gating, in frame order
@@ -2630,11 +2650,13 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
             ws.ln().hist_clean = hist_clean;
             run_integral(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc);
             if (streams[idx[0]]->cascade->c.has_tilted && (rc = run_tilted(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc))) return rc;
-            if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true))) return rc;   // detectMultiScale :809-811
+            if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true, tk.band_done))) return rc;   // detectMultiScale :809-811
+            band_recorded = true;
             jobs.push_back(job);
         }
         gbase += batch;
     }
+    if (!band_recorded) NVCA_HIP_CHECK(ctx, hipEventRecord(tk.band_done, ctx->cs()));       // nothing analysed: nothing to wait for
     if (!tk.done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
     NVCA_HIP_CHECK(ctx, hipEventRecord(tk.done, ctx->cs()));
     tk.pending = true;
@@ -2654,6 +2676,7 @@ static int face_collect(nvca_ctx *ctx, int res, FaceTicket &tk, nvca_rect *out, 
     (void)hipSetDevice(ctx->device);
     Workspace &ws = *ctx->ws;
     struct UseRes { Workspace &w; UseRes(Workspace &x, int r) : w(x) { w.cur_res = r; } ~UseRes() { w.cur_res = 0; } } use_res(ws, res);
+    struct UseLane { nvca_ctx *c; int old; UseLane(nvca_ctx *x, int l) : c(x), old(x->cur_lane) { c->cur_lane = l; } ~UseLane() { c->cur_lane = old; } } use_lane(ctx, tk.lane);
     const int n = tk.n;
     hipError_t he = hipEventSynchronize(tk.done);
     if (he != hipSuccess) { ctx->set_error(std::string("hipEventSynchronize: ") + hipGetErrorString(he)); face_release(tk); return NVCA_ERR_HIP; }
@@ -2699,6 +2722,7 @@ void nvca::free_face_ticket(FaceTicket *t)
 {
     if (!t) return;
     if (t->done) (void)hipEventDestroy(t->done);
+    if (t->band_done) (void)hipEventDestroy(t->band_done);
     delete t;
 }
 
@@ -2741,7 +2765,7 @@ try {
     FaceTicket &tk = ticket_slot(ctx, k);
     tk.serial = ++ctx->face_serial;
     int rc = face_submit(ctx, n, streams, frames, k, tk);
-    if (rc) { (void)hipStreamSynchronize(ctx->cs()); face_release(tk); return rc; }
+    if (rc) { (void)hipStreamSynchronize(ctx->lane_streams[tk.lane]); face_release(tk); return rc; }
     *ticket = k;
     return NVCA_OK;
 }

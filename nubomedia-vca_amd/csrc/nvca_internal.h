@@ -172,6 +172,7 @@ struct Switches {
     bool deep_lds = true;            // NVCA_DEEP_LDS_OFF: k_deep without LDS patches
     int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
+    bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
     bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
@@ -250,7 +251,11 @@ struct KernelTimer {
 
 struct nvca_cascade { nvca::Cascade c; nvca_ctx *ctx; };
 
-namespace nvca { static constexpr int kLanes = 8; }
+namespace nvca {
+static constexpr int kLanes = 9;          // lane 0: the context's stream; 1 .. 7: the batched part detectors; 8: the face detector's second batch in flight
+static constexpr int kPartLanes = 8;      // lanes [0, kPartLanes) are the ones the part detectors spread over
+static constexpr int kFaceLane2 = 8;
+}
 
 struct nvca_ctx {
     int device = 0;

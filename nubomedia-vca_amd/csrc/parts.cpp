@@ -327,7 +327,7 @@ try {
             FrameGroup &fg = groups.back();
             fg.data = f->data; fg.w = W; fg.h = H; fg.stride = f->stride; fg.mem = f->mem;
         }
-        w.lane = n > 1 ? 1 + w.group % (kLanes - 1) : 0;     // the part searches of one frame's streams share a lane
+        w.lane = n > 1 ? 1 + w.group % (kPartLanes - 1) : 0;     // the part searches of one frame's streams share a lane
         // the images this stream works on: requested here, computed below for all streams at once
         if (kind == NVCA_PART_EYE) {
             FrameGroup &fg = groups[w.group];
@@ -421,7 +421,7 @@ try {
                 if (fp.type == 2)          // ... and the mirrored images (EAR :796-803): results k + count
                     for (size_t m = m0; m < m1; m++) if (detect_job_add_image(job, b.base + b.slot * (b.members.size() + fp.members[m])) < 0) return NVCA_ERR_ARG;
                 const int lane = n > 1 ? next_lane : 0;
-                next_lane = next_lane + 1 < kLanes ? next_lane + 1 : 2;
+                next_lane = next_lane + 1 < kPartLanes ? next_lane + 1 : 2;
                 jobs.push_back(job); job_lane.push_back(lane); used_lanes.push_back(lane);
             }
         }
