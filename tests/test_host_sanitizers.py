@@ -142,3 +142,20 @@ def test_glue_under_sanitizers_matches_the_oracle(driver, tmp_path):
                 seen += 1
     assert seen == 400
     assert any("merges_checksum" in o for o in out)
+
+
+def test_work_pool_under_thread_sanitizer():
+    """the helper-thread pool of the per-job host work (csrc/work_pool.cpp), thousands of back-to-back runs under TSan"""
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ with sanitizer runtimes")
+    out = os.path.join(SAN, "build", "pool_driver")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    srcs = [os.path.join(SAN, "pool_driver.cpp"), os.path.join(ROOT, "nubomedia-vca_amd", "csrc", "work_pool.cpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in srcs):
+        r = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread"] + srcs + ["-o", out], capture_output=True, text=True)
+        if r.returncode != 0 and "tsan" in r.stderr.lower():
+            pytest.skip("no TSan runtime")
+        assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pool ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
