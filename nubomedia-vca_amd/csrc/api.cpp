@@ -152,6 +152,7 @@ static Switches read_switches()
     w.two_lanes = num("NVCA_TWO_LANES", 1) != 0;
     w.roi = num("NVCA_ROI", 1) != 0;
     w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
+    w.pre_cus = num("NVCA_PRE_CUS", 0);
     w.quiet = set("NVCA_QUIET");
     w.stamps_out = getenv("NVCA_STAMPS_OUT");
     return w;
@@ -737,6 +738,7 @@ nvca_ctx::~nvca_ctx()
     for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
     for (hipEvent_t e : chunk_events) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    for (int k = 0; k < 2; k++) { if (pre_streams[k]) (void)hipStreamDestroy(pre_streams[k]); if (pre_done[k]) (void)hipEventDestroy(pre_done[k]); }
     for (int l = 1; l < nvca::kLanes; l++) if (lane_streams[l]) (void)hipStreamDestroy(lane_streams[l]);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -821,6 +823,7 @@ try {
     else if (n == "two_lanes") w.two_lanes = value != 0;
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "stage_fuse") w.stage_fuse = value != 0;
+    else if (n == "pre_cus") w.pre_cus = value > 0 ? value : 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
     else if (n == "tiles") { w.tiles = value != 0; replan = true; }
@@ -2484,11 +2487,38 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
     tk.lane = (res == 2 && ctx->sw.two_lanes) ? kFaceLane2 : 0;
     struct UseLane { nvca_ctx *c; int old; UseLane(nvca_ctx *x, int l) : c(x), old(x->cur_lane) { c->cur_lane = l; } ~UseLane() { c->cur_lane = old; } } use_lane(ctx, tk.lane);
     if (!tk.band_done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&tk.band_done, hipEventDisableTiming));
+    // "pre_cus" = n: the pre-processing of a submitted batch runs on a stream of its own that is confined to n compute units
+    // (4 per XCD at 32: the mask's bits go round the XCDs first), beside the other batch's band kernel instead of behind it: the
+    // band kernel loses those CUs' share of its workgroups for as long as the bandwidth-bound kernels run there and keeps every
+    // wave slot of the others (spread over all CUs the same kernels keep band workgroups from starting everywhere: DESIGN 6)
+    hipStream_t pre_stream = nullptr; int pre_k = 0;
+    if (res > 0 && ctx->sw.two_lanes && ctx->sw.pre_cus > 0) {
+        pre_k = res == 2 ? 1 : 0;
+        if (ctx->pre_streams_cus != ctx->sw.pre_cus) {
+            for (int k = 0; k < 2; k++) if (ctx->pre_streams[k]) { (void)hipStreamSynchronize(ctx->pre_streams[k]); (void)hipStreamDestroy(ctx->pre_streams[k]); ctx->pre_streams[k] = nullptr; }
+            ctx->pre_streams_cus = ctx->sw.pre_cus;
+        }
+        if (!ctx->pre_streams[pre_k]) {
+            uint32_t mask[16] = {0};
+            for (int b = 0; b < std::min(ctx->sw.pre_cus, 512); b++) mask[b >> 5] |= 1u << (b & 31);
+            if (hipExtStreamCreateWithCUMask(&ctx->pre_streams[pre_k], 16, mask) != hipSuccess) { (void)hipGetLastError(); ctx->pre_streams[pre_k] = nullptr; }
+        }
+        if (!ctx->pre_done[pre_k] && hipEventCreateWithFlags(&ctx->pre_done[pre_k], hipEventDisableTiming) != hipSuccess) ctx->pre_done[pre_k] = nullptr;
+        if (ctx->pre_streams[pre_k] && ctx->pre_done[pre_k]) pre_stream = ctx->pre_streams[pre_k];
+    }
+    if (!pre_stream)
     for (int o = 1; o < 3; o++) {
         // a batch in flight on the other lane: this one's kernels start behind its band kernel (see FaceTicket)
         FaceTicket *ot = ctx->face_tickets[o];
         if (o != res && ot && ot->pending && ot->lane != tk.lane && ot->band_done) NVCA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->cs(), ot->band_done, 0));
     }
+    // while the pre-processing is being queued the lane's stream IS the confined one; the lane's own stream picks up behind it
+    struct PreSwap {
+        nvca_ctx *c; int lane; hipStream_t own, pre; hipEvent_t ev; bool on = false;
+        int begin() { if (!pre || on) return 0; hipError_t e = hipEventRecord(ev, own); if (e == hipSuccess) e = hipStreamWaitEvent(pre, ev, 0); if (e != hipSuccess) return 1; c->lane_streams[lane] = pre; on = true; return 0; }
+        int end() { if (!on) return 0; c->lane_streams[lane] = own; on = false; hipError_t e = hipEventRecord(ev, pre); if (e == hipSuccess) e = hipStreamWaitEvent(own, ev, 0); return e != hipSuccess; }
+        ~PreSwap() { if (on) { c->lane_streams[lane] = own; (void)hipStreamSynchronize(pre); } }
+    } pre_swap{ctx, tk.lane, ctx->lane_streams[tk.lane], pre_stream, pre_stream ? ctx->pre_done[pre_k] : nullptr};
     bool band_recorded = false;
     tk.n = n; tk.streams.assign(streams, streams + n); tk.work.assign(n, FrameWork()); tk.groups.clear();
     std::vector<FrameWork> &work = tk.work;
@@ -2574,6 +2604,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
         std::vector<CascadeJob> &jobs = grp.jobs;
         for (int s0 = 0; s0 < batch; s0 += chunk) {
             const int nc = std::min(chunk, batch - s0);
+            if (pre_swap.begin()) { ctx->set_error("event hand-over to the confined stream failed"); return NVCA_ERR_HIP; }
             if ((rc = stage_frames(ctx, frames, idx.data() + s0, nc, 3, gbase + s0, piped ? ctx->copy_stream : ctx->cs(), &stage_off, &gp->rowcopy))) return rc;
             if (piped) {
                 while (ctx->chunk_events.size() <= jobs.size()) {
@@ -2602,6 +2633,7 @@ static int face_submit(nvca_ctx *ctx, int n, nvca_face_stream *const *streams, c
             ws.ln().hist_clean = hist_clean;
             run_integral(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc);
             if (streams[idx[0]]->cascade->c.has_tilted && (rc = run_tilted(ctx, gp->g, ws.ln().lut.as<uint8_t>(), nc))) return rc;
+            if (pre_swap.end()) { ctx->set_error("event hand-over from the confined stream failed"); return NVCA_ERR_HIP; }
             if ((rc = cascade_enqueue(ctx, gp->det, gp->g.sum_slot, gp->g.spitch, job, gthr.data() + s0, true, tk.band_done))) return rc;   // detectMultiScale :809-811
             band_recorded = true;
             jobs.push_back(job);

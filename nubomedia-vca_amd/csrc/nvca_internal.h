@@ -175,6 +175,7 @@ struct Switches {
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
     bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
+    int  pre_cus = 0;                // NVCA_PRE_CUS=n: a submitted face batch's pre-processing runs on a stream confined to n CUs (hipExtStreamCreateWithCUMask), beside the other batch's band kernel (0: behind it, on the lane's own stream)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
     const char *stamps_out = nullptr;   // NVCA_STAMPS_OUT (diagnostic build only)
 };
@@ -263,6 +264,9 @@ struct nvca_ctx {
     hipStream_t lane_streams[nvca::kLanes] = {nullptr};   // [0] == stream; the others carry the batched part detectors' jobs (api.cpp, Lane)
     int cur_lane = 0;
     hipStream_t cs() const { return lane_streams[cur_lane]; }       // the stream of the lane that is being queued on
+    hipStream_t pre_streams[2] = {nullptr, nullptr};   // CU-masked streams for the pre-processing of the two face batches in flight ("pre_cus"), created on first use
+    int pre_streams_cus = 0;                  // the CU count they were created for
+    hipEvent_t pre_done[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
     nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect
