@@ -1,0 +1,47 @@
+/* abrt_trace.c -- test infrastructure: prints the C call stack of whoever raises SIGABRT (glibc's heap checks, std::terminate,
+ * a runtime's abort()) to stderr, then hands over to the handler that was installed before (Python's faulthandler, which
+ * shows the Python frames only) or to the default action.  tests/conftest.py builds and loads it (abrt_trace_install) on
+ * every test run, so that an abort in a GPU test run leaves evidence; also usable as LD_PRELOAD.  Never loaded by the product. */
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
+#include <string.h>
+#include <unistd.h>
+
+static struct sigaction prev_sa;
+static int out_fd = 2;
+static volatile sig_atomic_t fired;
+
+static void on_abrt(int sig)
+{
+    void *frames[64];
+    static const char head[] = "\n=== abrt_trace: SIGABRT, C call stack of the raising thread ===\n";
+    if (fired) { signal(sig, SIG_DFL); raise(sig); return; }      /* second time round (handlers chained to each other): die */
+    fired = 1;
+    (void)!write(out_fd, head, sizeof(head) - 1);
+    int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, out_fd);
+    sigaction(sig, &prev_sa, 0);      /* faulthandler's (or the default): it gets the re-raised signal */
+    raise(sig);
+}
+
+void abrt_trace_install(int fd)       /* fd: where to write (a duplicate of the real stderr: the test runner redirects fd 2) */
+{
+    if (fd >= 0) out_fd = fd;
+    struct sigaction cur;
+    if (sigaction(SIGABRT, 0, &cur) == 0 && cur.sa_handler == on_abrt) return;      /* already on top */
+    void *warm[2];
+    backtrace(warm, 2);               /* loads libgcc now, not inside the handler */
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_abrt;
+    sa.sa_flags = SA_NODEFER;
+    sigaction(SIGABRT, &sa, &prev_sa);
+}
+
+__attribute__((constructor)) static void on_load(void)
+{
+    /* as LD_PRELOAD the shim is in place before anything else; loaded from conftest.py the explicit call re-installs it on
+     * top of whatever the test runner put there in the meantime */
+    abrt_trace_install(-1);
+}
