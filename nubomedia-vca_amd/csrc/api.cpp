@@ -852,6 +852,7 @@ try {
     if (!ctx) return NVCA_ERR_ARG;
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane_streams[kFaceLane2]));      // a submitted batch may run there
+    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane_streams[kTrackerLane]));
 #ifdef NVCA_STAMPS
     if (ctx->stamps && switches().stamps_out) {
         std::vector<unsigned long long> h(64 * 16 * 64);

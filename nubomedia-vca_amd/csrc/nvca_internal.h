@@ -253,9 +253,10 @@ struct KernelTimer {
 struct nvca_cascade { nvca::Cascade c; nvca_ctx *ctx; };
 
 namespace nvca {
-static constexpr int kLanes = 9;          // lane 0: the context's stream; 1 .. 7: the batched part detectors; 8: the face detector's second batch in flight
+static constexpr int kLanes = 10;         // lane 0: the context's stream; 1 .. 7: the batched part detectors; 8: the face detector's second batch in flight; 9: the trackers
 static constexpr int kPartLanes = 8;      // lanes [0, kPartLanes) are the ones the part detectors spread over
 static constexpr int kFaceLane2 = 8;
+static constexpr int kTrackerLane = 9;    // NuboTracker's kernels: its state and workspace are its own, so a face batch in flight (lane 0 / 8) and a tracker call overlap
 }
 
 struct nvca_ctx {

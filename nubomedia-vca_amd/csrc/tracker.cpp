@@ -39,7 +39,7 @@ void nvca_tracker_destroy(nvca_tracker *t)
 try {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipStreamSynchronize(t->ctx->lane_streams[kTrackerLane]);
     t->prev.release(); t->mhi.release();
     delete t;
 }
@@ -59,6 +59,8 @@ try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ctx || n < 0 || (n > 0 && (!trackers || !frames || !ts || !n_out)) || cap < 0 || (cap > 0 && !out)) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
+    // the trackers' lane: a stream of its own, so the call neither queues behind a face batch in flight nor waits for it
+    struct UseLane { nvca_ctx *c; int old; UseLane(nvca_ctx *x, int l) : c(x), old(x->cur_lane) { c->cur_lane = l; } ~UseLane() { c->cur_lane = old; } } use_lane(ctx, kTrackerLane);
     ctx->timer.tick(1);
     for (int i = 0; i < n; i++) {
         n_out[i] = 0;
@@ -86,8 +88,8 @@ try {
             nvca_tracker *t = trackers[idx[b]];
             if (t->w != W || t->h != H) {
                 if (t->prev.ensure(N + 64) || t->mhi.ensure(N * sizeof(float) + 64)) { ctx->set_error("tracker state allocation failed"); return NVCA_ERR_NOMEM; }
-                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->mhi.p, 0, N * sizeof(float), ctx->stream));
-                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->prev.p, 0, N, ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->mhi.p, 0, N * sizeof(float), ctx->cs()));
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(t->prev.p, 0, N, ctx->cs()));
                 t->w = W; t->h = H;
             }
             const nvca_frame &f = frames[idx[b]];
@@ -108,7 +110,7 @@ try {
             memset(&s, 0, sizeof(s));
             if (f.mem == NVCA_MEM_HOST) {
                 uint8_t *d = ws.staging.as<uint8_t>() + off;
-                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (H - 1) + (size_t)W * 4, hipMemcpyHostToDevice, ctx->stream));
+                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (H - 1) + (size_t)W * 4, hipMemcpyHostToDevice, ctx->cs()));
                 s.src = d; off += ((size_t)f.stride * H + 255) / 256 * 256;
             } else s.src = (const uint8_t *)f.data;
             s.prev = t->prev.as<uint8_t>(); s.mhi = t->mhi.as<float>();
@@ -118,29 +120,29 @@ try {
             s.has_prev = t->num_frames > 0; s.sstride = f.stride;
             s.min_area = t->p.min_area; s.max_area = (long long)t->p.max_area;
         }
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->stream));
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->stream));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->cs()));
         { TimedLaunch tl(ctx, NVCA_K_TRACKER);
-          launch_tracker(ctx->stream, ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>(), ctx->sw.trk_order); }
+          launch_tracker(ctx->cs(), ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>(), ctx->sw.trk_order); }
         NVCA_LAUNCH_CHECK(ctx);
         tp1 = std::chrono::steady_clock::now();
         int *ho = ws.h_out.as<int>();
         int total = 0;
         if (any_ccl) {
             const int first = 1024;
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->stream));
-            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->cs()));
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
             total = ho[0];
             if (total < 0) { ctx->set_error("internal: negative component count"); return NVCA_ERR_INTERNAL; }
             if (total > kCompCap) { ctx->set_error("tracker: more motion components than the list holds"); return NVCA_ERR_OVERFLOW; }
             if (total > first) {
                 NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho + 2 + 6 * (size_t)first, ws.out.as<int>() + 2 + 6 * (size_t)first,
-                                                   sizeof(int) * 6 * (size_t)(total - first), hipMemcpyDeviceToHost, ctx->stream));
-                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                                   sizeof(int) * 6 * (size_t)(total - first), hipMemcpyDeviceToHost, ctx->cs()));
+                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
             }
         } else
-            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
         tp2 = std::chrono::steady_clock::now(); total_comps += total;
         // seed order (raster order of each component's first seed pixel) = cvSegmentMotion's output order
         std::vector<std::vector<std::pair<int, nvca_rect>>> comps(batch);
