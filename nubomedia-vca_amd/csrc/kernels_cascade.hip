@@ -590,11 +590,11 @@ __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec 
 {
     TileLds L;
     L.psum = (double *)lds;
-    L.q0 = (unsigned short *)(lds + kTileThreads * 8);
-    L.winx = L.q0 + 2 * kTileWin * kTileWin; L.winy = L.winx + kTileWin;
+    L.q0 = (unsigned short *)(lds + kTileSlots * 8);
+    L.winx = L.q0 + 2 * kTileSlots; L.winy = L.winx + kTileWin;
     L.qn = (int *)(L.winy + kTileWin);                       // qn[0..2] rotating queue counters, qn[3] = list base
     L.vnf_s = (double *)((unsigned char *)L.qn + 64);
-    L.rej = (unsigned *)(L.vnf_s + kTileWin * kTileWin);
+    L.rej = (unsigned *)(L.vnf_s + kTileSlots);
     L.carry = (int *)(L.rej + kTileWin);
     L.cmap = (unsigned short *)(L.carry + kTileWin);
     L.rmap = L.cmap + ((t.span_x + 3) & ~3);
@@ -718,8 +718,8 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
 #endif
         const int cout = cin == 2 ? 0 : cin + 1;
         if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
-        const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
-        unsigned short *qo = L.q0 + (cur ^ 1) * kTileWin * kTileWin;
+        const unsigned short *qi = L.q0 + cur * kTileSlots;
+        unsigned short *qo = L.q0 + (cur ^ 1) * kTileSlots;
         const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
         int adv = 1;
@@ -807,7 +807,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     if (tid == 0) L.qn[3] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
     __syncthreads();
     const unsigned gb = (unsigned)L.qn[3];
-    const unsigned short *qi = L.q0 + cur * kTileWin * kTileWin;
+    const unsigned short *qi = L.q0 + cur * kTileSlots;
     for (int i = tid; i < nh; i += kTileThreads) {
         const int w = qi[i], ix = t.ix0 + (w & 31);
         const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)ix;
@@ -881,21 +881,25 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         int *acc = (int *)L0.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;          // stage accumulators (tile_stages)
         if (tid < 2 * kStatStages) L0.qn[4 + tid] = 0;                                  // no tile seen yet
     }
-    static_assert(kTileWin * kTileWin == kTileThreads, "one window per thread and tile");
+    static_assert(kTileSlots == kTileThreads, "one window per thread and tile");
     const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band
+    // The coordinates of a tile (its record, this thread's list entries and window origin) are requested one tile ahead, right
+    // behind the previous tile's sample transfers: their round trip passes under those transfers instead of standing at the
+    // head of every tile (768 threads leave the registers for it)
+    TileRec t = load_const(a.tiles + b.first_tile);
+    TileCoords tc = tile_coords(a, t, sc);
+    int oxw = 0, oyw = 0;
+    if (ry < t.ny && rx < t.nx) { oxw = a.pos[sc.xpos_off + t.ix0 + rx]; oyw = a.pos[sc.ypos_off + t.iy0 + ry]; }
     for (int ti = 0; ti < b.ntiles; ti++) {
         __syncthreads();             // previous tile completely done with LDS
         NVCA_STAMP(a, ti, 0);
-        const TileRec t = load_const(a.tiles + b.first_tile + ti);
         const TileLds L = carve_tile(lds, t);
-        // this thread's window: its origin comes straight from the position tables, so that the four (eight) squared-integral
-        // corners -- uncoalesced global reads -- are requested before the tile's samples and arrive under their transfer
+        // this thread's window: the four (eight) squared-integral corners -- uncoalesced global reads -- are requested before the
+        // tile's samples and arrive under their transfer
         const bool active = ry < t.ny && rx < t.nx;
-        int xw = 0, yw = 0;
+        int xw = oxw, yw = oyw;
         unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-        if (active) { xw = a.pos[sc.xpos_off + t.ix0 + rx]; yw = a.pos[sc.ypos_off + t.iy0 + ry]; }
-        const TileCoords tc = tile_coords(a, t, sc);            // round 1: coordinates
-        if (active) {                                            // round 2: the squared-integral corners, then the samples
+        if (active) {
             xw -= t.x0; yw -= t.y0;
             const unsigned off = (unsigned)((t.y0 + yw) * sc.pitch + t.x0 + xw);
             const unsigned e0 = off + sc.eq[0], e1 = off + sc.eq[1], e2 = off + sc.eq[2], e3 = off + sc.eq[3];
@@ -905,6 +909,12 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         NVCA_STAMP(a, ti, 1);
         tile_commit(a, t, sc, slot, L, tc);
         if (tid < kStatStages) L.qn[4 + ((ti + 1) & 1) * kStatStages + tid] = 0;       // the survivor counts this tile will write
+        TileRec tn = t; TileCoords tcn = tc; int nxw = 0, nyw = 0;
+        if (ti + 1 < b.ntiles) {                                 // the next tile's coordinates
+            tn = load_const(a.tiles + b.first_tile + ti + 1);
+            tcn = tile_coords(a, tn, sc);
+            if (ry < tn.ny && rx < tn.nx) { nxw = a.pos[sc.xpos_off + tn.ix0 + rx]; nyw = a.pos[sc.ypos_off + tn.iy0 + ry]; }
+        }
         NVCA_STAMP(a, ti, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
         __syncthreads();
@@ -964,6 +974,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         }
         NVCA_STAMP(a, ti, 5);
         tile_stages<true>(a, t, sc, slot, L, ti, ti & 1);
+        t = tn; tc = tcn; oxw = nxw; oyw = nyw;
     }
 }
 

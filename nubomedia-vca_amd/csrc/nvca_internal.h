@@ -120,9 +120,13 @@ struct DeepRec { int col_off, ncol, row_off, nrow, span_x, span_y, pad0, pad1; }
 static constexpr int kDeepMaxSide = 64;            // patch side (distinct columns / rows)
 static constexpr int kDeepMaxSpan = 1280;          // largest corner offset + 1 the patch maps cover
 struct BandRec { int scale, iy0, ny, first_tile, ntiles, pad0, pad1, pad2; };
-static constexpr int kTileWin = 32;                 // windows per tile side (window id = ry * 32 + rx)
-static constexpr int kTileThreads = 1024;
-static constexpr int kTileLdsBudget = 80 * 1024 - 512;   // two tiles resident per CU (160 KiB LDS)
+static constexpr int kTileWin = 32;                 // windows per tile row (window id = ry * 32 + rx)
+static constexpr int kTileRows = 24;                // window rows per tile
+static constexpr int kTileSlots = kTileWin * kTileRows;   // windows per tile = queue capacity = threads of the tile kernels
+// 768 threads: two tile workgroups take 24 of a CU's 32 wave slots (and 85 registers each) -- the bandwidth-bound
+// pre-processing kernels of the next batch fit beside them without ever keeping a tile workgroup from starting
+static constexpr int kTileThreads = kTileSlots;
+static constexpr int kTileLdsBudget = 76 * 1024;   // two tiles resident per CU (160 KiB LDS) and 8 KiB left for small workgroups beside them
 static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
 // LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
 __host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
@@ -130,7 +134,7 @@ __host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
 // (band kernel) | per-row stage-0 reject words and carried run parity (band kernel)
 __host__ __device__ inline int tile_lds_fixed()
 {
-    return kTileThreads * 8 + 2 * kTileWin * kTileWin * 2 + 4 * kTileWin + 64 + kTileWin * kTileWin * 8 + 8 * kTileWin;
+    return kTileSlots * 8 + 2 * kTileSlots * 2 + 4 * kTileWin + 64 + kTileSlots * 8 + 8 * kTileWin;
 }
 __host__ __device__ inline int tile_lds_bytes(int ncol, int nrow, int span_x, int span_y)
 {

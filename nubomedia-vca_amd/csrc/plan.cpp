@@ -279,7 +279,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
     int max_tile = kTileWin;
     {
         long long tiles32 = 0;
-        for (const ScaleSpec &sp : specs) tiles32 += (long long)((sp.xs.size() + kTileWin - 1) / kTileWin) * (long long)((sp.ys.size() + kTileWin - 1) / kTileWin);
+        for (const ScaleSpec &sp : specs) tiles32 += (long long)((sp.xs.size() + kTileWin - 1) / kTileWin) * (long long)((sp.ys.size() + kTileRows - 1) / kTileRows);
         if (tiles32 < 128) max_tile = 16;
     }
     for (size_t s = 0; s < specs.size(); s++) {
@@ -344,8 +344,9 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                     coords(xp, i0, std::min(i0 + tw, sr.endX), offx, cx);
                     worst_c = std::max(worst_c, (int)cx.size()); worst_sx = std::max(worst_sx, cx.back() - xp[i0] + 1);
                 }
-                for (int i0 = 0; i0 < sr.endY; i0 += tw) {
-                    coords(yp, i0, std::min(i0 + tw, sr.endY), offy, cy);
+                const int th = std::min(tw, kTileRows);         // a tile is tw windows wide and up to kTileRows high (a window per thread)
+                for (int i0 = 0; i0 < sr.endY; i0 += th) {
+                    coords(yp, i0, std::min(i0 + th, sr.endY), offy, cy);
                     worst_r = std::max(worst_r, (int)cy.size()); worst_sy = std::max(worst_sy, cy.back() - yp[i0] + 1);
                 }
                 ok = worst_c <= kTileMaxCols && worst_r <= kTileThreads && worst_r * tile_pitch(worst_c) < 65536 &&
@@ -358,10 +359,11 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                 }
             }
             if (tw >= 1) {
-                for (int iy0 = 0; iy0 < sr.endY; iy0 += tw) {
-                    coords(yp, iy0, std::min(iy0 + tw, sr.endY), offy, cy);
+                const int th = std::min(tw, kTileRows);
+                for (int iy0 = 0; iy0 < sr.endY; iy0 += th) {
+                    coords(yp, iy0, std::min(iy0 + th, sr.endY), offy, cy);
                     BandRec b; memset(&b, 0, sizeof(b));
-                    b.scale = (int)s; b.iy0 = iy0; b.ny = std::min(tw, sr.endY - iy0); b.first_tile = (int)tiles.size();
+                    b.scale = (int)s; b.iy0 = iy0; b.ny = std::min(th, sr.endY - iy0); b.first_tile = (int)tiles.size();
                     b.ntiles = (sr.endX + tw - 1) / tw;
                     bands.push_back(b);
                     const int row_off = (int)tcoords.size();
@@ -370,7 +372,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                         coords(xp, ix0, std::min(ix0 + tw, sr.endX), offx, cx);
                         TileRec t; memset(&t, 0, sizeof(t));
                         t.scale = (int)s; t.ix0 = ix0; t.iy0 = iy0;
-                        t.nx = std::min(tw, sr.endX - ix0); t.ny = std::min(tw, sr.endY - iy0);
+                        t.nx = std::min(tw, sr.endX - ix0); t.ny = std::min(th, sr.endY - iy0);
                         t.x0 = xp[ix0]; t.y0 = yp[iy0];
                         t.ncol = (int)cx.size(); t.nrow = (int)cy.size();
                         t.span_x = cx.back() - t.x0 + 1; t.span_y = cy.back() - t.y0 + 1;

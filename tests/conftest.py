@@ -21,7 +21,7 @@ def _abort_evidence():
         out = os.path.join(ROOT, "tests", "san", "build", "abrt_trace.so")
         if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
             os.makedirs(os.path.dirname(out), exist_ok=True)
-            subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-g", "-o", out, src], check=True, capture_output=True, timeout=120)
+            subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-g", "-o", out, src, "-ldl"], check=True, capture_output=True, timeout=120)
         lib = ctypes.CDLL(out)
         lib.abrt_trace_fd = os.dup(2)          # taken while the runner configures, as its own fault handler does
         lib.abrt_trace_install(lib.abrt_trace_fd)

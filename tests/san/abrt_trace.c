@@ -3,9 +3,14 @@
  * shows the Python frames only) or to the default action.  tests/conftest.py builds and loads it (abrt_trace_install) on
  * every test run, so that an abort in a GPU test run leaves evidence; also usable as LD_PRELOAD.  Never loaded by the product. */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
 #include <string.h>
+#include <sys/prctl.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 static struct sigaction prev_sa;
@@ -21,6 +26,28 @@ static void on_abrt(int sig)
     (void)!write(out_fd, head, sizeof(head) - 1);
     int n = backtrace(frames, 64);
     backtrace_symbols_fd(frames, n, out_fd);
+    {   /* who is this thread, and what did it run lately: the words on its stack that point into loaded code (stale return
+         * addresses included) -- the unwinder above stops where a frame was left by a jump instead of a call */
+        char name[32] = {0}, line[512];
+        prctl(PR_GET_NAME, name, 0, 0, 0);
+        int len = snprintf(line, sizeof(line), "--- thread %ld \"%s\"; code addresses on its stack, innermost first ---\n", (long)syscall(SYS_gettid), name);
+        (void)!write(out_fd, line, (size_t)len);
+        uintptr_t *sp = (uintptr_t *)__builtin_frame_address(0);
+        int shown = 0;
+        for (int i = 0; i < 6000 && shown < 160; i++) {
+            /* stay inside the mapped stack: a page that is not there ends the scan (mincore) */
+            if (((uintptr_t)(sp + i) & 4095) == 0 || i == 0) {
+                unsigned char v;
+                if (syscall(SYS_mincore, (void *)((uintptr_t)(sp + i) & ~(uintptr_t)4095), 4096, &v) != 0) break;
+            }
+            Dl_info info;
+            const uintptr_t a = sp[i];
+            if (a < 0x10000 || !dladdr((void *)a, &info) || !info.dli_fname) continue;
+            len = snprintf(line, sizeof(line), "  [sp+%d] %s(+0x%lx) %s\n", i * 8, info.dli_fname, (unsigned long)(a - (uintptr_t)info.dli_fbase), info.dli_sname ? info.dli_sname : "");
+            (void)!write(out_fd, line, (size_t)len);
+            shown++;
+        }
+    }
     sigaction(sig, &prev_sa, 0);      /* faulthandler's (or the default): it gets the re-raised signal */
     raise(sig);
 }

@@ -96,7 +96,7 @@ static int check_plan(const Cascade &c, const DetectPlan &dp, int cols, int rows
     for (const TileRec &t : dp.tiles) {
         tiled += (long long)t.nx * t.ny;
         const ScaleRec &sc = dp.scales[t.scale];
-        if (t.nx < 1 || t.ny < 1 || t.nx > kTileWin || t.ny > kTileWin || t.ix0 + t.nx > sc.endX || t.iy0 + t.ny > sc.endY) return fail("tile outside its scale's grid");
+        if (t.nx < 1 || t.ny < 1 || t.nx > kTileWin || t.ny > kTileRows || t.ix0 + t.nx > sc.endX || t.iy0 + t.ny > sc.endY) return fail("tile outside its scale's grid");
         if (t.ncol < 1 || t.ncol > kTileMaxCols || t.nrow < 1 || t.nrow > kTileThreads) return fail("tile sample counts");
         if (tile_lds_bytes(t.ncol, t.nrow, t.span_x, t.span_y) > dp.tile_lds || dp.tile_lds > kTileLdsBudget) return fail("tile LDS size");
         if ((size_t)t.col_off + t.ncol > dp.tcoords.size() || (size_t)t.row_off + t.nrow > dp.tcoords.size()) return fail("tile coordinate lists out of range");
