@@ -571,6 +571,27 @@ __device__ __forceinline__ bool tile_stage_pass(unsigned cm, unsigned rm, double
     return !(sum < (double)st.thr);
 }
 
+// one stump (a per-lane record from the table) on one window: the integer vote (StageRec flag bit 2)
+template <bool PAIR>
+__device__ __forceinline__ int tile_vote_lane(unsigned cm, unsigned rm, double vnf, const TStumpRec &f)
+{
+    auto rs = [&](int q) {
+        const int c0 = lds_u16(cm + 2 * f.x0[q]), c1 = lds_u16(cm + 2 * f.x1[q]);
+        const int r0 = lds_u16(rm + 2 * f.y0[q]), r1 = lds_u16(rm + 2 * f.y1[q]);
+        return lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
+    };
+    const int s0 = rs(0), s1 = rs(1);
+    const double t = f.thr * vnf;
+    double v;
+    if (PAIR) v = (double)((float)s0 * f.w[0] + (float)s1 * f.w[1]);
+    else {
+        v = (double)((float)s0 * f.w[0]);
+        v += (double)((float)s1 * f.w[1]);
+        if ((f.nrect & 255) == 3) v += (double)((float)rs(2) * f.w[2]);
+    }
+    return v >= t ? f.a1i : f.a0i;
+}
+
 #ifdef NVCA_STAMPS
 // diagnostic build: thread 0 of the first 64 workgroups leaves s_memtime stamps per tile and phase (64 words per tile, 16 tiles)
 #define NVCA_STAMP(a, tile, id) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) { unsigned long long t__; \
@@ -723,7 +744,26 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
         const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
         int adv = 1;
-        if (st.flags & 4) {
+        if ((st.flags & 4) && n <= NW) {
+            // ---- a handful of windows left (the usual state of the last early stage: one or two windows a tile): a wave per
+            // window, a stump per lane -- the stage is one step for every wave instead of a chain of stumps walked by a lane or
+            // two of each wave.  Records come per lane from the table (L2), votes are integers: the wave's sum is exact.
+            if (wave < n) {
+                const int w = qi[wave];
+                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                const double vnf = vnf_of(w);
+                const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
+                int sum = 0;
+                for (int j = lane; j < st.count; j += 64) {
+                    const TStumpRec f = urecs[st.first + j];
+                    sum += pair ? tile_vote_lane<true>(cm, rm, vnf, f) : tile_vote_lane<false>(cm, rm, vnf, f);
+                }
+                for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+                if (lane == 0 && sum >= st.thr_i) qo[atomicAdd(&L.qn[cout], 1)] = (unsigned short)w;
+            }
+            if (s < kStatStages && tid == 0) stat_w[s] = n;
+            NVCA_STAMP(a, ti, 8 + 8 * s + 1); NVCA_STAMP(a, ti, 8 + 8 * s + 2); NVCA_STAMP(a, ti, 8 + 8 * s + 3);
+        } else if (st.flags & 4) {
             // ---- integer votes: balanced runs over (window group, stump), LDS accumulators, optional fusion with stage s + 1
             bool fuse = false;
             int first2 = 0, count2 = 0, thr2 = 0; bool pair2 = false;
