@@ -6,7 +6,7 @@
 //
 // Launches per batch of frames:
 //  K5  k_band        (batches with >= 540 bands in flight, api.cpp) one workgroup per row of tiles of a
-//                    scale, walking it left to right: per tile (<= 32 x 32 windows) the integral
+//                    scale, walking it left to right: per tile (<= 32 x 24 windows, a window per thread) the integral
 //                    samples the windows touch are staged, compacted, in LDS; window variance and
 //                    stage 0 for every window; OpenCV's adaptive x step (ix += result != 0 ? 1 : 2)
 //                    in closed form -- window j is visited iff the run of stage-0 rejects
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
 }
 
 // ---- K5b: stages 1 .. deep_stage-1 on LDS lattice tiles -------------------------------------
-// A tile is nx x ny (<= 32 x 32) windows of one scale.  Window origins and scaled rectangle corners of a scale
+// A tile is nx x ny (<= 32 x 24) windows of one scale.  Window origins and scaled rectangle corners of a scale
 // fall on a near-lattice, so the tile's windows touch only ~2.7 (n + 20) distinct columns and rows of the sum
 // plane whatever the scale.  Those rows x columns are copied, compacted, into LDS once; every rectangle corner
 // is then two u16 map look-ups (column index, row offset) and one LDS read, instead of a global gather whose 64

@@ -13,6 +13,31 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+/* When the shim is LD_PRELOADed it also sees every pthread_create of the process and remembers each thread's start routine:
+ * the abort hunted here is raised on a thread whose start routine jumps straight into abort(), so the call stack names nobody. */
+#include <pthread.h>
+#include <stdlib.h>
+typedef struct { void *(*fn)(void *); void *arg; } start_t;
+static struct { long tid; void *fn; } started[4096];
+static volatile int n_started;
+static void *start_shim(void *p)
+{
+    start_t s = *(start_t *)p;
+    free(p);
+    const int k = __sync_fetch_and_add(&n_started, 1);
+    if (k < 4096) { started[k].tid = (long)syscall(SYS_gettid); started[k].fn = (void *)s.fn; }
+    return s.fn(s.arg);
+}
+int pthread_create(pthread_t *th, const pthread_attr_t *attr, void *(*fn)(void *), void *arg)
+{
+    static int (*real)(pthread_t *, const pthread_attr_t *, void *(*)(void *), void *);
+    if (!real) real = (int (*)(pthread_t *, const pthread_attr_t *, void *(*)(void *), void *))dlsym(RTLD_NEXT, "pthread_create");
+    start_t *s = (start_t *)malloc(sizeof(start_t));
+    if (!s) return real(th, attr, fn, arg);
+    s->fn = fn; s->arg = arg;
+    return real(th, attr, start_shim, s);
+}
+
 static struct sigaction prev_sa;
 static int out_fd = 2;
 static volatile sig_atomic_t fired;
@@ -32,6 +57,20 @@ static void on_abrt(int sig)
         prctl(PR_GET_NAME, name, 0, 0, 0);
         int len = snprintf(line, sizeof(line), "--- thread %ld \"%s\"; code addresses on its stack, innermost first ---\n", (long)syscall(SYS_gettid), name);
         (void)!write(out_fd, line, (size_t)len);
+        {   /* its start routine, if the shim saw the thread being created (LD_PRELOAD) */
+            const long me = (long)syscall(SYS_gettid);
+            const int ns = n_started < 4096 ? n_started : 4096;
+            for (int k = 0; k < ns; k++)
+                if (started[k].tid == me) {
+                    Dl_info fi; memset(&fi, 0, sizeof(fi));
+                    (void)dladdr(started[k].fn, &fi);
+                    len = snprintf(line, sizeof(line), "--- its start routine: %s(+0x%lx) %s ---\n", fi.dli_fname ? fi.dli_fname : "?",
+                                   (unsigned long)((uintptr_t)started[k].fn - (uintptr_t)fi.dli_fbase), fi.dli_sname ? fi.dli_sname : "");
+                    (void)!write(out_fd, line, (size_t)len);
+                }
+            len = snprintf(line, sizeof(line), "--- threads created while the shim was watching: %d ---\n", ns);
+            (void)!write(out_fd, line, (size_t)len);
+        }
         uintptr_t *sp = (uintptr_t *)__builtin_frame_address(0);
         int shown = 0;
         for (int i = 0; i < 6000 && shown < 160; i++) {
