@@ -24,18 +24,21 @@ using namespace nvca;
 // =========================================================================
 namespace nvca {
 
+// NVCA_ALLOC_LOG=1 (diagnostic): every device allocation and release on stderr -- a GPU memory fault names an address, this says whose
+static bool alloc_log() { static const bool on = getenv("NVCA_ALLOC_LOG") != nullptr; return on; }
 int DevBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
-    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; bytes = 0; }
+    if (p) { (void)hipDeviceSynchronize(); if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes, grows)\n", p, bytes); (void)hipFree(p); p = nullptr; bytes = 0; }
     size_t want = n + n / 4;                                  // head-room: batches grow
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; e = hipMalloc(&p, n); want = n; }    // the refused head-room attempt must not surface later as a launch error
     if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; bytes = 0; return (int)e; }
     bytes = want;
+    if (alloc_log()) fprintf(stderr, "[nvca alloc] alloc %p .. %p (%zu bytes, %zu asked)\n", p, (void *)((char *)p + want), want, n);
     return 0;
 }
-void DevBuf::release() { if (p && bytes) (void)hipFree(p); p = nullptr; bytes = 0; }     // bytes == 0: a view into another buffer
+void DevBuf::release() { if (p && bytes) { if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes)\n", p, bytes); (void)hipFree(p); } p = nullptr; bytes = 0; }     // bytes == 0: a view into another buffer
 int PinnedBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
