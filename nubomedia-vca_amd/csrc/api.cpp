@@ -26,9 +26,63 @@ namespace nvca {
 
 // NVCA_ALLOC_LOG=1 (diagnostic): every device allocation and release on stderr -- a GPU memory fault names an address, this says whose
 static bool alloc_log() { static const bool on = getenv("NVCA_ALLOC_LOG") != nullptr; return on; }
+// NVCA_ALLOC_GUARD=1 (diagnostic, "electric fence"): every device buffer is mapped through the virtual-memory API with an
+// unmapped guard range before and behind it and ends (to 256 bytes) where its mapping ends, with no head-room: a kernel that
+// reads or writes past a buffer faults at that access, every time, instead of now and then when the neighbouring pages happen
+// to be unmapped.  Costs an allocation granule (2 MiB) per buffer; never on in production.
+// NVCA_ALLOC_GUARD=1: released buffers stay mapped (leaked: a test run allocates a few GB in all); =2: they are unmapped and their
+// address range stays reserved (a use after release faults too); =3: unmapped, released and the range freed.
+static int alloc_guard_mode() { static const int m = getenv("NVCA_ALLOC_GUARD") ? std::max(1, atoi(getenv("NVCA_ALLOC_GUARD"))) : 0; return m; }
+static bool alloc_guard() { return alloc_guard_mode() > 0; }
+namespace {
+struct GuardRec { void *va; size_t total, mapped, lead; hipMemGenericAllocationHandle_t h; };
+std::map<void *, GuardRec> g_guard;
+std::mutex g_guard_mu;
+hipError_t guard_alloc(void **out, size_t n)
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorUnknown;
+    const size_t body = (n + 255) & ~(size_t)255, mapped = (body + gran - 1) / gran * gran;
+    GuardRec r; r.total = mapped + 2 * gran; r.mapped = mapped; r.lead = gran; r.va = nullptr;
+    if ((e = hipMemAddressReserve(&r.va, r.total, gran, nullptr, 0)) != hipSuccess) return e;
+    if ((e = hipMemCreate(&r.h, mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(r.va, r.total); return e; }
+    char *base = (char *)r.va + gran;
+    if ((e = hipMemMap(base, mapped, 0, r.h, 0)) != hipSuccess) { (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.total); return e; }
+    hipMemAccessDesc acc; memset(&acc, 0, sizeof(acc));
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(base, mapped, &acc, 1)) != hipSuccess) { (void)hipMemUnmap(base, mapped); (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.total); return e; }
+    *out = base + (mapped - body);                       // the buffer ends where the mapping ends
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[*out] = r;
+    return hipSuccess;
+}
+void guard_free(void *p)
+{
+    GuardRec r;
+    { std::lock_guard<std::mutex> lk(g_guard_mu);
+      auto it = g_guard.find(p);
+      if (it == g_guard.end()) { (void)hipFree(p); return; }
+      r = it->second; g_guard.erase(it); }
+    (void)hipDeviceSynchronize();
+    if (alloc_guard_mode() >= 2) (void)hipMemUnmap((char *)r.va + r.lead, r.mapped);
+    if (alloc_guard_mode() >= 3) { (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.total); }
+}
+}
 int DevBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
+    if (alloc_guard()) {
+        if (p) { (void)hipDeviceSynchronize(); if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes, grows)\n", p, bytes); guard_free(p); p = nullptr; bytes = 0; }
+        const hipError_t ge = guard_alloc(&p, n);
+        if (ge != hipSuccess) { (void)hipGetLastError(); p = nullptr; bytes = 0; return (int)ge; }
+        bytes = n;
+        if (alloc_log()) fprintf(stderr, "[nvca alloc] alloc %p .. %p (%zu bytes, guarded)\n", p, (void *)((char *)p + n), n);
+        return 0;
+    }
     if (p) { (void)hipDeviceSynchronize(); if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes, grows)\n", p, bytes); (void)hipFree(p); p = nullptr; bytes = 0; }
     size_t want = n + n / 4;                                  // head-room: batches grow
     hipError_t e = hipMalloc(&p, want);
@@ -38,7 +92,7 @@ int DevBuf::ensure(size_t n)
     if (alloc_log()) fprintf(stderr, "[nvca alloc] alloc %p .. %p (%zu bytes, %zu asked)\n", p, (void *)((char *)p + want), want, n);
     return 0;
 }
-void DevBuf::release() { if (p && bytes) { if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes)\n", p, bytes); (void)hipFree(p); } p = nullptr; bytes = 0; }     // bytes == 0: a view into another buffer
+void DevBuf::release() { if (p && bytes) { if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes)\n", p, bytes); if (alloc_guard()) guard_free(p); else (void)hipFree(p); } p = nullptr; bytes = 0; }     // bytes == 0: a view into another buffer
 int PinnedBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
