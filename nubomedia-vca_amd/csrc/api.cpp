@@ -687,10 +687,39 @@ static void group_all(std::vector<std::vector<nvca_rect>> &raw, int min_neighbor
         if (min_neighbors != 0) group_rectangles(r, std::max(min_neighbors, 1), GROUP_EPS);
 }
 
+// Small host images do not go to the runtime as the caller's (pageable) pointers: they pass through page-locked memory of the
+// context's own, rows packed at the device pitch, and cross as ONE 1-D copy.  (a) A 2-D asynchronous copy from pageable memory
+// makes the runtime pin the caller's pages for the length of the copy -- tens of microseconds of system calls for an 8 KB image;
+// (b) under PyTorch's bundled ROCm 7.0 runtime exactly such a copy -- a 97 x 83 numpy image, two tests after frames of the same heap
+// had been page-locked and released again -- ended now and then in "Memory access fault by GPU ... on address <a page of the
+// host heap>" (DESIGN 6a): whatever the runtime remembers about host ranges it has seen, the library no longer depends on it.
+static constexpr size_t kHostStageBytes = 8u << 20, kHostStageMaxImage = 2u << 20;
+static uint8_t *host_stage_take(nvca_ctx *ctx, size_t need)
+{
+    if (need > kHostStageMaxImage) return nullptr;
+    if (!ctx->host_stage.p) {
+        if (ctx->host_stage.ensure(kHostStageBytes)) { (void)hipGetLastError(); return nullptr; }
+        memset(ctx->host_stage.p, 0, kHostStageBytes);
+        ctx->host_stage_used = 0;
+    }
+    const size_t al = (need + 255) & ~(size_t)255;
+    if (ctx->host_stage_used + al > kHostStageBytes) { (void)hipDeviceSynchronize(); ctx->host_stage_used = 0; }     // copies out of the old contents may still be queued
+    uint8_t *p = ctx->host_stage.as<uint8_t>() + ctx->host_stage_used;
+    ctx->host_stage_used += al;
+    return p;
+}
 // copy a host/device 2-D byte image into device memory with a pitch
 static int stage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
                     size_t height, int mem)
 {
+    if (mem == NVCA_MEM_HOST && height > 0 && width_bytes <= dpitch) {
+        const size_t need = dpitch * (height - 1) + width_bytes;
+        if (uint8_t *h = host_stage_take(ctx, need)) {
+            for (size_t y = 0; y < height; y++) memcpy(h + y * dpitch, (const uint8_t *)src + y * spitch, width_bytes);
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(dst, h, need, hipMemcpyHostToDevice, ctx->cs()));
+            return NVCA_OK;
+        }
+    }
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                                          ctx->cs()));
@@ -700,6 +729,16 @@ static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, 
                       size_t height, int mem)
 {
     NVCA_LAUNCH_CHECK(ctx);
+    if (mem == NVCA_MEM_HOST && height > 0 && width_bytes <= spitch) {          // out through the context's page-locked memory (see stage_2d)
+        const size_t need = spitch * (height - 1) + width_bytes;
+        if (uint8_t *h = host_stage_take(ctx, need)) {
+            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(h, src, need, hipMemcpyDeviceToHost, ctx->cs()));
+            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+            for (size_t y = 0; y < height; y++) memcpy((uint8_t *)dst + y * dpitch, h + y * spitch, width_bytes);
+            drain_timer(ctx);
+            return NVCA_OK;
+        }
+    }
     NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
                                          mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                          ctx->cs()));
@@ -786,6 +825,7 @@ nvca_ctx::~nvca_ctx()
     trk.release_all();
     part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
+    host_stage.release();
     nvca::work_pool_destroy(pool); pool = nullptr;
     overlay_img.release();
     for (auto &kv : roi_stage_recs) { kv.second->release(); delete kv.second; }

@@ -193,8 +193,11 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
         if (n == 0) break;
         const int cout = cin == 2 ? 0 : cin + 1;
         if (tid == 0) L.cnt[cout == 2 ? 0 : cout + 1] = 0;
-        const unsigned short *qi = cur ? L.qb : L.qa;
-        unsigned short *qo = cur ? L.qa : L.qb;
+        // the two queues lie back to back (qb == qa + kRoiMaxWin): chosen by arithmetic -- a select between the struct's pointer
+        // members made the compiler keep the struct in scratch memory and index it (56 bytes of private segment per thread, the
+        // only kernel of the library with any)
+        const unsigned short *qi = L.qa + cur * kRoiMaxWin;
+        unsigned short *qo = L.qa + (cur ^ 1) * kRoiMaxWin;
         for (int base = 0; base < n; base += kRoiThreads) {
             const int i = base + tid;
             bool pass = false; int wi = 0;
@@ -217,7 +220,7 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
     __syncthreads();
     // ---- C
     const int n = L.cnt[cin];
-    const unsigned short *qi = cur ? L.qb : L.qa;
+    const unsigned short *qi = L.qa + cur * kRoiMaxWin;
     for (int k = wave; k < n; k += kRoiWaves) {
         const int wi = qi[k], gy = gy0 + wi / nx, gx = wi - (wi / nx) * nx;
         int x, y; pos(gx, gy, x, y);

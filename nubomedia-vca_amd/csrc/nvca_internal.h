@@ -272,6 +272,9 @@ struct nvca_ctx {
     hipStream_t pre_streams[2] = {nullptr, nullptr};   // CU-masked streams for the pre-processing of the two face batches in flight ("pre_cus"), created on first use
     int pre_streams_cus = 0;                  // the CU count they were created for
     hipEvent_t pre_done[2] = {nullptr, nullptr};
+    // small host images on their way in and out (api.cpp stage_2d / unstage_2d): page-locked memory of the context's own, handed
+    // out front to back; when it is used up the device is drained and it starts over
+    nvca::PinnedBuf host_stage; size_t host_stage_used = 0;
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
     nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect

@@ -150,3 +150,35 @@ def test_loader_reads_the_handwritten_oldformat_files(lib):
     assert rc == 0 and shape == (24, 24, 3, 7), (rc, shape, err)
     rc, shape, err = _validate(lib, open(os.path.join(gold, "oldformat_trees_tilted_20x20.xml")).read())
     assert rc == 0 and shape == (20, 20, 2, 4), (rc, shape, err)
+
+
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """Every kernel of the library keeps its state in registers and LDS: a private segment (scratch memory) brings the runtime's
+    scratch set-up into every launch, and the one kernel that once had one (56 bytes a thread, a struct indexed by a flag) was the
+    kernel of the call that hit a GPU memory access fault under PyTorch's bundled ROCm 7.0 runtime.  Read from the
+    code objects inside the built objects."""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    build = os.path.join(ROOT, "nubomedia-vca_amd", "build")
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")) or not os.path.isdir(build):
+        pytest.skip("no LLVM tools / no build directory")
+    seen = 0
+    for f in sorted(os.listdir(build)):
+        if not f.endswith(".hip.o"):
+            continue
+        fb, co = str(tmp_path / (f + ".fatbin")), str(tmp_path / (f + ".co"))
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, os.path.join(build, f)], check=True, capture_output=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + fb, "--output=" + co], check=True, capture_output=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+        name = None
+        for ln in notes.splitlines():
+            ln = ln.strip()
+            if ln.startswith(".name:"):
+                name = ln.split()[-1]
+            elif ln.startswith(".private_segment_fixed_size:"):
+                seen += 1
+                assert int(ln.split()[-1]) == 0, (f, name, ln)
+            elif ln.startswith(".uses_dynamic_stack:"):
+                assert ln.split()[-1] == "false", (f, name, ln)
+    assert seen >= 20, seen
