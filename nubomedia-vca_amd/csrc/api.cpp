@@ -75,13 +75,17 @@ void guard_free(void *p)
 int DevBuf::ensure(size_t n)
 {
     if (n <= bytes) return 0;
-    if (alloc_guard()) {
+    static bool guard_broken = false;          // the runtime refused the virtual-memory calls: said once, plain allocations from then on
+    if (alloc_guard() && !guard_broken) {
         if (p) { (void)hipDeviceSynchronize(); if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes, grows)\n", p, bytes); guard_free(p); p = nullptr; bytes = 0; }
         const hipError_t ge = guard_alloc(&p, n);
-        if (ge != hipSuccess) { (void)hipGetLastError(); p = nullptr; bytes = 0; return (int)ge; }
-        bytes = n;
-        if (alloc_log()) fprintf(stderr, "[nvca alloc] alloc %p .. %p (%zu bytes, guarded)\n", p, (void *)((char *)p + n), n);
-        return 0;
+        if (ge == hipSuccess) {
+            bytes = n;
+            if (alloc_log()) fprintf(stderr, "[nvca alloc] alloc %p .. %p (%zu bytes, guarded)\n", p, (void *)((char *)p + n), n);
+            return 0;
+        }
+        (void)hipGetLastError(); p = nullptr; bytes = 0; guard_broken = true;
+        fprintf(stderr, "[nvca alloc] guard unavailable (%s): plain allocations\n", hipGetErrorString(ge));
     }
     if (p) { (void)hipDeviceSynchronize(); if (alloc_log()) fprintf(stderr, "[nvca alloc] free  %p (%zu bytes, grows)\n", p, bytes); (void)hipFree(p); p = nullptr; bytes = 0; }
     size_t want = n + n / 4;                                  // head-room: batches grow
