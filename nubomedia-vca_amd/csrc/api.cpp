@@ -2318,6 +2318,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             if (r == NVCA_ERR_OVERFLOW && roi_regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
                 // the round's candidate list was too short: its jobs are queued again, with room (see detect_job_advance)
                 roi_regrown++; roi_again = true;
+                if (g_job_stats) fprintf(stderr, "[nvca jobs] a small-image round overflowed its candidate list (cap %u for %zu jobs): queued again with %d per job\n", rb.cap, rb.jobs.size(), ctx->hit_cap_wanted);
                 for (DetectJob *o : rb.owners) { o->phase = o->roi_prev_phase; o->fused = false; for (int k = 0; k < kJobImages; k++) o->rkeys[k].clear(); }
             } else if (r) rc = r;
         }
