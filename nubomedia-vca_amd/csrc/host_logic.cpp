@@ -26,26 +26,29 @@ struct SimilarRects {
     }
 };
 
-// cv::partition: disjoint-set forest; class ids in order of first appearance
+// cv::partition: the classes are the connected components of the (symmetric) predicate, numbered in order of their first
+// member.  OpenCV tests every ordered pair; the components -- all the result depends on -- come out the same from the pairs
+// that CAN satisfy SimilarRects: |x1 - x2| <= delta with delta = eps (min w + min h) / 2 <= eps (w1 + h1) / 2, so a rectangle's
+// partners lie within that distance of it in x.  Rectangles sorted by x, a window per rectangle, pairs already in one class
+// skipped: a FIND_BIGGEST search's few hundred candidates per ladder step cost a few thousand tests instead of N^2.
 int partition(const std::vector<nvca_rect> &v, std::vector<int> &labels, SimilarRects pred)
 {
     const int N = (int)v.size();
     std::vector<int> parent(N, -1), rank(N, 0);
-    auto find = [&](int i) { while (parent[i] >= 0) i = parent[i]; return i; };
-    for (int i = 0; i < N; i++) {
-        int root = find(i);
-        for (int j = 0; j < N; j++) {
-            if (i == j || !pred(v[i], v[j])) continue;
-            int root2 = find(j);
-            if (root2 == root) continue;
+    auto find = [&](int i) { int r = i; while (parent[r] >= 0) r = parent[r]; for (int k = i, p; (p = parent[k]) >= 0; k = p) parent[k] = r; return r; };
+    std::vector<int> byx(N);
+    for (int i = 0; i < N; i++) byx[i] = i;
+    std::sort(byx.begin(), byx.end(), [&](int a, int b) { return v[a].x < v[b].x; });
+    for (int a = 0; a < N; a++) {
+        const int i = byx[a];
+        const double reach = pred.eps * (v[i].w + v[i].h) * 0.5;             // no partner of i is further away in x
+        for (int b = a + 1; b < N; b++) {                                   // every pair is met once, from its left member: delta <= the reach of BOTH
+            const int j = byx[b];
+            if ((double)(v[j].x - v[i].x) > reach) break;                   // sorted by x: nobody further right is within reach either
+            int root = find(i), root2 = find(j);
+            if (root2 == root || !pred(v[i], v[j])) continue;
             if (rank[root] > rank[root2]) parent[root2] = root;
-            else {
-                parent[root] = root2;
-                rank[root2] += rank[root] == rank[root2];
-                root = root2;
-            }
-            for (int k = j, p; (p = parent[k]) >= 0; k = p) parent[k] = root;
-            for (int k = i, p; (p = parent[k]) >= 0; k = p) parent[k] = root;
+            else { parent[root] = root2; rank[root2] += rank[root] == rank[root2]; }
         }
     }
     labels.assign(N, 0);

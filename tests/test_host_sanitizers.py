@@ -103,7 +103,8 @@ def test_glue_under_sanitizers_matches_the_oracle(driver, tmp_path):
         return "%d %s" % (len(r), " ".join(str(int(v)) for v in r.reshape(-1)))
 
     for i in range(150):
-        r = rects(int(rng.integers(0, 40)))
+        # mostly a few dozen boxes; every tenth case a FIND_BIGGEST-sized list (hundreds of near-copies: the x-window partition's case)
+        r = rects(int(rng.integers(200, 700))) if i % 10 == 9 else rects(int(rng.integers(0, 40)))
         thr = int(rng.integers(1, 5))
         lines.append("G %d %d 0.2 %s" % (i, thr, fmt(r)))
         expect[("group", i)] = orc.group_rectangles(r, thr, 0.2)
