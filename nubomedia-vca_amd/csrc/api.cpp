@@ -1989,10 +1989,28 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
         }
     }
     bool fits = steps.size() <= 63;                                  // the key holds 6 bits of step
-    for (RoiStep &st : steps) {
-        const int nx = (st.endX - st.startX + st.step - 1) / st.step, ny = (st.endY - st.startY + st.step - 1) / st.step;
-        if (nx > kRoiMaxWin) fits = false;                           // (a grid row longer than the queues: not with images this small)
-        st.key_x0 = st.startX; st.key_dx = st.step; st.key_y0 = st.startY; st.key_dy = st.step;
+    {
+        // A step's rows are independent of one another (the adaptive x step works row by row, a pyramid level's grid is fixed):
+        // a step with more windows than the queues hold goes out as several records, a band of whole rows each -- one workgroup
+        // per band instead of one per step walking its bands one after the other (the largest pyramid level of a 160 x 90 face
+        // pass is 10 k windows: alone it set the length of the whole launch).  Every band builds the integral pair for itself.
+        std::vector<RoiStep> bands;
+        for (size_t li = 0; li < steps.size(); li++) {
+            RoiStep st = steps[li];
+            const int nx = (st.endX - st.startX + st.step - 1) / st.step, ny = (st.endY - st.startY + st.step - 1) / st.step;
+            if (nx > kRoiMaxWin) fits = false;                       // (a grid row longer than the queues: not with images this small)
+            st.key_step = (int)li;
+            st.key_x0 = st.startX; st.key_dx = st.step; st.key_dy = st.step;
+            const int rows_per = nx > 0 && nx < kRoiMaxWin ? kRoiMaxWin / nx : 1;
+            for (int gy0 = 0; gy0 < std::max(ny, 1); gy0 += rows_per) {
+                RoiStep b = st;
+                b.startY = st.startY + gy0 * st.step;
+                b.endY = std::min(st.endY, st.startY + (gy0 + rows_per) * st.step);
+                b.key_y0 = b.startY;
+                bands.push_back(b);
+            }
+        }
+        steps.swap(bands);
     }
     if (!fits && j.roi_prev_phase == 2) { ctx->set_error("internal: a narrowed search outgrew the small-image path"); return NVCA_ERR_INTERNAL; }   // (its full grids fitted)
     if (!fits) { j.phase = j.roi_prev_phase; return NVCA_OK; }       // this one takes the large-image path

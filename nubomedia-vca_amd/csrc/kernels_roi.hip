@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict
     extern __shared__ __align__(16) unsigned char roi_lds[];
     const RoiStep st = steps[blockIdx.x];
     const RoiJobDev job = jobs[st.job];
-    const int li = blockIdx.x - job.first_step;
+    const int li = st.key_step;               // the step's number inside its job (several records -- bands of rows -- may share it)
     RoiLds L;
     L.s = (lds_i32 *)roi_lds;
     L.q = (lds_u32 *)(L.s + plane_words);

@@ -578,7 +578,7 @@ struct RoiStep {                  // one ladder step (scale-cascade scan) or one
     const TStumpRec *trecs;       // the cascade's stumps at this step's factor (levels: factor 1)
     int ex, ey, ew, eh;           // variance rectangle (window-relative)
     int startX, endX, startY, endY;   // scale-cascade: grid indices, window origin = cvRound(i * ystep); levels: origins 0 .. end, every `step` pixels
-    int step, adaptive, job, pad_s;       // job: index of the step's job in the launch
+    int step, adaptive, job, key_step;    // job: index of the step's job in the launch; key_step: the step's number inside its job (a candidate's key carries it; a step with many rows goes out as several records -- one workgroup each -- with the same number)
     int key_x0, key_dx, key_y0, key_dy;   // a candidate's key: column key_x0 + gx * key_dx, row key_y0 + gy * key_dy (grid indices, or level origins)
     int szw, szh;                 // level size
     int mode, xmax, xofs_off, yofs_off, ialpha_off, ibeta_off;      // the level's cv::resize tables (byte offsets into the launch's table blob)
