@@ -1855,7 +1855,7 @@ static constexpr int kRoiMaxWords = 14848;          // (cols + 1) * (rows + 2) w
 struct RoiBatch {
     std::vector<RoiJobDev> jobs; std::vector<RoiStep> steps; std::vector<unsigned char> tabs; std::vector<DetectJob *> owners; std::vector<int> owner_img;
     std::vector<ScaleTable *> held;                 // stump tables of the launch: kept from eviction until it has been collected
-    int plane_words = 0, lev_bytes = 0, lane = 0; unsigned cap = 0;
+    int plane_words = 0, lev_bytes = 0, lane = 0; unsigned cap = 0; size_t first = 0;
     ~RoiBatch() { for (ScaleTable *t : held) if (t->refs > 0) t->refs--; }
 };
 static bool roi_eligible(const nvca_ctx *ctx, const DetectJob &j, int njobs_in_round)
@@ -2048,7 +2048,8 @@ static int roi_launch(nvca_ctx *ctx, RoiBatch &rb, bool full_cap)
     // overflows it is queued again with the exact size (run_detect_jobs raises hit_cap for the rest of the call)
     const long long want = (long long)ctx->hit_cap * nj;
     rb.cap = (unsigned)std::min<long long>(want, full_cap ? (1ll << 26) : (1ll << 18));
-    const size_t first = std::min<size_t>(rb.cap, 8192);
+    const size_t first = std::min<size_t>(rb.cap, std::max<size_t>(8192, ctx->roi_first_hint));
+    rb.first = first;
     if (ctx->roi_tables.ensure(total) || ctx->roi_h_tables.ensure(total) || ctx->roi_hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->roi_h_hits.ensure(((size_t)rb.cap + 1) * 8)) {
         ctx->set_error("allocation failed (small-image detector)"); return NVCA_ERR_NOMEM;
     }
@@ -2078,12 +2079,15 @@ static int roi_collect(nvca_ctx *ctx, RoiBatch &rb)
         ctx->set_error("raw candidate capacity exceeded (nvca_ctx_set_hit_capacity)");
         return NVCA_ERR_OVERFLOW;
     }
-    const size_t first = std::min<size_t>(rb.cap, 8192);
+    // the list's head came back with the launch; how much of it to fetch that way next time follows the recent rounds (a second
+    // copy is a second wait)
+    ctx->roi_first_hint = std::max<size_t>((size_t)(total + total / 4), ctx->roi_first_hint - ctx->roi_first_hint / 16);
+    const size_t first = rb.first;
     if (total > first) {
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ctx->roi_hits.as<unsigned long long>() + 1 + first, (total - first) * 8, hipMemcpyDeviceToHost, ctx->cs()));
         NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     }
-    std::sort(hh + 1, hh + 1 + total);
+    // (the list is in the order the workgroups appended: every job sorts its own keys into the serial order when it advances)
     for (unsigned long long i = 0; i < total; i++) {
         const unsigned long long slot = hh[1 + i] >> 32;
         const unsigned key = (unsigned)hh[1 + i];
@@ -2120,9 +2124,11 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
     bool have = j.dp != nullptr;
     const bool was_fused = j.fused;
     if (j.fused) {
-        // candidates of the round's k_roi launch, already in serial order: step, row, column -> rectangle
+        // candidates of the round's k_roi launch, sorted into the serial order (step, row, column) -> rectangle
         raw.assign(j.nimg, {}); sc.assign(j.nimg, {}); grouped.assign(j.nimg, 0);
         for (int k = 0; k < j.nimg; k++) {
+            std::sort(j.rkeys[k].begin(), j.rkeys[k].end());
+            raw[k].reserve(j.rkeys[k].size()); sc[k].reserve(j.rkeys[k].size());
             for (unsigned key : j.rkeys[k]) {
                 const DetectJob::RoiStepInfo &ri = j.rinfo[key >> 26];
                 const int iy = (key >> 13) & 8191, ix = key & 8191;
@@ -2275,6 +2281,7 @@ int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
 
 // run a set of detectMultiScale calls to completion: one wait per round for all of them.  lanes (optional, [n]): the lane
 // each job runs on -- jobs of one lane execute in order, lanes side by side
+double g_jobs_fine_s[6] = {0, 0, 0, 0, 0, 0};        // NVCA_PART_STATS: roi_add_job, roi_launch, roi_collect, helper-thread advance, serial advance, small-path jobs (count)
 double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS (diagnostic, one context at a time): where run_detect_jobs spends the host's time
 static inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
@@ -2302,7 +2309,9 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             ctx->cur_lane = lanes ? lanes[i] : lane0;
             if (rb.jobs.empty()) rb.lane = ctx->cur_lane;
             j.roi_prev_phase = j.phase;
+            const double ta = g_job_stats ? mono_s() : 0;
             rc = roi_add_job(ctx, rb, j);
+            if (g_job_stats) { g_jobs_fine_s[0] += mono_s() - ta; g_jobs_fine_s[5] += 1; }
             if (!rc && !j.fused) j.small = false;          // more ladder steps than the key holds: the large-image path takes it
             else used[ctx->cur_lane] = true;
         }
@@ -2315,8 +2324,10 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             rc = detect_job_enqueue(ctx, *jobs[i], r0, total);
             r0 += jobs[i]->slots();
         }
+        const double tl = g_job_stats ? mono_s() : 0;
         if (!rc && !rb.jobs.empty()) { ctx->cur_lane = rb.lane; used[rb.lane] = true; rc = roi_launch(ctx, rb, roi_regrown > 0); }
         const double t1 = g_job_stats ? mono_s() : 0;
+        if (g_job_stats) g_jobs_fine_s[1] += t1 - tl;
         if (g_job_stats) g_jobs_enqueue_s += t1 - t0;
         for (int l = 0; l < kLanes; l++) {
             if (!used[l]) continue;
@@ -2332,6 +2343,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         if (!rc && !rb.jobs.empty()) {
             ctx->cur_lane = rb.lane;
             const int r = roi_collect(ctx, rb);
+            if (g_job_stats) g_jobs_fine_s[2] += mono_s() - t2;
             ctx->cur_lane = lane0;
             if (r == NVCA_ERR_OVERFLOW && roi_regrown < 2 && ctx->hit_cap_wanted > ctx->hit_cap) {
                 // the round's candidate list was too short: its jobs are queued again, with room (see detect_job_advance)
@@ -2343,6 +2355,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         // the small-path jobs' candidates are turned into rectangles, replayed (FIND_BIGGEST) and grouped job by job: independent
         // host work, shared with the context's helper threads (a job touches nothing but itself; set_error is locked)
         std::vector<DetectJob *> par;
+        const double tp0 = g_job_stats ? mono_s() : 0;
         if (!rc && !roi_again)
             for (int i = 0; i < n; i++) if (jobs[i]->phase != 3 && jobs[i]->fused) par.push_back(jobs[i]);
         if (par.size() >= 4) {
@@ -2367,6 +2380,8 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             if (arg.rc.load()) rc = arg.rc.load();
             for (DetectJob *j : par) j->roi_prev_phase = -1;          // handled
         }
+        const double tp1 = g_job_stats ? mono_s() : 0;
+        if (g_job_stats) g_jobs_fine_s[3] += tp1 - tp0;
         for (int i = 0; i < n; i++) {
             if (jobs[i]->phase == 3) continue;
             if (rc) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; continue; }
@@ -2377,6 +2392,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             if (r) rc = r;
         }
         ctx->cur_lane = lane0;
+        if (g_job_stats) g_jobs_fine_s[4] += mono_s() - tp1;
         if (rc) {
             for (int i = 0; i < n; i++) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; }
             return rc;

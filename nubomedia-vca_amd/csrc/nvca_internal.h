@@ -300,6 +300,7 @@ struct nvca_ctx {
     // small-image detector (kernels_roi.hip): per-cascade stage records on the device, the tables / candidate list of a launch
     std::map<uint64_t, nvca::DevBuf *> roi_stage_recs;
     nvca::DevBuf roi_tables, roi_hits; nvca::PinnedBuf roi_h_tables, roi_h_hits;
+    size_t roi_first_hint = 0;              // candidates of the recent small-image rounds (+ a quarter): what the launch copies back with itself
     nvca::WorkPool *pool = nullptr; bool pool_tried = false;
     std::mutex err_mu;                // set_error may be called from the helper threads
 #ifdef NVCA_STAMPS

@@ -28,7 +28,7 @@ struct nvca_part_stream {
     std::deque<RectV> queue;
 };
 
-namespace nvca { extern double g_jobs_enqueue_s, g_jobs_wait_s, g_jobs_advance_s; }
+namespace nvca { extern double g_jobs_enqueue_s, g_jobs_wait_s, g_jobs_advance_s, g_jobs_fine_s[6]; }
 namespace {
 inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline int cv_round(double v)
@@ -501,11 +501,14 @@ try {
     if (stats) {
         const double ts4 = mono_s();
         if (n >= stats_min) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
-        else g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0;
+        else { g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; for (double &v : g_jobs_fine_s) v = 0; }
         if (n >= stats_min && ++calls % 8 == 0) {
             fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f | merging (previous calls) %.3f, whole call (previous 8) %.3f\n",
                     acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3,
                     phase3_acc / 8 * 1e3, total_acc / 8 * 1e3);
+            fprintf(stderr, "nubovca part batch, job rounds in detail (ms per call): adding jobs %.3f (%.0f jobs), launch %.3f, collect %.3f, advance on the helpers %.3f, advance serial %.3f\n",
+                    g_jobs_fine_s[0] / 8 * 1e3, g_jobs_fine_s[5] / 8, g_jobs_fine_s[1] / 8 * 1e3, g_jobs_fine_s[2] / 8 * 1e3, g_jobs_fine_s[3] / 8 * 1e3, g_jobs_fine_s[4] / 8 * 1e3);
+            for (double &v : g_jobs_fine_s) v = 0;
             acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; phase3_acc = 0; total_acc = 0;
         }
     }
