@@ -2337,6 +2337,15 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         ctx->cur_lane = lane0;
         const double t2 = g_job_stats ? mono_s() : 0;
         if (g_job_stats) g_jobs_wait_s += t2 - t1;
+        if (g_job_stats && !rb.jobs.empty() && n >= ctx->sw.part_stats) {
+            static int lines = 0;
+            if (++lines > 200 && lines <= 212) {          // (a dozen rounds of the steady state: what a round holds and how long its launch took)
+                int kinds[3] = {0, 0, 0}, narrowed = 0;
+                for (DetectJob *o : rb.owners) { kinds[o->kind]++; if (o->roi_prev_phase == 2) narrowed++; }
+                fprintf(stderr, "[nvca jobs] small-image round: %zu images (plain %d, scale-image %d, biggest-object %d of which narrowed %d), %zu workgroups, waited %.0f us\n",
+                        rb.jobs.size(), kinds[0], kinds[1], kinds[2], narrowed, rb.steps.size(), (t2 - t1) * 1e6);
+            }
+        }
         struct Adv { double t; bool on; ~Adv() { if (on) g_jobs_advance_s += mono_s() - t; } } adv{t2, g_job_stats};
         drain_timer(ctx);
         bool roi_again = false;

@@ -1,8 +1,11 @@
 // work_pool.cpp -- a few helper threads for host work that is independent per job (nvca_internal.h: WorkPool).
 // Pure C++ (no HIP): also built under ThreadSanitizer by tests/test_host_sanitizers.py.
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -15,23 +18,50 @@ WorkPool *work_pool_create(int threads);
 void work_pool_destroy(WorkPool *p);
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *arg, int i), void *arg);
 
+// A run is opened by the calling thread (gen goes odd), worked on by the caller and by whichever helpers get there, and closed
+// (gen goes even) as soon as every index has been handled: the caller never waits for a helper to WAKE, only for the ones that
+// joined the run to leave it.  A helper announces itself (inside++) before it looks at the run's fields and backs out if the
+// run it saw has been closed meanwhile, so the caller may rewrite the fields once it has seen inside == 0.  Helpers spin for a
+// short while after a run (rounds of a batched call follow each other within a few hundred microseconds) before they sleep.
 struct WorkPool {
     std::vector<std::thread> th;
-    std::mutex m; std::condition_variable cv, done;
-    void (*fn)(void *, int) = nullptr; void *arg = nullptr;
-    int n = 0; std::atomic<int> next{0}; int busy = 0, acked = 0; uint64_t gen = 0; bool stop = false;
+    std::mutex m; std::condition_variable cv;
+    void (*fn)(void *, int) = nullptr; void *arg = nullptr; int n = 0;
+    std::atomic<int> next{0}, finished{0}, inside{0}, sleepers{0};
+    std::atomic<uint64_t> gen{0};                       // odd: a run is open
+    std::atomic<bool> stop{false};
+    int spin_us = 50;
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void worker()
     {
         uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv.wait(lk, [&] { return stop || gen != seen; });
-            if (stop) return;
-            seen = gen; busy++; acked++;
-            lk.unlock();
-            for (int i; (i = next.fetch_add(1)) < n;) fn(arg, i);
-            lk.lock();
-            if (--busy == 0) done.notify_all();
+            uint64_t g = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 0;; spins++) {
+                if (stop.load()) return;
+                g = gen.load();
+                if ((g & 1) && g != seen) break;
+                if ((spins & 63) != 63 || std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us)) { relax(); continue; }
+                std::unique_lock<std::mutex> lk(m);
+                sleepers.fetch_add(1);
+                cv.wait(lk, [&] { g = gen.load(); return stop.load() || ((g & 1) && g != seen); });
+                sleepers.fetch_sub(1);
+                if (stop.load()) return;
+                break;
+            }
+            inside.fetch_add(1);
+            if (gen.load() != g) { inside.fetch_sub(1); continue; }      // closed before this helper got here (a later run is picked up next time round)
+            seen = g;
+            for (int i; (i = next.fetch_add(1)) < n;) { fn(arg, i); finished.fetch_add(1); }
+            inside.fetch_sub(1);
         }
     }
 };
@@ -40,6 +70,7 @@ WorkPool *work_pool_create(int threads)
     if (threads <= 0) return nullptr;
     WorkPool *p = new (std::nothrow) WorkPool();
     if (!p) return nullptr;
+    if (const char *e = getenv("NVCA_HOST_SPIN_US")) p->spin_us = std::max(0, atoi(e));
     try { for (int i = 0; i < threads; i++) p->th.emplace_back([p] { p->worker(); }); }
     catch (...) { }                                     // fewer threads than asked for (or none): the caller works anyway
     return p;
@@ -47,7 +78,7 @@ WorkPool *work_pool_create(int threads)
 void work_pool_destroy(WorkPool *p)
 {
     if (!p) return;
-    { std::lock_guard<std::mutex> lk(p->m); p->stop = true; }
+    { std::lock_guard<std::mutex> lk(p->m); p->stop.store(true); }
     p->cv.notify_all();
     for (std::thread &t : p->th) t.join();
     delete p;
@@ -55,12 +86,14 @@ void work_pool_destroy(WorkPool *p)
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *, int), void *arg)
 {
     if (!p || p->th.empty() || n < 4) { for (int i = 0; i < n; i++) fn(arg, i); return; }
-    { std::lock_guard<std::mutex> lk(p->m); p->fn = fn; p->arg = arg; p->n = n; p->next.store(0); p->acked = 0; p->gen++; }
-    p->cv.notify_all();
-    for (int i; (i = p->next.fetch_add(1)) < n;) fn(arg, i);          // the caller takes part
-    std::unique_lock<std::mutex> lk(p->m);
-    // every helper has woken for this generation and left its loop: none can still be reading fn / arg / n when the next run sets them
-    p->done.wait(lk, [&] { return p->busy == 0 && p->acked == (int)p->th.size(); });
+    p->fn = fn; p->arg = arg; p->n = n; p->next.store(0); p->finished.store(0);          // (no helper is inside: the previous run waited for that)
+    const uint64_t g = p->gen.load() + 1;
+    p->gen.store(g);
+    if (p->sleepers.load() > 0) { { std::lock_guard<std::mutex> lk(p->m); } p->cv.notify_all(); }      // (through the mutex: a helper between its check and its wait is not missed)
+    for (int i; (i = p->next.fetch_add(1)) < n;) { fn(arg, i); p->finished.fetch_add(1); }              // the caller takes part
+    while (p->finished.load() < n) WorkPool::relax();
+    p->gen.store(g + 1);
+    while (p->inside.load() != 0) WorkPool::relax();
 }
 
 } // namespace nvca
