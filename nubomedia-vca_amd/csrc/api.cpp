@@ -960,6 +960,7 @@ try {
         (void)hipMemcpy(h.data(), ctx->stamps, h.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(switches().stamps_out, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
+    if (switches().stamps_out) roi_stamps_dump((std::string(switches().stamps_out) + ".roi.txt").c_str());
 #endif
     return NVCA_OK;
 }

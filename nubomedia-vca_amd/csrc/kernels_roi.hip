@@ -136,11 +136,23 @@ __device__ __forceinline__ double roi_vote(const lds_i32 *s, int off, int P, dou
 //      the stage's sums are exact in any order -- StageRec flag bit 1 -- and in OpenCV's order otherwise)
 // The queues and the per-window normalisers hold kRoiMaxWin windows: a larger grid goes through in bands of whole rows.
 static constexpr int kRoiThreads = 1024, kRoiWaves = kRoiThreads / 64;
+#ifdef NVCA_STAMPS
+// diagnostic build: thread 0 of every workgroup adds the s_memtime ticks of each phase to a device-global table
+// ([0..7] scale-cascade steps, [8..15] scale-image levels: image + integral, A, B, C, workgroups, windows in C)
+__device__ unsigned long long g_roi_phase[16];
+#define ROI_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_roi_phase[sbase + (k)], now_ - tprev); tprev = now_; } } while (0)
+#define ROI_STAMP_ARGS , unsigned long long &tprev, int sbase
+#define ROI_STAMP_PASS , tprev, sbase
+#else
+#define ROI_STAMP(k) do { } while (0)
+#define ROI_STAMP_ARGS
+#define ROI_STAMP_PASS
+#endif
 static constexpr int kRoiDeep = 4;
 struct RoiLds { lds_i32 *s; lds_u32 *q; double *vnf; unsigned short *qa, *qb; int *cnt; lds_u8 *lev; };
 template <class Pos>
 __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const RoiStep &st, int li, int nx, int gy0, int gy1, int P, const RoiLds &L, Pos pos,
-                                                 unsigned long long *__restrict__ hits, unsigned hit_cap)
+                                                 unsigned long long *__restrict__ hits, unsigned hit_cap ROI_STAMP_ARGS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nst = job.nstages, deep = nst < kRoiDeep ? nst : kRoiDeep;
@@ -185,6 +197,10 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
             carry = tail == nin ? ((nin + carry) & 1) : (tail & 1);
         }
     }
+#ifdef NVCA_STAMPS
+    __syncthreads();
+    ROI_STAMP(1);
+#endif
     // ---- B: the counters rotate over three words (read cin, append to cout, clear the third): one barrier per stage
     int cin = 0, cur = 0;
     for (int sidx = 1; sidx < deep; sidx++) {
@@ -218,8 +234,12 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
         cur ^= 1; cin = cout;
     }
     __syncthreads();
+    ROI_STAMP(2);
     // ---- C
     const int n = L.cnt[cin];
+#ifdef NVCA_STAMPS
+    if (tid == 0) atomicAdd(&g_roi_phase[sbase + 5], (unsigned long long)n);
+#endif
     const unsigned short *qi = L.qa + cur * kRoiMaxWin;
     for (int k = wave; k < n; k += kRoiWaves) {
         const int wi = qi[k], gy = gy0 + wi / nx, gx = wi - (wi / nx) * nx;
@@ -247,15 +267,16 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
         }
     }
     __syncthreads();                                  // the queues are reused by the next band
+    ROI_STAMP(3);
 }
 // a step's grid in bands of whole rows that fit the queues (the adaptive x step works row by row: bands are independent)
 template <class Pos>
 __device__ __forceinline__ void roi_step_windows(const RoiJobDev &job, const RoiStep &st, int li, int nx, int ny, int P, const RoiLds &L, Pos pos,
-                                                 unsigned long long *__restrict__ hits, unsigned hit_cap)
+                                                 unsigned long long *__restrict__ hits, unsigned hit_cap ROI_STAMP_ARGS)
 {
     if (nx <= 0 || ny <= 0) return;
     const int rows_per = nx >= kRoiMaxWin ? 1 : kRoiMaxWin / nx;
-    for (int gy0 = 0; gy0 < ny; gy0 += rows_per) roi_band_windows(job, st, li, nx, gy0, gy0 + rows_per < ny ? gy0 + rows_per : ny, P, L, pos, hits, hit_cap);
+    for (int gy0 = 0; gy0 < ny; gy0 += rows_per) roi_band_windows(job, st, li, nx, gy0, gy0 + rows_per < ny ? gy0 + rows_per : ny, P, L, pos, hits, hit_cap ROI_STAMP_PASS);
 }
 
 // One workgroup per (job, step): the steps of a job are independent of one another once the image is there, so each takes the
@@ -279,6 +300,10 @@ __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict
     L.lev = (lds_u8 *)(L.cnt + 4);
     const int tid = threadIdx.x;
     const uint8_t *__restrict__ img = job.img;
+#ifdef NVCA_STAMPS
+    unsigned long long tprev = __builtin_amdgcn_s_memtime(); const int sbase = job.scale_image ? 8 : 0;
+    if (tid == 0) atomicAdd(&g_roi_phase[sbase + 4], 1ull);
+#endif
     if (job.scale_image) {
         // cvHaarDetectObjectsForROC, CV_HAAR_SCALE_IMAGE branch, one factor: resize, integrate, scan the unscaled window on a fixed grid
         const int szw = st.szw, szh = st.szh, P = szw + 1;
@@ -291,14 +316,16 @@ __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict
         __syncthreads();
         roi_integral([&](int x, int y) { return L.lev[y * szw + x]; }, szw, szh, L.s, L.q, P);
         const int nx = (st.endX - st.startX + st.step - 1) / st.step, ny = (st.endY - st.startY + st.step - 1) / st.step;   // origins 0, step, 2 step, ...
-        roi_step_windows(job, st, li, nx, ny, P, L, [&](int gx, int gy, int &x, int &y) { x = st.startX + gx * st.step; y = st.startY + gy * st.step; }, hits, hit_cap);
+        ROI_STAMP(0);
+        roi_step_windows(job, st, li, nx, ny, P, L, [&](int gx, int gy, int &x, int &y) { x = st.startX + gx * st.step; y = st.startY + gy * st.step; }, hits, hit_cap ROI_STAMP_PASS);
         return;
     }
     // scale-cascade scan, one ladder step: the image's integral pair, the features scaled by the step's factor, stride max(2, factor), adaptive x step
     const int P = job.w + 1;
     roi_integral([&](int x, int y) { return img[(size_t)y * job.stride + x]; }, job.w, job.h, L.s, L.q, P);
+    ROI_STAMP(0);
     roi_step_windows(job, st, li, st.endX - st.startX, st.endY - st.startY, P, L,
-                     [&](int gx, int gy, int &x, int &y) { x = roi_cvround((st.startX + gx) * st.ystep); y = roi_cvround((st.startY + gy) * st.ystep); }, hits, hit_cap);
+                     [&](int gx, int gy, int &x, int &y) { x = roi_cvround((st.startX + gx) * st.ystep); y = roi_cvround((st.startY + gy) * st.ystep); }, hits, hit_cap ROI_STAMP_PASS);
 }
 
 void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep *steps, const unsigned char *tabs, unsigned long long *hits,
@@ -306,6 +333,23 @@ void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep
 {
     NVCA_LAUNCH(k_roi, dim3(nsteps), dim3(kRoiThreads), (size_t)lds_bytes, st, jobs, steps, tabs, hits, hit_cap, plane_words);
 }
+#ifdef NVCA_STAMPS
+void roi_stamps_dump(const char *path)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_roi_phase), sizeof(h)) != hipSuccess) return;
+    if (FILE *f = fopen(path, "w")) {
+        const char *names[2] = {"scale-cascade steps", "scale-image levels"};
+        for (int k = 0; k < 2; k++) {
+            const unsigned long long *p = h + 8 * k;
+            const double wg = p[4] ? (double)p[4] : 1.;
+            fprintf(f, "%s: %llu workgroups; ticks per workgroup: image + integral %.0f, A (normaliser + stage 0) %.0f, B (stages 1-3) %.0f, C (late stages) %.0f; windows into C per workgroup %.2f\n",
+                    names[k], p[4], p[0] / wg, p[1] / wg, p[2] / wg, p[3] / wg, p[5] / wg);
+        }
+        fclose(f);
+    }
+}
+#endif
 int roi_grant_lds(int bytes)
 {
     static std::mutex mu;

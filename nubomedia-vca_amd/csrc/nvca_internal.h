@@ -594,6 +594,9 @@ struct RoiJobDev {
 static constexpr int kRoiMaxWin = 2048;           // windows of one ladder step / pyramid level of a small-image job
 void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep *steps, const unsigned char *tabs, unsigned long long *hits,
                 unsigned hit_cap, int plane_words, int lds_bytes);
+#ifdef NVCA_STAMPS
+void roi_stamps_dump(const char *path);     // diagnostic build: k_roi's phase sums as text
+#endif
 int roi_grant_lds(int bytes);     // dynamic LDS above 64 KiB is granted per function and device (monotonic, process-wide); returns a hipError_t as int
 
 // groupRectangles per frame on the device; out: [batch][2 + 4*out_cap] ints: count (-1 = host must group), raw count, boxes
