@@ -165,7 +165,7 @@ print(json.dumps({"roi_chain_batched": {"video_streams": V, "frames_per_s": V * 
 # ---- the same V video streams spread over C contexts on the one GPU, one host thread per context (what the GStreamer shim's
 # per-GPU frontend does with NVCA_VIRTUAL_GPUS): the launch-bound chains of different contexts are queued in parallel
 import threading
-for C in (2, 4):
+for C in (() if "--no-contexts" in sys.argv else (2, 4)):
     if V % C:
         continue
     ctxs = [capi.Context(0) for _ in range(C)]

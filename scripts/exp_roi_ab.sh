@@ -6,7 +6,7 @@ for rep in 1 2; do
   for cfg in "$@"; do
     read -r name lib envs <<< "$cfg"
     [ "$lib" = "-" ] && lib=""
-    env NVCA_LIB=$lib $envs python3 scripts/bench_roi_chain.py > $OUT/$name.$rep.txt 2> $OUT/$name.$rep.err
+    env NVCA_LIB=$lib $envs python3 scripts/bench_roi_chain.py --no-contexts > $OUT/$name.$rep.txt 2> $OUT/$name.$rep.err
     python3 - $OUT/$name.$rep.txt $name <<'PY'
 import json, sys
 out = {}
