@@ -115,70 +115,80 @@ __device__ __forceinline__ bool joined(float a, float b, float seg)
 }
 
 // the component kernels run 256 pixels of a row per block: one flagged segment
-__device__ __forceinline__ bool segment_live(const uint8_t *__restrict__ flags, int w, int h)
+__device__ __forceinline__ bool segment_live(const uint8_t *__restrict__ flags, int w, int h, int y)
 {
-    return flags[((size_t)blockIdx.z * h + blockIdx.y) * seg_per_row(w) + blockIdx.x] != 0;
+    return flags[((size_t)blockIdx.z * h + y) * seg_per_row(w) + blockIdx.x] != 0;
 }
+// A block of the component kernels walks kCclRows rows of its 256-pixel column: most segments of a frame hold no motion and
+// are skipped on their flag byte, and a grid of one block per segment (69 k blocks for 8 x 1080p) cost 30 us per kernel in
+// block dispatch alone -- five kernels a tick.
+static constexpr int kCclRowsDefault = 8;
 
 // Labels start as horizontal runs: within a wave (64 consecutive pixels of a row) every pixel points at the first pixel
 // of its maximal run of joined neighbours, so the row direction needs no atomics except across wave boundaries.
-__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags, int kCclRows)
 {
-    if (!segment_live(flags, w, h)) return;           // nothing but zeros here: no labels are written, and nobody will read any
     const TrkSlot s = slots[blockIdx.z];
     int *lab = labels + (size_t)blockIdx.z * w * h;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const bool in = x < w;
-    const int i = y * w + x;
-    const float v = in ? s.mhi[i] : 0.f;
-    float l = __shfl_up(v, 1);
-    if (lane == 0) l = (in && x > 0) ? s.mhi[i - 1] : 0.f;
-    const bool link = v != 0.f && l != 0.f && joined(v, l, s.seg);
-    const unsigned long long starts = ~__ballot(link) | 1ull;                   // lanes that begin a run inside this wave
-    const unsigned long long upto = starts & (~0ull >> (63 - lane));            // ... at or left of this lane
-    const int head = 63 - __clzll((long long)upto);
-    if (in) lab[i] = v != 0.f ? i - (lane - head) : -1;
+    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!segment_live(flags, w, h, y)) continue;  // nothing but zeros here: no labels are written, and nobody will read any
+        const int i = y * w + x;
+        const float v = in ? s.mhi[i] : 0.f;
+        float l = __shfl_up(v, 1);
+        if (lane == 0) l = (in && x > 0) ? s.mhi[i - 1] : 0.f;
+        const bool link = v != 0.f && l != 0.f && joined(v, l, s.seg);
+        const unsigned long long starts = ~__ballot(link) | 1ull;                   // lanes that begin a run inside this wave
+        const unsigned long long upto = starts & (~0ull >> (63 - lane));            // ... at or left of this lane
+        const int head = 63 - __clzll((long long)upto);
+        if (in) lab[i] = v != 0.f ? i - (lane - head) : -1;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags, int kCclRows)
 {
-    if (!segment_live(flags, w, h)) return;
     const TrkSlot s = slots[blockIdx.z];
     const int n = w * h;
     int *lab = labels + (size_t)blockIdx.z * n;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    const int i = y * w + x;
-    const float v = s.mhi[i];
-    if (v == 0.f) return;
-    const float l = x > 0 ? s.mhi[i - 1] : 0.f;
-    const bool link_l = l != 0.f && joined(v, l, s.seg);
-    if ((threadIdx.x & 63) == 0 && link_l) uf_union(lab, i, i - 1);             // runs are cut at wave boundaries
-    if (y > 0) {
-        const float u = s.mhi[i - w];
-        if (u != 0.f && joined(v, u, s.seg)) {
-            // redundant when the left neighbour already ties the two rows together: v~l, l~ul, ul~u
-            const float ul = x > 0 ? s.mhi[i - w - 1] : 0.f;
-            const bool tied = link_l && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
-            if (!tied) uf_union(lab, i, i - w);
+    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!segment_live(flags, w, h, y)) continue;
+        const int i = y * w + x;
+        const float v = s.mhi[i];
+        if (v == 0.f) continue;
+        const float l = x > 0 ? s.mhi[i - 1] : 0.f;
+        const bool link_l = l != 0.f && joined(v, l, s.seg);
+        if ((threadIdx.x & 63) == 0 && link_l) uf_union(lab, i, i - 1);             // runs are cut at wave boundaries
+        if (y > 0) {
+            const float u = s.mhi[i - w];
+            if (u != 0.f && joined(v, u, s.seg)) {
+                // redundant when the left neighbour already ties the two rows together: v~l, l~ul, ul~u
+                const float ul = x > 0 ? s.mhi[i - w - 1] : 0.f;
+                const bool tied = link_l && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
+                if (!tied) uf_union(lab, i, i - w);
+            }
         }
     }
 }
 
 
-__global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags, int kCclRows)
 {
-    if (!segment_live(flags, w, h)) return;
     const int n = w * h;
     int *lab = labels + (size_t)blockIdx.z * n;
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    const int i = blockIdx.y * w + x;
-    if (lab[i] < 0) return;
-    const int r = uf_find(lab, i);
-    lab[i] = r;
-    if (r == i) { CompAcc c; c.minx = c.miny = 0x7fffffff; c.maxx = c.maxy = -1; c.seed = 0x7fffffff; c.pad = 0; ac[i] = c; }
+    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!segment_live(flags, w, h, y)) continue;
+        const int i = y * w + x;
+        if (lab[i] < 0) continue;
+        const int r = uf_find(lab, i);
+        lab[i] = r;
+        if (r == i) { CompAcc c; c.minx = c.miny = 0x7fffffff; c.maxx = c.maxy = -1; c.seed = 0x7fffffff; c.pad = 0; ac[i] = c; }
+    }
 }
 
 // bounding box / first seed of a root: min / max atomics, attempted only when the value read (at device scope, past the
@@ -199,7 +209,7 @@ __device__ __forceinline__ void acc_report(CompAcc *c, int minx, int maxx, int y
 }
 
 __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
-                                                    CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags, int order)
+                                                    CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags, int order, int kCclRows)
 {
     const TrkSlot s = slots[blockIdx.z];
     const int nseg = seg_per_row(w);
@@ -210,9 +220,10 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     // When most of the frame moves, rows are visited from the outside in (0, last, 1, last - 1, ...): the extreme rows of a
     // frame-sized component arrive first, and everything that follows fails the "would it still improve" test instead of
     // queueing up (0.76 -> 0.46 ms per 4 x 720p); otherwise top to bottom, which is kinder to memory (0.49 -> 0.42 ms per 8 x 1080p)
-    const int by = (order & 1) ? ((blockIdx.y & 1) ? h - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1)) : (int)blockIdx.y;
     const int bx = (int)blockIdx.x;
-    if (!flags[((size_t)blockIdx.z * h + by) * nseg + bx]) return;
+    for (int v = blockIdx.y * kCclRows, v1 = min(v + kCclRows, h); v < v1; v++) {
+    const int by = (order & 1) ? ((v & 1) ? h - 1 - (v >> 1) : (v >> 1)) : v;
+    if (!flags[((size_t)blockIdx.z * h + by) * nseg + bx]) continue;
     const int x = bx * 256 + threadIdx.x, y = by, lane = threadIdx.x & 63;
     const int i = y * w + x;
     const int r = x < w ? lab[i] : -1;                // labels are final roots after k_ccl_flatten
@@ -245,30 +256,33 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
         todo &= ~g;
     }
     if ((todo >> lane) & 1ull) acc_report(&ac[r], start_l ? x : 0x7fffffff, end_r ? x : -1, y, start_l, seed0 ? i : 0x7fffffff);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ccl_collect(const TrkSlot *__restrict__ slots, const int *__restrict__ labels,
                                                      const CompAcc *__restrict__ acc, int w, int h, const uint8_t *__restrict__ flags,
-                                                     int *__restrict__ out /* [0]=count, then 6 ints per comp */, int cap)
+                                                     int *__restrict__ out /* [0]=count, then 6 ints per comp */, int cap, int kCclRows)
 {
-    if (!segment_live(flags, w, h)) return;
     const int slot = blockIdx.z, n = w * h;
     const int *lab = labels + (size_t)slot * n;
     const CompAcc *ac = acc + (size_t)slot * n;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    const int i = blockIdx.y * w + x;
-    if (lab[i] != i) return;
-    const CompAcc c = ac[i];
-    if (c.seed == 0x7fffffff) return;
-    {   // TRK/gstnubotracker.cpp:171-200: boxes outside the area window are erased and never merged with anything
-        const int area = (c.maxx - c.minx + 1) * (c.maxy - c.miny + 1);
-        if (!(area > slots[slot].min_area && (long long)area < slots[slot].max_area)) return;
-    }
-    const int k = atomicAdd(&out[0], 1);
-    if (k < cap) {
-        int *o = out + 2 + (size_t)k * 6;
-        o[0] = slot; o[1] = c.seed; o[2] = c.minx; o[3] = c.miny; o[4] = c.maxx - c.minx + 1; o[5] = c.maxy - c.miny + 1;
+    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!segment_live(flags, w, h, y)) continue;
+        const int i = y * w + x;
+        if (lab[i] != i) continue;
+        const CompAcc c = ac[i];
+        if (c.seed == 0x7fffffff) continue;
+        {   // TRK/gstnubotracker.cpp:171-200: boxes outside the area window are erased and never merged with anything
+            const int area = (c.maxx - c.minx + 1) * (c.maxy - c.miny + 1);
+            if (!(area > slots[slot].min_area && (long long)area < slots[slot].max_area)) continue;
+        }
+        const int k = atomicAdd(&out[0], 1);
+        if (k < cap) {
+            int *o = out + 2 + (size_t)k * 6;
+            o[0] = slot; o[1] = c.seed; o[2] = c.minx; o[3] = c.miny; o[4] = c.maxx - c.minx + 1; o[5] = c.maxy - c.miny + 1;
+        }
     }
 }
 
@@ -280,13 +294,14 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     if (vec4) NVCA_LAUNCH(k_trk_pixel4, gp, dim3(256), 0, st, slots, w, h, flags);
     else NVCA_LAUNCH(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h, flags);
     if (!run_ccl) return;
-    dim3 g2((w + 255) / 256, h, batch);
-    NVCA_LAUNCH(k_ccl_init, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
-    NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
-    NVCA_LAUNCH(k_ccl_flatten, g2, dim3(256), 0, st, labels, (CompAcc *)acc, w, h, (const uint8_t *)flags);
+    static const int rows = [] { const char *e = getenv("NVCA_CCL_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 256 ? v : kCclRowsDefault; }();
+    dim3 g2((w + 255) / 256, (h + rows - 1) / rows, batch);
+    NVCA_LAUNCH(k_ccl_init, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags, rows);
+    NVCA_LAUNCH(k_ccl_merge, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags, rows);
+    NVCA_LAUNCH(k_ccl_flatten, g2, dim3(256), 0, st, labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, rows);
     // order (Switches::trk_order): -1: decided per frame on the device
-    NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, order);
-    NVCA_LAUNCH(k_ccl_collect, g2, dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, w, h, (const uint8_t *)flags, out, cap);
+    NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, order, rows);
+    NVCA_LAUNCH(k_ccl_collect, g2, dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, w, h, (const uint8_t *)flags, out, cap, rows);
 }
 
 
