@@ -213,6 +213,7 @@ static Switches read_switches()
     w.two_lanes = num("NVCA_TWO_LANES", 1) != 0;
     w.roi = num("NVCA_ROI", 1) != 0;
     w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
+    w.stage_order = num("NVCA_STAGE_ORDER", 1) != 0;
     w.pre_cus = num("NVCA_PRE_CUS", 0);
     w.quiet = set("NVCA_QUIET");
     w.stamps_out = getenv("NVCA_STAMPS_OUT");
@@ -545,7 +546,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
         a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
-        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0;
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0; a.stage_order = ctx->sw.stage_order ? 1 : 0;
         a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
@@ -924,6 +925,7 @@ try {
     else if (n == "two_lanes") w.two_lanes = value != 0;
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "stage_fuse") w.stage_fuse = value != 0;
+    else if (n == "stage_order") w.stage_order = value != 0;
     else if (n == "pre_cus") w.pre_cus = value > 0 ? value : 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }

@@ -728,11 +728,23 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     // nobody touches during this stage and which the next stage appends to -- one barrier per stage instead of two
     int cin = 0;
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    int s = 1;
-    while (s < last) {
+    // The early stages 1 .. m may be walked in any order: a window goes on iff it passes all of them, and which of them it
+    // fails first changes nothing anyone sees.  The band kernel walks them in the order the PREVIOUS tile of its band found
+    // cheapest -- stump count per window killed, from that tile's entered / passed counts per stage (stat words: entered << 16 |
+    // passed; word 0: the order for this tile, 4 bits a position, written by thread 0 at the end of the previous tile; 0 =
+    // nothing known, the cascade's own order).  A stage that lets nearly everything through is then met by the few windows the
+    // selective ones leave.  Switch "stage_order"; never together with stage fusion.
+    const int m = last - 1;
+    const bool adapt = VNF_LDS && a.stage_order && !a.stage_fuse && m >= 2 && m < kStatStages;
+    unsigned ordpack = 0x54321u;
+    if (adapt) { const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(stat_r[0]); if (o) ordpack = o; }
+    int s = adapt ? (int)(ordpack & 15u) : 1;
+    int kpos = 0, prev = 0; unsigned entered = 0;          // wave-uniform
+    while (adapt ? kpos < m : s < last) {
         __syncthreads();             // queue complete (first pass: tile and maps staged as well)
         NVCA_STAMP(a, ti, 8 + 8 * s);
         const int n = L.qn[cin];
+        if (adapt && tid == 0 && prev) stat_w[prev] |= n;        // what the stage before let through
         if (n == 0) break;
 #ifdef NVCA_STAMPS
         if (threadIdx.x == 0 && blockIdx.x < 64 && ti < 16 && a.dbg) a.dbg[((size_t)blockIdx.x * 16 + ti) * 64 + 8 + 8 * s + 7] = (unsigned long long)n;
@@ -761,7 +773,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
                 if (lane == 0 && sum >= st.thr_i) qo[atomicAdd(&L.qn[cout], 1)] = (unsigned short)w;
             }
-            if (s < kStatStages && tid == 0) stat_w[s] = n;
+            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
             NVCA_STAMP(a, ti, 8 + 8 * s + 1); NVCA_STAMP(a, ti, 8 + 8 * s + 2); NVCA_STAMP(a, ti, 8 + 8 * s + 3);
         } else if (st.flags & 4) {
             // ---- integer votes: balanced runs over (window group, stump), LDS accumulators, optional fusion with stage s + 1
@@ -811,7 +823,7 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 pass = pass_a && (!fuse || sb >= thr2);
                 w = qi[tid];
             }
-            if (s < kStatStages && tid == 0) stat_w[s] = n;
+            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
             if (fuse && s + 1 < kStatStages) {     // stage s + 1 has no queue of its own this time: count who would have entered it
                 const unsigned long long am = __ballot(pass_a);
                 if (lane == 0 && am) atomicAdd(&stat_w[s + 1], (int)__popcll(am));
@@ -833,13 +845,42 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
                 }
                 queue_push(pass, w, qo, &L.qn[cout]);
             }
-            if (tid == 0 && s < kStatStages) stat_w[s] = n;
+            if (tid == 0 && s < kStatStages) stat_w[s] = adapt ? n << 16 : n;
         }
-        cur ^= 1; cin = cout; s += adv;
+        cur ^= 1; cin = cout;
+        if (adapt) { prev = s; entered |= 1u << s; kpos++; s = (int)((ordpack >> (4 * kpos)) & 15u); }
+        else s += adv;
     }
     __syncthreads();
     NVCA_STAMP(a, ti, 6);
     const int nh = L.qn[cin];
+    if (adapt && tid == 0) {
+        if (prev && kpos >= m) stat_w[prev] |= nh;           // the walk reached its end: the last stage's survivors
+        // the order for the next tile.  A stage this tile did not reach, or met with a handful of windows only, keeps what was
+        // known about it; cost of a stage = its stumps per window killed (x 64: integer arithmetic)
+        int key[kStatStages - 1], id[kStatStages - 1];
+        bool known = true;
+#pragma unroll
+        for (int q = 1; q < kStatStages; q++) {
+            int v = stat_w[q];
+            const int old = stat_r[q];
+            if (q <= m && (!((entered >> q) & 1u) || ((v >> 16) < 16 && old != 0))) { v = old; stat_w[q] = v; }
+            const int ent = v >> 16, pas = v & 0xffff, cnt = L.carry[kTileRows + q];
+            if (q <= m && ent == 0) known = false;
+            const int killed = ent - pas > 0 ? ent - pas : 0;
+            key[q - 1] = q > m ? 0x7fffffff : (killed ? (cnt * ent * 64) / killed : 0x7ffffff0);
+            id[q - 1] = q;
+        }
+#pragma unroll
+        for (int pass_i = 0; pass_i < kStatStages - 2; pass_i++)
+#pragma unroll
+            for (int q = 0; q + 1 < kStatStages - 1 - pass_i; q++)
+                if (key[q] > key[q + 1]) { const int tk = key[q]; key[q] = key[q + 1]; key[q + 1] = tk; const int ti2 = id[q]; id[q] = id[q + 1]; id[q + 1] = ti2; }
+        unsigned pack = 0;
+#pragma unroll
+        for (int q = 0; q < kStatStages - 1; q++) pack |= (unsigned)id[q] << (4 * q);
+        stat_w[0] = known ? (int)pack : 0;
+    }
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
@@ -917,7 +958,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     {   // carried parity lives at a fixed place: the carve-up's fixed part does not depend on the tile
         const TileRec t0 = load_const(a.tiles + b.first_tile);
         const TileLds L0 = carve_tile(lds, t0);
-        if (tid < kTileWin) L0.carry[tid] = 0;
+        if (tid < kTileWin) L0.carry[tid] = (tid >= kTileRows && tid - kTileRows < a.nstages) ? a.stages[tid - kTileRows].count : 0;      // rows 0 .. 23: the carried parities; behind them: stumps per stage (tile_stages' stage order)
         int *acc = (int *)L0.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;          // stage accumulators (tile_stages)
         if (tid < 2 * kStatStages) L0.qn[4 + tid] = 0;                                  // no tile seen yet
     }

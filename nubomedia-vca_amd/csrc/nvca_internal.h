@@ -178,6 +178,7 @@ struct Switches {
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
+    bool stage_order = true;         // NVCA_STAGE_ORDER=0: k_band walks the early stages 1 .. deep_stage-1 in the cascade's order on every tile (1: in the order the previous tile of the band found cheapest -- cost per window killed; the set of survivors is the same)
     bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
     int  pre_cus = 0;                // NVCA_PRE_CUS=n: a submitted face batch's pre-processing runs on a stream confined to n CUs (hipExtStreamCreateWithCUMask), beside the other batch's band kernel (0: behind it, on the lane's own stream)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
@@ -446,6 +447,7 @@ struct CascadeArgs {
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
     int stage_fuse;                // Switches::stage_fuse
+    int stage_order;               // Switches::stage_order
     int deep_stage;                // first stage evaluated by k_deep
     int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key

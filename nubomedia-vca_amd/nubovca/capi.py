@@ -231,7 +231,7 @@ class Context:
     # defaults of the A/B switches when the environment sets none (nvca_ctx_set_option)
     OPTION_DEFAULTS = {"band": -1, "band_map": 0, "tiles": 1, "deep_stage": 0, "deep_lds": 1, "pyr_off": 0, "host_group": 0,
                        "group_zerocopy": 1, "sparse_ingest": 1, "ingest_chunk": 8, "skip_cascade": 0, "host_profile": 0,
-                       "part_stats": 0, "trk_order": -1, "plan_debug": 0, "quiet": 0, "roi": 1, "stage_fuse": 0, "host_threads": -1, "two_lanes": 1}
+                       "part_stats": 0, "trk_order": -1, "plan_debug": 0, "quiet": 0, "roi": 1, "stage_fuse": 0, "stage_order": 1, "host_threads": -1, "two_lanes": 1}
 
     def set_option(self, name, value):
         self.check(self.L.nvca_ctx_set_option(self.h, name.encode(), int(value)))
