@@ -317,7 +317,7 @@ struct GeomPlan {
 DetectPlan::~DetectPlan()
 {
     release_tables();
-    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_blob.release();
+    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_stage_hint.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -335,6 +335,7 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
         {&d_deeprecs, deeprecs.data(), deeprecs.size() * sizeof(DeepRec)},
+        {&d_stage_hint, nullptr, tiles.empty() ? (size_t)0 : 8 * sizeof(int)},          // zero: nothing known yet
     };
     // one device allocation and one copy for all tables (a FIND_BIGGEST scan builds a plan per scale, per call)
     size_t total = 0;
@@ -342,7 +343,7 @@ int DetectPlan::upload(nvca_ctx *ctx)
     if (total == 0) return NVCA_OK;
     std::vector<unsigned char> blob(total);
     size_t off = 0;
-    for (auto &it : items) { if (it.n) memcpy(blob.data() + off, it.h, it.n); off += (it.n + 255) & ~(size_t)255; }
+    for (auto &it : items) { if (it.n && it.h) memcpy(blob.data() + off, it.h, it.n); off += (it.n + 255) & ~(size_t)255; }
     for (auto &it : items) it.d->release();
     if (d_blob.ensure(total)) { ctx->set_error("hipMalloc failed for plan tables"); return NVCA_ERR_NOMEM; }
     NVCA_HIP_CHECK(ctx, hipMemcpy(d_blob.p, blob.data(), total, hipMemcpyHostToDevice));
@@ -546,7 +547,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
         a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
-        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0; a.stage_order = ctx->sw.stage_order ? 1 : 0;
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0; a.stage_order = ctx->sw.stage_order ? 1 : 0; a.stage_hint = dp.d_stage_hint.as<int>();
         a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();

@@ -735,9 +735,16 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
     // nothing known, the cascade's own order).  A stage that lets nearly everything through is then met by the few windows the
     // selective ones leave.  Switch "stage_order"; never together with stage fusion.
     const int m = last - 1;
-    const bool adapt = VNF_LDS && a.stage_order && !a.stage_fuse && m >= 2 && m < kStatStages;
+    const bool adapt = a.stage_order && !a.stage_fuse && m >= 2 && m < kStatStages;
     unsigned ordpack = 0x54321u;
-    if (adapt) { const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(stat_r[0]); if (o) ordpack = o; }
+    if (adapt) {
+        // (the word may come from the plan's hint words, which other workgroups write as they go: it is used only if its first m
+        // positions name each of the stages 1 .. m once)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(stat_r[0]);
+        unsigned seen = 0;
+        for (int q = 0; q < m; q++) seen |= 1u << ((o >> (4 * q)) & 15u);
+        if (seen == (2u << m) - 2u) ordpack = o;
+    }
     int s = adapt ? (int)(ordpack & 15u) : 1;
     int kpos = 0, prev = 0; unsigned entered = 0;          // wave-uniform
     while (adapt ? kpos < m : s < last) {
@@ -880,6 +887,11 @@ __device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec 
 #pragma unroll
         for (int q = 0; q < kStatStages - 1; q++) pack |= (unsigned)id[q] << (4 * q);
         stat_w[0] = known ? (int)pack : 0;
+        if (known && a.stage_hint) {            // plain stores: any mixture of finished tiles' words is a usable start
+#pragma unroll
+            for (int q = 1; q < kStatStages; q++) a.stage_hint[q] = stat_w[q];
+            a.stage_hint[0] = (int)pack;
+        }
     }
     if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
@@ -910,7 +922,9 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileLds L = carve_tile(lds, t);
     const TileCoords tc = tile_coords(a, t, sc);
     tile_commit(a, t, sc, slot, L, tc);
-    { int *acc = (int *)L.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0; if (tid < 2 * kStatStages) L.qn[4 + tid] = 0; }     // stage accumulators, no band history
+    { int *acc = (int *)L.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;                                                       // stage accumulators
+      if (tid < 2 * kStatStages) L.qn[4 + tid] = (tid < kStatStages && a.stage_hint) ? a.stage_hint[tid] : 0;                   // no band history: what the plan's tiles last left
+      if (tid >= kTileRows && tid < kTileWin) L.carry[tid] = tid - kTileRows < a.nstages ? a.stages[tid - kTileRows].count : 0; }  // stumps per stage (tile_stages' stage order)
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
     __syncthreads();                 // qn zeroed, maps and samples staged
@@ -960,7 +974,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         const TileLds L0 = carve_tile(lds, t0);
         if (tid < kTileWin) L0.carry[tid] = (tid >= kTileRows && tid - kTileRows < a.nstages) ? a.stages[tid - kTileRows].count : 0;      // rows 0 .. 23: the carried parities; behind them: stumps per stage (tile_stages' stage order)
         int *acc = (int *)L0.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;          // stage accumulators (tile_stages)
-        if (tid < 2 * kStatStages) L0.qn[4 + tid] = 0;                                  // no tile seen yet
+        if (tid < 2 * kStatStages) L0.qn[4 + tid] = (tid < kStatStages && a.stage_hint) ? a.stage_hint[tid] : 0;      // no tile of this band seen yet: what the plan's tiles last left
     }
     static_assert(kTileSlots == kTileThreads, "one window per thread and tile");
     const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band

@@ -448,6 +448,7 @@ struct CascadeArgs {
     int nstages; int pair_policy;  // 1 = F32PAIR
     int stage_fuse;                // Switches::stage_fuse
     int stage_order;               // Switches::stage_order
+    int *stage_hint;               // [8] per plan: the stat words (order | entered << 16 | passed per stage) the last tile that finished left -- where a band's first tile and the per-tile kernel start from
     int deep_stage;                // first stage evaluated by k_deep
     int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key

@@ -70,7 +70,7 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_blob;   // the table buffers are views into d_blob
+    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_stage_hint, d_blob;   // the table buffers are views into d_blob (d_stage_hint: 8 words the tile kernels keep their stage statistics in, zero at upload)
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
