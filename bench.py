@@ -166,6 +166,14 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
         content[name] = {"frames_per_s": fps, "ms_per_step": ms}
     tab["content"] = content
     tab["content_note"] = "device-resident, %d frames per call (8 distinct frames cycled), same cascade and parameters as the headline" % F
+    # what the adaptive order of the early stages is worth on THIS cascade and content (it changes no result): the headline's frames,
+    # one synchronous call per batch, with the tile kernels walking stages 1 .. 5 in the order the previous tile found cheapest
+    # (the default) and in the cascade's own order -- a trained cascade, whose stages reject about half each, gets the second figure
+    fps_a, ms_a = rate(frames_np, 3)
+    with ctx.options(stage_order=0):
+        fps_n, ms_n = rate(frames_np, 3)
+    tab["stage_order"] = {"adaptive_frames_per_s": fps_a, "adaptive_ms_per_call": ms_a, "cascade_order_frames_per_s": fps_n, "cascade_order_ms_per_call": ms_n,
+                          "note": "synchronous calls (not the serving loop); same boxes either way; the gain comes from this synthetic cascade's non-monotone stage selectivities (DESIGN.md 6)"}
 
     # the other BASELINE configs on this GPU, a few ticks each (their own `--workload` runs give the full line)
     def multi(Wm, Hm, S, with_tracker, ticks=3, reps=4):
