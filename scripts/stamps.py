@@ -15,10 +15,11 @@ for b in range(64):
             continue
         r = {"fill_coords": s[1] - s[0], "fill_commit": s[2] - s[1], "fill_wait": s[3] - s[2], "stage0": s[4] - s[3], "adaptive": s[5] - s[4]}
         prev = s[5]
-        for st in range(1, 6):
+        # the stages in the order this tile walked them (the band kernel orders stages 1 .. 5 by what the previous tile saw)
+        walked = sorted((st for st in range(1, 6) if s[8 + 8 * st] != 0), key=lambda st: s[8 + 8 * st])
+        r["order"] = int("".join(str(st) for st in walked) or "0")
+        for st in walked:
             o = 8 + 8 * st
-            if s[o] == 0:
-                break
             r["s%d_top_barrier" % st] = s[o] - prev
             if s[o + 1]:
                 r["s%d_stumps" % st] = s[o + 1] - s[o]
@@ -39,6 +40,12 @@ for r in rows:
         if k not in keys:
             keys.append(k)
 print("tiles:", len(rows))
+orders = {}
+for r in rows:
+    orders[r["order"]] = orders.get(r["order"], 0) + 1
+print("stage orders walked (digits = stages in order, tiles):", sorted(orders.items(), key=lambda kv: -kv[1])[:8])
 for k in keys:
+    if k == "order":
+        continue
     v = np.array([r[k] for r in rows if k in r])
     print("%-22s median %8.0f  mean %8.0f  (n=%d)" % (k, np.median(v), v.mean(), len(v)))
