@@ -161,7 +161,10 @@ def test_face_tracker_batch_8x1080p_vs_oracle(ctx, casc, orc_cascade):
 
 
 @pytest.mark.parametrize("env,N", [({"band": 1}, 5), ({"band": 1, "band_map": 1}, 8),
-                                   ({"band": 1, "band_map": 2}, 16)])
+                                   ({"band": 1, "band_map": 2}, 16),
+                                   # the early stages in the cascade's own order on every tile, in both tile kernels (the default walks
+                                   # them in the order the previous tile found cheapest: the survivors must not depend on it)
+                                   ({"band": 1, "stage_order": 0}, 6), ({"band": 0, "stage_order": 0}, 6), ({"band": 0}, 6)])
 def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N):
     """k_band decodes (band, frame slot) from the block index (and NVCA_BAND_MAP remaps it): frames of DIFFERENT content
     in one geometry, forced through the band kernel, each checked against the oracle (a slot / plane mix-up would
@@ -179,7 +182,10 @@ def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N):
         res = ctx.face_batch_process(streams, fr)
     kt = ctx.kernel_timing()
     ctx.enable_kernel_timing(0)
-    assert _launched(kt, "cascade_band") == 1 and _launched(kt, "cascade_tile") == 0, kt
+    if env.get("band"):
+        assert _launched(kt, "cascade_band") == 1 and _launched(kt, "cascade_tile") == 0, kt
+    else:
+        assert _launched(kt, "cascade_band") == 0 and _launched(kt, "cascade_tile") == 1, kt
     seen = 0
     for i in range(N):
         eb, eid = orc.FaceStream(orc_cascade, width_to_process=W, scale_factor_pct=10, min_neighbors=2).process(frames[i])
