@@ -590,7 +590,9 @@ def main():
                                    ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
                        "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
                        "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world, "ranks_seen": ranks_seen,
-                       "batches_in_flight": 2 if pipelined else 1},
+                       "batches_in_flight": 2 if pipelined else 1,
+                       "early_stage_order": ("cascade" if os.environ.get("NVCA_STAGE_ORDER") == "0" else
+                                             "adaptive (same survivors; secondary.stage_order has this cascade's figure in its own order)")},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
