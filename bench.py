@@ -117,9 +117,9 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
     page-locked), and the content sweep of SURVEY.md 8d (uniform noise; gradient + K pasted templates)."""
     from nubovca import capi, synth
 
-    def rate(frames, reps, host=False, pinned=False, per_call=None):
+    def rate(frames, reps, host=False, pinned=False, per_call=None, use=None):
         per_call = per_call or len(frames)
-        st = capi.FaceStream(ctx, casc, **props)
+        st = capi.FaceStream(ctx, use or casc, **props)
         if host:
             fr = [capi.make_frame(f) for f in frames]
             if pinned:
@@ -166,14 +166,13 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
         content[name] = {"frames_per_s": fps, "ms_per_step": ms}
     tab["content"] = content
     tab["content_note"] = "device-resident, %d frames per call (8 distinct frames cycled), same cascade and parameters as the headline" % F
-    # what the adaptive order of the early stages is worth on THIS cascade and content (it changes no result): the headline's frames,
-    # one synchronous call per batch, with the tile kernels walking stages 1 .. 5 in the order the previous tile found cheapest
-    # (the default) and in the cascade's own order -- a trained cascade, whose stages reject about half each, gets the second figure
-    fps_a, ms_a = rate(frames_np, 3)
-    with ctx.options(stage_order=0):
-        fps_n, ms_n = rate(frames_np, 3)
-    tab["stage_order"] = {"adaptive_frames_per_s": fps_a, "adaptive_ms_per_call": ms_a, "cascade_order_frames_per_s": fps_n, "cascade_order_ms_per_call": ms_n,
-                          "note": "synchronous calls (not the serving loop); same boxes either way; the gain comes from this synthetic cascade's non-monotone stage selectivities (DESIGN.md 6)"}
+    # rounds 1-3 quoted the headline on the UNcalibrated stand-in cascade (stage thresholds from i.i.d. noise: on this content its
+    # stages 0-3 let 51 / 64 / 82 / 94 % through and stage 4 rejects 97.5 %): the same frames through it, for continuity
+    other = synth.synthetic_cascade_xml() if args.cascade == "calibrated" else synth.calibrated_cascade_xml()
+    oc = ctx.load_cascade_xml(other)
+    fps_o, ms_o = rate(frames_np, 3, use=oc)
+    tab["other_cascade"] = {"cascade": "standin (rounds 1-3)" if args.cascade == "calibrated" else "calibrated", "frames_per_s": fps_o, "ms_per_call": ms_o,
+                            "note": "synchronous calls (not the serving loop), same frames and parameters as the headline"}
 
     # the other BASELINE configs on this GPU, a few ticks each (their own `--workload` runs give the full line)
     def multi(Wm, Hm, S, with_tracker, ticks=3, reps=4):
@@ -358,6 +357,10 @@ def main():
                          "--streams-per-gpu 720p streams, one frame each per step; face_tracker: configs[4], "
                          "--streams-per-gpu 1080p streams through NuboFaceDetector and NuboTracker")
     ap.add_argument("--streams-per-gpu", type=int, default=0)
+    ap.add_argument("--cascade", default="calibrated", choices=["calibrated", "standin"],
+                    help="calibrated (default since round 4): the synthetic cascade with every early stage's threshold set on windows of "
+                         "the bench's own content so that each stage rejects about half of what reaches it (a trained cascade's profile); "
+                         "standin: rounds 1-3's cascade (thresholds from i.i.d. noise: non-monotone stage selectivities on this content)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -394,7 +397,7 @@ def main():
     multi_stream = args.workload != "face1080p"
     W, H, F = args.width, args.height, args.frames_per_step
     w2p = args.width_to_process or W
-    xml = synth.synthetic_cascade_xml()
+    xml = synth.calibrated_cascade_xml() if args.cascade == "calibrated" else synth.synthetic_cascade_xml()
     ctx = capi.Context(local_rank)
     casc = ctx.load_cascade_xml(xml)
     props = {"width_to_process": w2p, "multi_scale_factor": args.scale_factor_pct}
@@ -582,7 +585,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32 rect sums / f32 products / f64 stage sums (u8 pixels)",
             "data": "synthetic (%s field + %d pasted templates; seeded synthetic stump cascade shaped like "
-                    "haarcascade_frontalface_alt: 22 stages, 2135 stumps)" % (args.content, args.faces),
+                    "haarcascade_frontalface_alt: 22 stages, 2135 stumps, %s stage thresholds)" % (args.content, args.faces, args.cascade),
             "config": {"workload": ("NuboFaceDetector %dx%d single stream per GPU" if not multi_stream else
                                     ("NuboFaceDetector %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F) if trackers is None else
                                      "NuboFaceDetector + NuboTracker %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F))
@@ -591,8 +594,8 @@ def main():
                        "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
                        "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world, "ranks_seen": ranks_seen,
                        "batches_in_flight": 2 if pipelined else 1,
-                       "early_stage_order": ("cascade" if os.environ.get("NVCA_STAGE_ORDER") == "0" else
-                                             "adaptive (same survivors; secondary.stage_order has this cascade's figure in its own order)")},
+                       "cascade": ("calibrated: stage thresholds set on windows of this content, every early stage rejects about half of what reaches it"
+                                   if args.cascade == "calibrated" else "standin: rounds 1-3's thresholds from i.i.d. noise")},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

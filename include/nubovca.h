@@ -88,9 +88,11 @@ int  nvca_ctx_set_sum_policy(nvca_ctx *ctx, int policy);
 /* Measurement / bisecting switches, per context.  The process-wide defaults come from the environment
  * (NVCA_BAND, NVCA_TILES, ... read once, when the first context is created); this sets one for this context.  Names: "band"
  * (-1 / 0 / 1), "band_map", "tiles", "deep_stage", "deep_lds", "pyr_off", "host_group", "group_zerocopy", "sparse_ingest",
- * "ingest_chunk", "skip_cascade", "host_profile", "part_stats", "trk_order", "plan_debug", "quiet", "roi", "stage_fuse", "host_threads", "two_lanes".  None of them changes a
- * result.  Switches that shape plans drop the context's cached plans (not while a submitted batch is in flight). */
+ * "ingest_chunk", "skip_cascade", "host_profile", "part_stats", "trk_order", "plan_debug", "quiet", "roi", "host_threads", "two_lanes", "pre_cus".  None of them changes a
+ * result.  Switches that shape plans drop the context's cached plans (not while a submitted batch is in flight).
+ * nvca_ctx_get_option reads the value a switch holds for this context (so that a caller can put it back). */
 int  nvca_ctx_set_option(nvca_ctx *ctx, const char *name, int value);
+int  nvca_ctx_get_option(nvca_ctx *ctx, const char *name, int *value);
 /* block until everything queued on the context's HIP stream has finished */
 int  nvca_ctx_synchronize(nvca_ctx *ctx);
 /* the hipStream_t the context launches on (for interop / profiling) */

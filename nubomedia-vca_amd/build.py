@@ -14,13 +14,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libnubovca_hip.so")
+# NVCA_BUILD_VARIANT=name: a side build (own object directory, variants/name.so, extra flags from NVCA_BUILD_FLAGS) for A/B
+# runs through NVCA_LIB; the shipped library is never touched by it
+VARIANT = os.environ.get("NVCA_BUILD_VARIANT")
+OBJ = os.path.join(HERE, "build" if not VARIANT else "build_" + VARIANT)
+LIB = os.path.join(HERE, "libnubovca_hip.so") if not VARIANT else os.path.join(HERE, "variants", VARIANT + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
 if os.environ.get("NVCA_BUILD_STAMPS"):      # diagnostic build: in-kernel phase stamps (scripts/stamps.py); never the shipped library
     COMMON.append("-DNVCA_STAMPS")
+COMMON += os.environ.get("NVCA_BUILD_FLAGS", "").split()
 ARCH = ["--offload-arch=gfx950"]
 
 
@@ -33,6 +37,7 @@ def _newer(src, dst, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]

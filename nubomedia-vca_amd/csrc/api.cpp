@@ -212,8 +212,6 @@ static Switches read_switches()
     w.host_threads = num("NVCA_HOST_THREADS", -1);
     w.two_lanes = num("NVCA_TWO_LANES", 1) != 0;
     w.roi = num("NVCA_ROI", 1) != 0;
-    w.stage_fuse = num("NVCA_STAGE_FUSE", 0) != 0;
-    w.stage_order = num("NVCA_STAGE_ORDER", 1) != 0;
     w.pre_cus = num("NVCA_PRE_CUS", 0);
     w.quiet = set("NVCA_QUIET");
     w.stamps_out = getenv("NVCA_STAMPS_OUT");
@@ -317,7 +315,7 @@ struct GeomPlan {
 DetectPlan::~DetectPlan()
 {
     release_tables();
-    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_stage_hint.release(); d_blob.release();
+    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -335,7 +333,6 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
         {&d_deeprecs, deeprecs.data(), deeprecs.size() * sizeof(DeepRec)},
-        {&d_stage_hint, nullptr, tiles.empty() ? (size_t)0 : 8 * sizeof(int)},          // zero: nothing known yet
     };
     // one device allocation and one copy for all tables (a FIND_BIGGEST scan builds a plan per scale, per call)
     size_t total = 0;
@@ -547,7 +544,7 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
         a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
-        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_fuse = ctx->sw.stage_fuse ? 1 : 0; a.stage_order = ctx->sw.stage_order ? 1 : 0; a.stage_hint = dp.d_stage_hint.as<int>();
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
         a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
@@ -925,8 +922,6 @@ try {
     else if (n == "roi") w.roi = value != 0;
     else if (n == "two_lanes") w.two_lanes = value != 0;
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
-    else if (n == "stage_fuse") w.stage_fuse = value != 0;
-    else if (n == "stage_order") w.stage_order = value != 0;
     else if (n == "pre_cus") w.pre_cus = value > 0 ? value : 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
@@ -940,6 +935,37 @@ try {
         NVCA_HIP_CHECK(ctx, hipDeviceSynchronize());
         ctx->plans.clear();
     }
+    return NVCA_OK;
+}
+NVCA_API_CATCH(ctx)
+// the value a switch holds for this context right now (what the environment or an earlier nvca_ctx_set_option left)
+int nvca_ctx_get_option(nvca_ctx *ctx, const char *name, int *value)
+try {
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!name || !value) return NVCA_ERR_ARG;
+    const std::string n(name);
+    const Switches &w = ctx->sw;
+    if (n == "band") *value = w.band;
+    else if (n == "band_map") *value = w.band_map;
+    else if (n == "group_zerocopy") *value = w.group_zero_copy;
+    else if (n == "host_group") *value = w.host_group;
+    else if (n == "skip_cascade") *value = w.skip_cascade;
+    else if (n == "host_profile") *value = w.host_profile;
+    else if (n == "sparse_ingest") *value = w.sparse_ingest;
+    else if (n == "ingest_chunk") *value = w.ingest_chunk;
+    else if (n == "part_stats") *value = w.part_stats;
+    else if (n == "trk_order") *value = w.trk_order;
+    else if (n == "quiet") *value = w.quiet;
+    else if (n == "roi") *value = w.roi;
+    else if (n == "two_lanes") *value = w.two_lanes;
+    else if (n == "host_threads") *value = w.host_threads;
+    else if (n == "pre_cus") *value = w.pre_cus;
+    else if (n == "plan_debug") *value = w.plan_debug;
+    else if (n == "pyr_off") *value = w.pyr_off;
+    else if (n == "tiles") *value = w.tiles;
+    else if (n == "deep_stage") *value = w.deep_stage;
+    else if (n == "deep_lds") *value = w.deep_lds;
+    else { ctx->set_error("unknown option: " + n); return NVCA_ERR_ARG; }
     return NVCA_OK;
 }
 NVCA_API_CATCH(ctx)

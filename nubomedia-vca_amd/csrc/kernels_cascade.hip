@@ -571,38 +571,56 @@ __device__ __forceinline__ bool tile_stage_pass(unsigned cm, unsigned rm, double
     return !(sum < (double)st.thr);
 }
 
-// one stump (a per-lane record from the table) on one window: the integer vote (StageRec flag bit 2)
-template <bool PAIR>
-__device__ __forceinline__ int tile_vote_lane(unsigned cm, unsigned rm, double vnf, const TStumpRec &f)
+// ---- a stump per LANE: the compact record (LStumpRec) arrives as three 16-byte vector loads ------------------------------
+struct LRec { int4 a, b, c; };      // a: xx0 yy0 xx1 yy1 | b: xx2 yy2 w0 w1 | c: w2 thr a0 a1
+__device__ __forceinline__ LRec load_lrec(const LStumpRec *p)
 {
-    auto rs = [&](int q) {
-        const int c0 = lds_u16(cm + 2 * f.x0[q]), c1 = lds_u16(cm + 2 * f.x1[q]);
-        const int r0 = lds_u16(rm + 2 * f.y0[q]), r1 = lds_u16(rm + 2 * f.y1[q]);
-        return lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
-    };
-    const int s0 = rs(0), s1 = rs(1);
-    const double t = f.thr * vnf;
+    const int4 *q = (const int4 *)p;
+    LRec r; r.a = q[0]; r.b = q[1]; r.c = q[2];
+    return r;
+}
+// one rectangle through the tile's maps: xx / yy hold the two corner columns / rows as byte offsets into the u16 maps
+__device__ __forceinline__ int lane_rect(unsigned cm, unsigned rm, unsigned xx, unsigned yy)
+{
+    const int c0 = lds_u16(cm + (xx & 0xffffu)), c1 = lds_u16(cm + (xx >> 16));
+    const int r0 = lds_u16(rm + (yy & 0xffffu)), r1 = lds_u16(rm + (yy >> 16));
+    return lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
+}
+// the vote of the lane's stump on the lane's window: the file's float (a0 / a1), selected exactly as tile_vote_s selects it
+template <bool PAIR>
+__device__ __forceinline__ float lane_vote(unsigned cm, unsigned rm, double vnf, const LRec &f)
+{
+    const int s0 = lane_rect(cm, rm, (unsigned)f.a.x, (unsigned)f.a.y);
+    const int s1 = lane_rect(cm, rm, (unsigned)f.a.z, (unsigned)f.a.w);
+    const double t = (double)__int_as_float(f.c.y) * vnf;          // node->threshold * variance_norm_factor
+    const float w0 = __int_as_float(f.b.z), w1 = __int_as_float(f.b.w);
     double v;
-    if (PAIR) v = (double)((float)s0 * f.w[0] + (float)s1 * f.w[1]);
+    if (PAIR) v = (double)((float)s0 * w0 + (float)s1 * w1);
     else {
-        v = (double)((float)s0 * f.w[0]);
-        v += (double)((float)s1 * f.w[1]);
-        if ((f.nrect & 255) == 3) v += (double)((float)rs(2) * f.w[2]);
+        v = (double)((float)s0 * w0);
+        v += (double)((float)s1 * w1);
+        if (f.b.x | f.b.y) v += (double)((float)lane_rect(cm, rm, (unsigned)f.b.x, (unsigned)f.b.y) * __int_as_float(f.c.x));
     }
-    return v >= t ? f.a1i : f.a0i;
+    return __int_as_float(v >= t ? f.c.w : f.c.z);
 }
 
 #ifdef NVCA_STAMPS
 // diagnostic build: thread 0 of the first 64 workgroups leaves s_memtime stamps per tile and phase (64 words per tile, 16 tiles)
 #define NVCA_STAMP(a, tile, id) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) { unsigned long long t__; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = t__; } } while (0)
+#define NVCA_STAMP_VAL(a, tile, id, v) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = (unsigned long long)(v); } while (0)
 #else
 #define NVCA_STAMP(a, tile, id) do { } while (0)
+#define NVCA_STAMP_VAL(a, tile, id, v) do { } while (0)
 #endif
 
 // LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
 struct TileLds {
-    double *psum; unsigned short *q0, *winx, *winy; int *qn; double *vnf_s; unsigned *rej; int *carry;
+    double *vnf_s;                // [kTileSlots] variance normaliser per window
+    unsigned *xyw;                // [kTileSlots] window origin relative to the tile's: 2 xw | 2 yw << 16 (byte offsets into the maps)
+    unsigned short *wl;           // [waves][64] the windows a wave still carries (window id = ry * 32 + rx), compacted
+    unsigned short *winx, *winy;  // [kTileWin] each: window origins of the tile's columns / rows (k_tile)
+    int *scratch;                 // 16 words
     unsigned short *cmap, *rmap; int *T; int pitchT;
     int tword;                    // absolute LDS word address of T: the row map holds tword + r * pitchT
     unsigned cmA, rmA;            // LDS byte addresses of the maps
@@ -610,14 +628,12 @@ struct TileLds {
 __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec &t)
 {
     TileLds L;
-    L.psum = (double *)lds;
-    L.q0 = (unsigned short *)(lds + kTileSlots * 8);
-    L.winx = L.q0 + 2 * kTileSlots; L.winy = L.winx + kTileWin;
-    L.qn = (int *)(L.winy + kTileWin);                       // qn[0..2] rotating queue counters, qn[3] = list base
-    L.vnf_s = (double *)((unsigned char *)L.qn + 64);
-    L.rej = (unsigned *)(L.vnf_s + kTileSlots);
-    L.carry = (int *)(L.rej + kTileWin);
-    L.cmap = (unsigned short *)(L.carry + kTileWin);
+    L.vnf_s = (double *)lds;
+    L.xyw = (unsigned *)(L.vnf_s + kTileSlots);
+    L.wl = (unsigned short *)(L.xyw + kTileSlots);
+    L.winx = L.wl + (kTileThreads / 64) * 64; L.winy = L.winx + kTileWin;
+    L.scratch = (int *)(L.winy + kTileWin);
+    L.cmap = (unsigned short *)(L.scratch + 16);
     L.rmap = L.cmap + ((t.span_x + 3) & ~3);
     L.T = (int *)(L.rmap + ((t.span_y + 3) & ~3));
     L.pitchT = tile_pitch(t.ncol);
@@ -666,248 +682,125 @@ __device__ __forceinline__ void tile_commit(const CascadeArgs &a, const TileRec 
             if (k < nk && lane + 64 * k < t.ncol)
                 __builtin_amdgcn_global_load_lds((gptr_t)(rowp + c.xcb[k]), (lptr_t)(dst + 64 * k), 4, 0, 0);
     }
-    if (tid < 3) L.qn[tid] = 0;          // the three rotating queue counters (qn[3]: list base scratch)
     if (tid < t.nx) L.winx[tid] = (unsigned short)(c.wx - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(c.wy - t.y0);
     if (c.mapc >= 0) L.cmap[c.mapc - t.x0] = (unsigned short)(tid * 4);
     if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(L.tword + tid * L.pitchT);     // absolute word address of the row: a corner address is one shift-add
 }
 
-__device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
+// ---- the walk of a wave through the cascade -----------------------------------------------------------------------------
+// After stage 0 a wave carries k <= 64 windows of its own two window rows (compacted in L.wl, its 64-entry list) and takes them
+// through stages 1 .. last-1 BY ITSELF: no workgroup barrier, no shared queue -- the waves of a tile run independently (and
+// overlap each other's latencies) until the tile's samples are replaced.  Per stage, with G = 64 / k:
+//   G >= 2  lane l = (window j = l % k, stump group cc = l / k): step t evaluates stump t * G + cc of the stage on window j --
+//           G stumps of every window per step, records per lane (LStumpRec, three 16-byte loads from L1 / L2), k * G of the 64
+//           lanes busy whatever k is.  A lane keeps one window for the whole stage and sums its stumps' votes privately; the G
+//           partial sums of a window then meet in lane j over log2(G) cross-lane steps.  Exact: the stage's votes are integers
+//           of a common unit (StageRec flag bit 2: i32 sums) or at least sums that are exact in f64 in any order (flag bit 1).
+//   G == 1  (more than 32 windows: the first stages) a window per lane, the stage's stumps one after the other as wave-uniform
+//           records in scalar registers.  Also any stage whose votes may not be re-ordered (neither flag bit), in OpenCV's order.
+// The windows that pass are re-compacted in place (a lane reads its entry before any lane writes).  Whoever is left after
+// stage last-1 goes to the candidate list (the cascade ends here: the usual plan, every stage runs out of the tile) or to
+// the late-stage kernel's list (plans whose tiles cannot hold the late stages' samples).
+template <bool PAIR, class Sum>
+__device__ __forceinline__ bool walk_stage_lanes(const TileLds &L, unsigned short *wl, int k, int G, const LStumpRec *lrecs, const StageRec &st)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned long long km = __ballot(keep);
-    if (km) {
-        int wbase = 0;
-        if (lane == 0) wbase = atomicAdd(count, __popcll(km));
-        wbase = __shfl(wbase, 0);
-        if (keep) q[wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
+    const unsigned inv = 65535u / (unsigned)k + 1u;              // floor(l / k) = l * inv >> 16 for l < 64, k <= 64 (error < 64 / 65536 * k)
+    const int cc = (int)(((unsigned)lane * inv) >> 16), j = lane - cc * k;
+    const bool on = cc < G;
+    unsigned cm = L.cmA, rm = L.rmA; double vnf = 1.;
+    if (on) {
+        const int w = wl[j];
+        const unsigned xy = L.xyw[w];
+        cm += xy & 0xffffu; rm += xy >> 16;
+        vnf = L.vnf_s[w];
     }
+    Sum acc = 0;
+    const int C = st.count;
+    const LStumpRec *base = lrecs + st.first;
+    int c = cc;
+    LRec f;
+    if (on && c < C) f = load_lrec(base + c);
+    for (; __any(on && c < C); c += G) {
+        const bool act = on && c < C;
+        LRec fn = f;
+        if (on && c + G < C) fn = load_lrec(base + c + G);        // the next step's record is on its way under this step's LDS work
+        if (act) {
+            const float a = lane_vote<PAIR>(cm, rm, vnf, f);
+            if (sizeof(Sum) == sizeof(int)) acc += (Sum)(int)ldexpf(a, -st.vote_exp);       // exact: a is a multiple of 2^vote_exp below 2^31 of them
+            else acc += (Sum)(double)a;
+        }
+        f = fn;
+    }
+    for (int sft = 1; sft < G; sft <<= 1) {
+        const Sum o = __shfl(acc, lane + sft * k);
+        if (cc + sft < G) acc += o;
+    }
+    if (sizeof(Sum) == sizeof(int)) return (int)acc >= st.thr_i;
+    return !((double)acc < (double)st.thr);
 }
 
-// stages 1 .. last-1 on the windows queued in q0[0 .. qn[0]) (window id = ry * 32 + rx), then the survivors go to the
-// deep list / the candidates.  VNF_LDS: the variance normaliser comes from L.vnf_s (band kernel, which also has to
-// publish it for k_deep) instead of the stage-0 pre-pass's global array.  Ends with every thread past its last LDS use
-// of the queues only after the caller's next barrier.
-// Integer-vote stages (StageRec flag bit 2: every vote an exact multiple of 2^vote_exp, every sum below 2^31 of them -- proven
-// per stage in plan.cpp -- so any order and any grouping of the additions is bit for bit the f64 sum OpenCV forms).
-//   * The stage's work is the nw x C grid (64-window groups of the padded queue) x (stumps); it is dealt to the 16 waves
-//     as equal contiguous runs of (group, stump) items, whatever n and C are: no wave idles while another walks a longer
-//     partition (split-K by whole partitions left 4 of 16 waves idle at 374 windows, and ran 6 / 5 / 5 / 5 stumps at 21).
-//   * A wave adds its run's sum to the window's accumulator in LDS (ds_add: integer, hence exact in any order): no partial-sum
-//     table, no serial add-up by one thread.
-//   * (switch "stage_fuse", off by default: measured 2 % SLOWER on the headline workload -- the stump phases are bound by the LDS
-//     pipe, so the speculative evaluations cost more than the barrier they save)  Two consecutive such stages are evaluated in ONE pass (stage s + 1 speculatively for the windows that stage s will turn
-//     out to reject -- no side effects, the same pass / fail per stage) when the previous tile of the band saw at least 3/4 of
-//     stage s's windows survive it: the re-queue, its barrier and the wait for the slowest wave are paid once for both.
-//     Which stages are fused never changes a result.
-// acc: 2 ints per queue slot in the (otherwise partial-sum) region at the start of the tile's LDS, all zero outside a stage.
-// Survivor counts per stage live in two sets of kStatStages words behind the queue counters (qn[4 ..]): a tile reads the set
-// the previous tile of its band wrote (par) and writes the other one, which the band kernel zeroes at the top of the tile --
-// every wave therefore takes the same fusion decisions from words nobody writes during the tile.
-static constexpr int kStatStages = 6;         // stages 0 .. 5: the early stages of the default split (deep_stage 6)
-template <bool VNF_LDS>
-__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0, int par = 0)
+template <bool VNF_OUT>
+__device__ __forceinline__ void wave_walk(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int k, int ti = 0)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int *stat_r = L.qn + 4 + par * kStatStages;       // what the previous tile saw
-    int *stat_w = L.qn + 4 + (par ^ 1) * kStatStages;       // what this tile sees
-    constexpr int NW = kTileThreads / 64;
-    const TStumpRec *urecs = sc.trecs;
-    const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
-    const double *__restrict__ vnfp = a.vnf + vbase;
-    auto vnf_of = [&](int w) {
-        if (VNF_LDS) return L.vnf_s[w];
-        const int ix = t.ix0 + (w & 31);
-        return vnfp[((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
-    };
-    int *acc = (int *)L.psum;
-    int cur = 0;
-    // queue counters rotate over three words: a stage reads qn[cin], appends to qn[cout] and clears the third one, which
-    // nobody touches during this stage and which the next stage appends to -- one barrier per stage instead of two
-    int cin = 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned short *wl = L.wl + wave * 64;
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    // The early stages 1 .. m may be walked in any order: a window goes on iff it passes all of them, and which of them it
-    // fails first changes nothing anyone sees.  The band kernel walks them in the order the PREVIOUS tile of its band found
-    // cheapest -- stump count per window killed, from that tile's entered / passed counts per stage (stat words: entered << 16 |
-    // passed; word 0: the order for this tile, 4 bits a position, written by thread 0 at the end of the previous tile; 0 =
-    // nothing known, the cascade's own order).  A stage that lets nearly everything through is then met by the few windows the
-    // selective ones leave.  Switch "stage_order"; never together with stage fusion.
-    const int m = last - 1;
-    const bool adapt = a.stage_order && !a.stage_fuse && m >= 2 && m < kStatStages;
-    unsigned ordpack = 0x54321u;
-    if (adapt) {
-        // (the word may come from the plan's hint words, which other workgroups write as they go: it is used only if its first m
-        // positions name each of the stages 1 .. m once)
-        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(stat_r[0]);
-        unsigned seen = 0;
-        for (int q = 0; q < m; q++) seen |= 1u << ((o >> (4 * q)) & 15u);
-        if (seen == (2u << m) - 2u) ordpack = o;
-    }
-    int s = adapt ? (int)(ordpack & 15u) : 1;
-    int kpos = 0, prev = 0; unsigned entered = 0;          // wave-uniform
-    while (adapt ? kpos < m : s < last) {
-        __syncthreads();             // queue complete (first pass: tile and maps staged as well)
-        NVCA_STAMP(a, ti, 8 + 8 * s);
-        const int n = L.qn[cin];
-        if (adapt && tid == 0 && prev) stat_w[prev] |= n;        // what the stage before let through
-        if (n == 0) break;
-#ifdef NVCA_STAMPS
-        if (threadIdx.x == 0 && blockIdx.x < 64 && ti < 16 && a.dbg) a.dbg[((size_t)blockIdx.x * 16 + ti) * 64 + 8 + 8 * s + 7] = (unsigned long long)n;
-#endif
-        const int cout = cin == 2 ? 0 : cin + 1;
-        if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
-        const unsigned short *qi = L.q0 + cur * kTileSlots;
-        unsigned short *qo = L.q0 + (cur ^ 1) * kTileSlots;
+    k = __builtin_amdgcn_readfirstlane(k);
+    for (int s = 1; s < last && k > 0; s++) {
+        NVCA_STAMP(a, ti, 8 + 2 * s); NVCA_STAMP_VAL(a, ti, 9 + 2 * s, k);
         const StageRec st = load_const(a.stages + s);
         const bool pair = a.pair_policy && (st.flags & 1);
-        int adv = 1;
-        if ((st.flags & 4) && n <= NW) {
-            // ---- a handful of windows left (the usual state of the last early stage: one or two windows a tile): a wave per
-            // window, a stump per lane -- the stage is one step for every wave instead of a chain of stumps walked by a lane or
-            // two of each wave.  Records come per lane from the table (L2), votes are integers: the wave's sum is exact.
-            if (wave < n) {
-                const int w = qi[wave];
-                const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
-                const double vnf = vnf_of(w);
-                const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
-                int sum = 0;
-                for (int j = lane; j < st.count; j += 64) {
-                    const TStumpRec f = urecs[st.first + j];
-                    sum += pair ? tile_vote_lane<true>(cm, rm, vnf, f) : tile_vote_lane<false>(cm, rm, vnf, f);
-                }
-                for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-                if (lane == 0 && sum >= st.thr_i) qo[atomicAdd(&L.qn[cout], 1)] = (unsigned short)w;
-            }
-            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
-            NVCA_STAMP(a, ti, 8 + 8 * s + 1); NVCA_STAMP(a, ti, 8 + 8 * s + 2); NVCA_STAMP(a, ti, 8 + 8 * s + 3);
-        } else if (st.flags & 4) {
-            // ---- integer votes: balanced runs over (window group, stump), LDS accumulators, optional fusion with stage s + 1
-            bool fuse = false;
-            int first2 = 0, count2 = 0, thr2 = 0; bool pair2 = false;
-            if (s + 1 < last && s + 1 < kStatStages) {
-                const int seen_s = stat_r[s], seen_n = stat_r[s + 1];          // 0: no tile yet
-                if (a.stage_fuse && seen_s > 0 && 4 * seen_n >= 3 * seen_s) {
-                    const StageRec st2 = load_const(a.stages + s + 1);
-                    fuse = (st2.flags & 4) != 0;
-                    first2 = st2.first; count2 = st2.count; thr2 = st2.thr_i; pair2 = a.pair_policy && (st2.flags & 1);
-                }
-            }
-            const int Ca = st.count, C = fuse ? Ca + count2 : Ca;
-            const int nw = (n + 63) >> 6, items = nw * C, K = (items + NW - 1) / NW;
-            int e = wave * K;
-            const int e1 = e + K < items ? e + K : items;
-            while (e < e1) {                       // at most two window groups per wave (K <= C), wave-uniform
-                const int wg = e / C, c0 = e - wg * C, c1 = (C - c0 < e1 - e) ? C : c0 + (e1 - e);
-                const int i = wg * 64 + lane;
-                if (i < n) {
-                    const int w = qi[i];
-                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
-                    const double vnf = vnf_of(w);
-                    const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
-                    if (c0 < Ca) {
-                        const int hi = c1 < Ca ? c1 : Ca;
-                        const int v = pair ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + st.first, c0, hi, 1) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + st.first, c0, hi, 1);
-                        atomicAdd(&acc[2 * i], v);
-                    }
-                    if (c1 > Ca) {
-                        const int lo = c0 > Ca ? c0 - Ca : 0;
-                        const int v = pair2 ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + first2, lo, c1 - Ca, 1) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + first2, lo, c1 - Ca, 1);
-                        atomicAdd(&acc[2 * i + 1], v);
-                    }
-                }
-                e += c1 - c0;
-            }
-            NVCA_STAMP(a, ti, 8 + 8 * s + 1);
-            __syncthreads();
-            NVCA_STAMP(a, ti, 8 + 8 * s + 2);
-            bool pass = false, pass_a = false; int w = 0;
-            if (tid < n) {
-                const int sa = acc[2 * tid], sb = acc[2 * tid + 1];
-                acc[2 * tid] = 0; acc[2 * tid + 1] = 0;
-                pass_a = sa >= st.thr_i;
-                pass = pass_a && (!fuse || sb >= thr2);
-                w = qi[tid];
-            }
-            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
-            if (fuse && s + 1 < kStatStages) {     // stage s + 1 has no queue of its own this time: count who would have entered it
-                const unsigned long long am = __ballot(pass_a);
-                if (lane == 0 && am) atomicAdd(&stat_w[s + 1], (int)__popcll(am));
-            }
-            queue_push(pass, w, qo, &L.qn[cout]);
-            if (fuse) adv = 2;
-            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
+        const int G = 64 / k;
+        bool pass;
+        if (G >= 2 && (st.flags & 6)) {
+            if (st.flags & 4) pass = pair ? walk_stage_lanes<true, int>(L, wl, k, G, sc.lrecs, st) : walk_stage_lanes<false, int>(L, wl, k, G, sc.lrecs, st);
+            else pass = pair ? walk_stage_lanes<true, double>(L, wl, k, G, sc.lrecs, st) : walk_stage_lanes<false, double>(L, wl, k, G, sc.lrecs, st);
         } else {
-            // votes that are not exact integers of a common unit (StageRec flag bit 2 clear: not seen with f32 votes below 128
-            // stumps a stage): window per thread, the stage's stumps in OpenCV's order
-            for (int base = 0; base < n; base += kTileThreads) {
-                const int i = base + tid;
-                bool pass = false; int w = 0;
-                if (i < n) {
-                    w = qi[i];
-                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
-                    const double vnf = vnf_of(w);
-                    pass = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, urecs, st, pair);
-                }
-                queue_push(pass, w, qo, &L.qn[cout]);
+            pass = false;
+            if (lane < k) {
+                const int w = wl[lane];
+                const unsigned xy = L.xyw[w];
+                pass = tile_stage_pass(L.cmA + (xy & 0xffffu), L.rmA + (xy >> 16), L.vnf_s[w], sc.trecs, st, pair);
             }
-            if (tid == 0 && s < kStatStages) stat_w[s] = adapt ? n << 16 : n;
         }
-        cur ^= 1; cin = cout;
-        if (adapt) { prev = s; entered |= 1u << s; kpos++; s = (int)((ordpack >> (4 * kpos)) & 15u); }
-        else s += adv;
+        // survivors move to the front of the list: every lane reads its entry before any lane writes
+        const int mine = lane < k ? (int)wl[lane] : 0;
+        const unsigned long long pm = __ballot(lane < k && pass);
+        asm volatile("" ::: "memory");
+        if (lane < k && pass) wl[__popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)mine;
+        asm volatile("" ::: "memory");
+        k = __popcll(pm);
     }
-    __syncthreads();
     NVCA_STAMP(a, ti, 6);
-    const int nh = L.qn[cin];
-    if (adapt && tid == 0) {
-        if (prev && kpos >= m) stat_w[prev] |= nh;           // the walk reached its end: the last stage's survivors
-        // the order for the next tile.  A stage this tile did not reach, or met with a handful of windows only, keeps what was
-        // known about it; cost of a stage = its stumps per window killed (x 64: integer arithmetic)
-        int key[kStatStages - 1], id[kStatStages - 1];
-        bool known = true;
-#pragma unroll
-        for (int q = 1; q < kStatStages; q++) {
-            int v = stat_w[q];
-            const int old = stat_r[q];
-            if (q <= m && (!((entered >> q) & 1u) || ((v >> 16) < 16 && old != 0))) { v = old; stat_w[q] = v; }
-            const int ent = v >> 16, pas = v & 0xffff, cnt = L.carry[kTileRows + q];
-            if (q <= m && ent == 0) known = false;
-            const int killed = ent - pas > 0 ? ent - pas : 0;
-            key[q - 1] = q > m ? 0x7fffffff : (killed ? (cnt * ent * 64) / killed : 0x7ffffff0);
-            id[q - 1] = q;
-        }
-#pragma unroll
-        for (int pass_i = 0; pass_i < kStatStages - 2; pass_i++)
-#pragma unroll
-            for (int q = 0; q + 1 < kStatStages - 1 - pass_i; q++)
-                if (key[q] > key[q + 1]) { const int tk = key[q]; key[q] = key[q + 1]; key[q + 1] = tk; const int ti2 = id[q]; id[q] = id[q + 1]; id[q + 1] = ti2; }
-        unsigned pack = 0;
-#pragma unroll
-        for (int q = 0; q < kStatStages - 1; q++) pack |= (unsigned)id[q] << (4 * q);
-        stat_w[0] = known ? (int)pack : 0;
-        if (known && a.stage_hint) {            // plain stores: any mixture of finished tiles' words is a usable start
-#pragma unroll
-            for (int q = 1; q < kStatStages; q++) a.stage_hint[q] = stat_w[q];
-            a.stage_hint[0] = (int)pack;
-        }
-    }
-    if (nh == 0) return;
+    if (k == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
-    if (tid == 0) L.qn[3] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
-    __syncthreads();
-    const unsigned gb = (unsigned)L.qn[3];
-    const unsigned short *qi = L.q0 + cur * kTileSlots;
-    for (int i = tid; i < nh; i += kTileThreads) {
-        const int w = qi[i], ix = t.ix0 + (w & 31);
+    unsigned gb = 0;
+    if (lane == 0) gb = (unsigned)atomicAdd(list, (unsigned long long)k);
+    gb = (unsigned)__shfl((int)gb, 0);
+    if (lane < k) {
+        const int w = wl[lane], ix = t.ix0 + (w & 31);
         const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)ix;
-        if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
-        if (VNF_LDS && last != a.nstages) a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
+        if (gb + lane < cap) list[1 + gb + lane] = ((unsigned long long)slot << 32) | key;
+        if (VNF_OUT && last != a.nstages) {
+            const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
+            a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
+        }
     }
-    NVCA_STAMP(a, ti, 7);
+}
+
+// the windows a wave keeps after stage 0 (keep: this lane's window is visited and passed) -> its list; returns their number
+__device__ __forceinline__ int wave_list(const TileLds &L, bool keep, int w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long km = __ballot(keep);
+    if (keep) L.wl[wave * 64 + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
+    asm volatile("" ::: "memory");
+    return __popcll(km);
 }
 
 __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(CascadeArgs a)
@@ -922,31 +815,31 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileLds L = carve_tile(lds, t);
     const TileCoords tc = tile_coords(a, t, sc);
     tile_commit(a, t, sc, slot, L, tc);
-    { int *acc = (int *)L.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;                                                       // stage accumulators
-      if (tid < 2 * kStatStages) L.qn[4 + tid] = (tid < kStatStages && a.stage_hint) ? a.stage_hint[tid] : 0;                   // no band history: what the plan's tiles last left
-      if (tid >= kTileRows && tid < kTileWin) L.carry[tid] = tid - kTileRows < a.nstages ? a.stages[tid - kTileRows].count : 0; }  // stumps per stage (tile_stages' stage order)
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
-    __syncthreads();                 // qn zeroed, maps and samples staged
-    // adaptive-step reachability + compaction of the visited stage-0 survivors (window id = ry * 32 + rx)
-    for (int base = 0; base < t.ny * kTileWin; base += kTileThreads) {
-        const int w = base + tid, ry = w >> 5, rx = w & 31;
-        bool keep = false;
-        if (ry < t.ny && rx < t.nx) {
-            const int ix = t.ix0 + rx;
-            const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
-            if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
-        }
-        queue_push(keep, w, L.q0, &L.qn[0]);
+    // this thread's window (window id = ry * 32 + rx = tid: a wave holds two window rows): the pre-pass's verdict on it and its
+    // normaliser, under the tile's transfers
+    const int w = tid, ry = w >> 5, rx = w & 31;
+    bool keep = false; double vnf = 1.;
+    if (ry < t.ny && rx < t.nx) {
+        const int ix = t.ix0 + rx;
+        const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
+        if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
+        if (keep) vnf = a.vnf[(((size_t)slot * a.ntasks + sc.task_off + (size_t)(t.iy0 + ry) * sc.wpr) + (ix >> 6)) * 64 + (ix & 63)];
     }
-    tile_stages<false>(a, t, sc, slot, L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
+    __syncthreads();                 // maps, origins and samples staged
+    if (keep) { L.xyw[w] = 2u * L.winx[rx] | (2u * L.winy[ry]) << 16; L.vnf_s[w] = vnf; }
+    const int k = wave_list(L, keep, w);
+    wave_walk<false>(a, t, sc, slot, L, k);
 }
 
 // ---- K5: the whole early cascade of a band of window rows in one workgroup ---------------------------------------
 // The workgroup walks the band's tiles left to right.  Per tile: stage the samples, evaluate the window variance and
 // stage 0 for every window from LDS (only the squared-integral corners are global reads), resolve the adaptive x step
-// from the tile's reject bits plus the parity of the reject run carried over from the tiles to the left, then run the
-// later stages as k_tile does.  No stage-0 pre-pass, no per-window global intermediates.
+// inside the wave -- a wave holds two whole window rows of the tile, so the reject bits it needs are its own ballot, and the
+// parity of the reject run that reaches the tile's left edge is carried from tile to tile in a register -- then every wave
+// takes its windows through the remaining stages on its own (wave_walk).  Two workgroup barriers per tile: before the tile's
+// samples are replaced and after they have landed.  No stage-0 pre-pass, no per-window global intermediates.
 __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(CascadeArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -969,15 +862,9 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     const int ex0 = sc.eq[0] % sc.pitch, ey0 = sc.eq[0] / sc.pitch, ex1 = sc.eq[3] % sc.pitch, ey1 = sc.eq[3] / sc.pitch;
     const StageRec st0 = load_const(a.stages);
     const bool pair0 = a.pair_policy && (st0.flags & 1);
-    {   // carried parity lives at a fixed place: the carve-up's fixed part does not depend on the tile
-        const TileRec t0 = load_const(a.tiles + b.first_tile);
-        const TileLds L0 = carve_tile(lds, t0);
-        if (tid < kTileWin) L0.carry[tid] = (tid >= kTileRows && tid - kTileRows < a.nstages) ? a.stages[tid - kTileRows].count : 0;      // rows 0 .. 23: the carried parities; behind them: stumps per stage (tile_stages' stage order)
-        int *acc = (int *)L0.psum; acc[tid] = 0; acc[tid + kTileThreads] = 0;          // stage accumulators (tile_stages)
-        if (tid < 2 * kStatStages) L0.qn[4 + tid] = (tid < kStatStages && a.stage_hint) ? a.stage_hint[tid] : 0;      // no tile of this band seen yet: what the plan's tiles last left
-    }
     static_assert(kTileSlots == kTileThreads, "one window per thread and tile");
     const int w = tid, ry = w >> 5, rx = w & 31;          // this thread's window in every tile of the band
+    unsigned carry = 0;                                    // wave-uniform: parity of the stage-0 reject run that ends at the previous tile's right edge, bit 0 / 1: the wave's first / second row
     // The coordinates of a tile (its record, this thread's list entries and window origin) are requested one tile ahead, right
     // behind the previous tile's sample transfers: their round trip passes under those transfers instead of standing at the
     // head of every tile (768 threads leave the registers for it)
@@ -986,7 +873,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     int oxw = 0, oyw = 0;
     if (ry < t.ny && rx < t.nx) { oxw = a.pos[sc.xpos_off + t.ix0 + rx]; oyw = a.pos[sc.ypos_off + t.iy0 + ry]; }
     for (int ti = 0; ti < b.ntiles; ti++) {
-        __syncthreads();             // previous tile completely done with LDS
+        __syncthreads();             // every wave is done with the previous tile's LDS
         NVCA_STAMP(a, ti, 0);
         const TileLds L = carve_tile(lds, t);
         // this thread's window: the four (eight) squared-integral corners -- uncoalesced global reads -- are requested before the
@@ -1003,7 +890,6 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         }
         NVCA_STAMP(a, ti, 1);
         tile_commit(a, t, sc, slot, L, tc);
-        if (tid < kStatStages) L.qn[4 + ((ti + 1) & 1) * kStatStages + tid] = 0;       // the survivor counts this tile will write
         TileRec tn = t; TileCoords tcn = tc; int nxw = 0, nyw = 0;
         if (ti + 1 < b.ntiles) {                                 // the next tile's coordinates
             tn = load_const(a.tiles + b.first_tile + ti + 1);
@@ -1015,60 +901,59 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         __syncthreads();
         NVCA_STAMP(a, ti, 3);
         // variance + stage 0 for every window of the tile; a wave covers two window rows
-        {
-            bool pass0 = false;
-            if (active) {
-                const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
-                const int ws = lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
-                const double mean = (double)ws * sc.inv_area;
-                // squared-pixel sum of the variance window: exact integers below 2^53 (see window_sqsum)
-                double vnf;
-                if (sq_lo_only) vnf = (double)(unsigned)(q0 - q1 - q2 + q3);
-                else vnf = (double)(((unsigned long long)h0 << 32) | q0) - (double)(((unsigned long long)h1 << 32) | q1) -
-                           (double)(((unsigned long long)h2 << 32) | q2) + (double)(((unsigned long long)h3 << 32) | q3);
-                vnf = vnf * sc.inv_area - mean * mean;
-                vnf = vnf >= 0. ? sqrt(vnf) : 1.;
-                L.vnf_s[w] = vnf;
-                pass0 = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, sc.trecs, st0, pair0);
-            }
-            const unsigned long long fb = __ballot(active && !pass0);
-            if (lane == 0 && ry < t.ny) L.rej[ry] = (unsigned)fb;
-            if (lane == 32 && ry < t.ny) L.rej[ry] = (unsigned)(fb >> 32);
+        bool pass0 = false;
+        if (active) {
+            const int c0 = L.cmap[xw + ex0], c1 = L.cmap[xw + ex1], r0 = L.rmap[yw + ey0], r1 = L.rmap[yw + ey1];
+            const int ws = lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
+            const double mean = (double)ws * sc.inv_area;
+            // squared-pixel sum of the variance window: exact integers below 2^53 (see window_sqsum)
+            double vnf;
+            if (sq_lo_only) vnf = (double)(unsigned)(q0 - q1 - q2 + q3);
+            else vnf = (double)(((unsigned long long)h0 << 32) | q0) - (double)(((unsigned long long)h1 << 32) | q1) -
+                       (double)(((unsigned long long)h2 << 32) | q2) + (double)(((unsigned long long)h3 << 32) | q3);
+            vnf = vnf * sc.inv_area - mean * mean;
+            vnf = vnf >= 0. ? sqrt(vnf) : 1.;
+            L.vnf_s[w] = vnf;
+            L.xyw[w] = 2u * (unsigned)xw | (2u * (unsigned)yw) << 16;
+            pass0 = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, sc.trecs, st0, pair0);
         }
-        __syncthreads();
-        NVCA_STAMP(a, ti, 4);
         // OpenCV's adaptive x step: a window is visited iff the run of stage-0 rejects immediately left of it in its
-        // row has even length; a run that reaches the tile's left edge continues with the carried parity
-        {
-            bool keep = false;
-            if (active) {
-                const unsigned R = L.rej[ry];
-                if (!((R >> rx) & 1u)) {
-                    if (!sc.adaptive) keep = true;
-                    else {
-                        int ones = 0;
-                        if (rx > 0) {
-                            const unsigned m = ~(R << (32 - rx));                 // window rx-1 at the MSB, rejects are 0 now
-                            ones = m ? __clz((int)m) : 32;
-                            if (ones > rx) ones = rx;
-                        }
-                        const int parity = ones == rx ? ((rx + L.carry[ry]) & 1) : (ones & 1);
-                        keep = !parity;
-                    }
+        // row has even length; a run that reaches the tile's left edge continues with the carried parity.  The wave's own
+        // ballot holds the reject bits of its two rows.
+        const unsigned long long fb = __ballot(active && !pass0);
+        const unsigned R = lane < 32 ? (unsigned)fb : (unsigned)(fb >> 32);
+        bool keep = false;
+        if (active && !((R >> rx) & 1u)) {
+            if (!sc.adaptive) keep = true;
+            else {
+                int ones = 0;
+                if (rx > 0) {
+                    const unsigned m = ~(R << (32 - rx));                 // window rx-1 at the MSB, rejects are 0 now
+                    ones = m ? __clz((int)m) : 32;
+                    if (ones > rx) ones = rx;
                 }
+                const int cbit = (int)((carry >> (lane >> 5)) & 1u);
+                const int parity = ones == rx ? ((rx + cbit) & 1) : (ones & 1);
+                keep = !parity;
             }
-            queue_push(keep, w, L.q0, &L.qn[0]);
         }
-        __syncthreads();
-        if (tid < t.ny) {            // parity of the reject run that ends at this tile's right edge
-            const unsigned R = L.rej[tid];
-            const unsigned m = ~(R << (32 - t.nx));
-            int ones = m ? __clz((int)m) : 32;
-            if (ones > t.nx) ones = t.nx;
-            L.carry[tid] = ones == t.nx ? ((t.nx + L.carry[tid]) & 1) : (ones & 1);
+        {   // parity of the reject run that ends at this tile's right edge, for both rows of the wave
+            unsigned nc = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned Rh = h ? (unsigned)(fb >> 32) : (unsigned)fb;
+                const unsigned m = ~(Rh << (32 - t.nx));
+                int ones = m ? __clz((int)m) : 32;
+                if (ones > t.nx) ones = t.nx;
+                const unsigned p = ones == t.nx ? ((unsigned)t.nx + ((carry >> h) & 1u)) & 1u : (unsigned)ones & 1u;
+                nc |= p << h;
+            }
+            carry = (unsigned)__builtin_amdgcn_readfirstlane((int)nc);
         }
-        NVCA_STAMP(a, ti, 5);
-        tile_stages<true>(a, t, sc, slot, L, ti, ti & 1);
+        const int k = wave_list(L, keep, w);
+        NVCA_STAMP(a, ti, 4); NVCA_STAMP_VAL(a, ti, 5, k);
+        wave_walk<true>(a, t, sc, slot, L, k, ti);
+        NVCA_STAMP(a, ti, 7);
         t = tn; tc = tcn; oxw = nxw; oyw = nyw;
     }
 }

@@ -72,7 +72,7 @@ struct ScaleRec {           // one evaluated scale
     double factor;
     const struct TStumpRec *trecs;   // the cascade's stumps at this scale's factor (device; shared by every plan that uses the factor)
     const struct GNodeRec *grecs;    // general cascades (tree weak classifiers / tilted features): every node at this scale's factor
-    long long pad_g;
+    const struct LStumpRec *lrecs;   // the same stumps as trecs in the compact per-lane form (tile kernels: a stump per lane)
 };
 
 // A node of a weak classifier in its general form: up to three rectangles, upright (corners of the integral image) or
@@ -112,6 +112,16 @@ struct TStumpRec {          // a stump with separate corner columns / rows (wind
                             // 96 bytes: the tile kernels fetch a record with two wide scalar loads (16 + 8 dwords)
 };
 static_assert(sizeof(TStumpRec) == 96, "TStumpRec layout is read dword by dword in kernels_cascade.hip");
+// The same stump in 48 bytes, for lanes that each evaluate a DIFFERENT stump (the tile kernels once few windows of a wave are
+// left: lane = (window, stump) pair): three 16-byte vector loads per lane instead of a record held in scalar registers.
+// Corner coordinates are window-relative pixels TIMES TWO (byte offsets into the tile's u16 maps), low half = first corner;
+// rectangle 2 is absent iff both its words are zero.  Threshold and votes are the file's floats (the kernels widen them
+// exactly); a stage's stumps are in the order of the TStumpRec table.
+struct alignas(16) LStumpRec {
+    unsigned xx0, yy0, xx1, yy1, xx2, yy2;      // per rectangle: xx = 2 x0 | 2 x1 << 16, yy = 2 y0 | 2 y1 << 16
+    float w0, w1, w2, thr, a0, a1;
+};
+static_assert(sizeof(LStumpRec) == 48, "LStumpRec is read as three int4 in kernels_cascade.hip");
 // A band is one row of tiles (<= 32 window rows of one scale, the full scan width): k_band walks it left to right in one
 // workgroup, so stage 0 and OpenCV's adaptive x step (which depends on the stage-0 results to the left) need no pre-pass.
 // Per scale: the distinct corner columns / rows (window-relative pixels) of the late stages' stumps.  k_deep stages that
@@ -130,11 +140,11 @@ static constexpr int kTileLdsBudget = 76 * 1024;   // two tiles resident per CU 
 static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
 // LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
 __host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
-// fixed part: split-K partial sums | two window queues | window origins | counters | per-window variance normaliser
-// (band kernel) | per-row stage-0 reject words and carried run parity (band kernel)
+// fixed part (carve_tile in kernels_cascade.hip): per-window variance normaliser f64 | per-window map offsets u32 | one window list
+// of 64 u16 per wave | window origins u16 (k_tile) | scratch
 __host__ __device__ inline int tile_lds_fixed()
 {
-    return kTileSlots * 8 + 2 * kTileSlots * 2 + 4 * kTileWin + 64 + kTileSlots * 8 + 8 * kTileWin;
+    return kTileSlots * 8 + kTileSlots * 4 + (kTileThreads / 64) * 64 * 2 + 4 * kTileWin + 64;
 }
 __host__ __device__ inline int tile_lds_bytes(int ncol, int nrow, int span_x, int span_y)
 {
@@ -178,8 +188,6 @@ struct Switches {
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
-    bool stage_order = true;         // NVCA_STAGE_ORDER=0: k_band walks the early stages 1 .. deep_stage-1 in the cascade's order on every tile (1: in the order the previous tile of the band found cheapest -- cost per window killed; the set of survivors is the same)
-    bool stage_fuse = false;         // NVCA_STAGE_FUSE=1: k_band / k_tile evaluate two integer-vote stages in one pass where the previous tile saw >= 3/4 survive (measured slower: DESIGN 6)
     int  pre_cus = 0;                // NVCA_PRE_CUS=n: a submitted face batch's pre-processing runs on a stream confined to n CUs (hipExtStreamCreateWithCUMask), beside the other batch's band kernel (0: behind it, on the lane's own stream)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
     const char *stamps_out = nullptr;   // NVCA_STAMPS_OUT (diagnostic build only)
@@ -446,10 +454,7 @@ struct CascadeArgs {
     unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
-    int stage_fuse;                // Switches::stage_fuse
-    int stage_order;               // Switches::stage_order
-    int *stage_hint;               // [8] per plan: the stat words (order | entered << 16 | passed per stage) the last tile that finished left -- where a band's first tile and the per-tile kernel start from
-    int deep_stage;                // first stage evaluated by k_deep
+    int deep_stage;                // first stage evaluated by k_deep (== nstages: the tile kernels walk the whole cascade, k_deep is not launched)
     int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key
     unsigned deep_cap;

@@ -159,6 +159,19 @@ void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
             if (r.x0[q] == r.x0[0] && r.x1[q] == r.x1[0]) r.nrect |= 512 << (2 * (q - 1));
         }
     }
+    // the compact per-lane form of the same records (kernels_cascade.hip, lane_vote): coordinates as byte offsets into u16 maps
+    t.lhost.assign(t.host.size(), LStumpRec());
+    for (size_t i = 0; i < t.host.size(); i++) {
+        const TStumpRec &r = t.host[i];
+        LStumpRec &l = t.lhost[i];
+        memset(&l, 0, sizeof(l));
+        auto pk = [](int a, int b) { return (unsigned)(2 * a) | (unsigned)(2 * b) << 16; };
+        l.xx0 = pk(r.x0[0], r.x1[0]); l.yy0 = pk(r.y0[0], r.y1[0]);
+        l.xx1 = pk(r.x0[1], r.x1[1]); l.yy1 = pk(r.y0[1], r.y1[1]);
+        if ((r.nrect & 255) == 3) { l.xx2 = pk(r.x0[2], r.x1[2]); l.yy2 = pk(r.y0[2], r.y1[2]); }
+        l.w0 = r.w[0]; l.w1 = r.w[1]; l.w2 = (r.nrect & 255) == 3 ? r.w[2] : 0.f;
+        l.thr = (float)r.thr; l.a0 = (float)r.a0; l.a1 = (float)r.a1;       // all three came from floats: the round trip is exact
+    }
     // integer votes of the stages whose sums are provably exact as 32-bit integers (StageRec flag bit 2)
     std::vector<StageRec> st;
     build_stage_recs(c, st);
@@ -254,11 +267,29 @@ nvca_rect DetectPlan::hit_rect(unsigned key) const
 
 int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&in, bool allow_tiles, std::string &err)
 {
-    generic = c.generic(); needs_tilted = c.has_tilted; generic_stumps = c.stump_based;
     specs = std::move(in);
+    const int ns = (int)c.stages.size();
+    if (ctx->sw.deep_stage > 0) { deep_stage = ctx->sw.deep_stage; return build_tables(ctx, c, allow_tiles, err); }
+    if (!ctx->sw.tiles || c.generic()) { deep_stage = 6; return build_tables(ctx, c, allow_tiles, err); }      // row strips / the general evaluator: no tiles to walk
+    // By default the tile kernels walk the WHOLE cascade (deep_stage == number of stages, no late-stage kernel): the corner offsets of
+    // all stages fall on the same near-lattice as those of the first six, so a tile that holds them is a few per cent larger
+    // (1080p, 22 stages: 56 KB instead of 53).  A cascade whose late stages do not fit -- a scale left without tiles, or tiles
+    // squeezed below 20 windows a side -- keeps the split: early stages on tiles, the rest in k_deep.
+    deep_stage = ns;
+    int rc = build_tables(ctx, c, allow_tiles, err);
+    if (rc == NVCA_OK && !generic && ctx->sw.tiles && ns > 6 && (!strips.empty() || (min_tile_side > 0 && min_tile_side < std::min(max_tile_side, 20)))) {
+        deep_stage = 6;
+        rc = build_tables(ctx, c, allow_tiles, err);
+    }
+    return rc;
+}
+
+int DetectPlan::build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, std::string &err)
+{
+    generic = c.generic(); needs_tilted = c.has_tilted; generic_stumps = c.stump_based;
     nstumps = (int)c.cls.size();
     scales.clear(); strips.clear(); pos.clear(); tasks.clear(); tiles.clear(); release_tables();
-    if (ctx->sw.deep_stage > 0) deep_stage = ctx->sw.deep_stage;
+    min_tile_side = 0; max_tile_side = 0;
     // stages 1 .. deep_stage-1 run on LDS lattice tiles (k_tile); NVCA_TILES=0 selects the older row strips (k_strip)
     bool use_tiles = ctx->sw.tiles;
     if (generic) use_tiles = false;              // the LDS tile kernels are built around upright stumps
@@ -294,6 +325,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
         sr.eq[0] = tabp->ey * pitch + tabp->ex;               sr.eq[1] = tabp->ey * pitch + tabp->ex + tabp->ew;
         sr.eq[2] = (tabp->ey + tabp->eh) * pitch + tabp->ex;  sr.eq[3] = (tabp->ey + tabp->eh) * pitch + tabp->ex + tabp->ew;
         sr.trecs = tabp->dev.as<TStumpRec>();
+        sr.lrecs = tabp->d_lrecs;
         sr.grecs = tabp->d_grecs;
         if (generic) {
             // every corner of every node must stay inside the planes for every window of the grid (a faulting read takes the
@@ -359,6 +391,7 @@ int DetectPlan::build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleS
                 }
             }
             if (tw >= 1) {
+                min_tile_side = min_tile_side ? std::min(min_tile_side, tw) : tw; max_tile_side = max_tile;
                 const int th = std::min(tw, kTileRows);
                 for (int iy0 = 0; iy0 < sr.endY; iy0 += th) {
                     coords(yp, iy0, std::min(iy0 + th, sr.endY), offy, cy);
@@ -515,9 +548,11 @@ ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor)
     }
     std::unique_ptr<ScaleTable> t(new ScaleTable());
     build_scale_table(c, factor, *t);
-    const size_t bytes = t->host.size() * sizeof(TStumpRec);
-    if (t->dev.ensure(bytes ? bytes : 8)) { ctx->set_error("hipMalloc failed for a stump table"); return nullptr; }
+    const size_t bytes = t->host.size() * sizeof(TStumpRec), lbytes = t->lhost.size() * sizeof(LStumpRec);
+    if (t->dev.ensure(bytes + lbytes ? bytes + lbytes : 8)) { ctx->set_error("hipMalloc failed for a stump table"); return nullptr; }
     if (bytes && hipMemcpy(t->dev.p, t->host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy failed for a stump table"); return nullptr; }
+    if (lbytes && hipMemcpy((unsigned char *)t->dev.p + bytes, t->lhost.data(), lbytes, hipMemcpyHostToDevice) != hipSuccess) { ctx->set_error("hipMemcpy failed for a stump table"); return nullptr; }
+    t->d_lrecs = lbytes ? (const LStumpRec *)((const unsigned char *)t->dev.p + bytes) : nullptr;
     if (!t->ghost.empty()) {             // general cascade: nodes | leaf values | first-node indices in one block
         const size_t nb = (t->ghost.size() * sizeof(GNodeRec) + 255) & ~(size_t)255, ab = (t->galpha.size() * sizeof(float) + 255) & ~(size_t)255;
         const size_t cb = t->gcls_first.size() * sizeof(int);

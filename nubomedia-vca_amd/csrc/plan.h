@@ -10,7 +10,9 @@ void scale_grid(int ow, int oh, int cols, int rows, double scaleFactor, int minw
 // the window, re-balanced weights, equRect.  Cached per (cascade, factor) in the context and shared by all plans.
 struct ScaleTable {
     std::vector<TStumpRec> host;
-    DevBuf dev;
+    std::vector<LStumpRec> lhost;     // the same stumps, compact per-lane form (same order)
+    DevBuf dev;                       // TStumpRec[n] followed by LStumpRec[n]
+    const LStumpRec *d_lrecs = nullptr;
     // general cascades (tree weak classifiers / tilted features): every node at this factor, plus the cascade's leaf values and
     // first-node indices (cascade-level, kept with the table so that a plan finds everything in one place)
     std::vector<GNodeRec> ghost;
@@ -58,7 +60,7 @@ struct DetectPlan {
     bool generic = false;             // tree weak classifiers / tilted features: evaluated by k_gen_stage0 + k_gen_rest
     bool needs_tilted = false;        // the cascade reads the tilted integral
     bool generic_stumps = false;      // general evaluator, but every weak classifier is a stump (the SSE2 pair policy applies)
-    int deep_stage = 6;          // first stage run stump-per-lane (k_deep)
+    int deep_stage = 6;          // first stage run by k_deep; == stages.size(): the tile kernels walk the whole cascade (the default whenever the tiles can hold every stage's samples)
     std::vector<TileRec> tiles;  // LDS lattice tiles (k_tile); empty: row strips (k_strip)
     std::vector<int> tile_order; int tile_blocks_per_frame = 0;
     std::vector<unsigned short> tcoords;
@@ -70,10 +72,12 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_stage_hint, d_blob;   // the table buffers are views into d_blob (d_stage_hint: 8 words the tile kernels keep their stage statistics in, zero at upload)
+    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_blob;   // the table buffers are views into d_blob
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
+    int build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, std::string &err);      // from `specs` and `deep_stage`
+    int min_tile_side = 0, max_tile_side = 0;       // smallest tile side (windows) any scale got / the side asked for
     nvca_rect hit_rect(unsigned key) const;
     bool hit_valid(unsigned key) const;   // the key names a window of this plan's scan grids (a device result is checked before it indexes host tables)
     int build_scale_cascade(nvca_ctx *ctx, const Cascade &c, int cols, int rows, int pitch, double scaleFactor,

@@ -81,7 +81,7 @@ SYMBOLS = [
     "nvca_part_stream_push_faces", "nvca_part_stream_process", "nvca_part_stream_faces",
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
     "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count", "nvca_draw_shapes",
-    "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option", "nvca_overlay_blend",
+    "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option", "nvca_ctx_get_option", "nvca_overlay_blend",
 ]
 
 _lib = None
@@ -128,6 +128,7 @@ def load():
     L.nvca_ctx_set_hit_capacity.argtypes = [vp, C.c_int]
     L.nvca_ctx_set_sum_policy.argtypes = [vp, C.c_int]
     L.nvca_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.nvca_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.nvca_overlay_blend.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, C.POINTER(Overlay)]
     L.nvca_ctx_synchronize.argtypes = [vp]
     L.nvca_ctx_stream.argtypes = [vp]
@@ -228,27 +229,29 @@ class Context:
     def set_sum_policy(self, policy):
         self.check(self.L.nvca_ctx_set_sum_policy(self.h, policy))
 
-    # defaults of the A/B switches when the environment sets none (nvca_ctx_set_option)
-    OPTION_DEFAULTS = {"band": -1, "band_map": 0, "tiles": 1, "deep_stage": 0, "deep_lds": 1, "pyr_off": 0, "host_group": 0,
-                       "group_zerocopy": 1, "sparse_ingest": 1, "ingest_chunk": 8, "skip_cascade": 0, "host_profile": 0,
-                       "part_stats": 0, "trk_order": -1, "plan_debug": 0, "quiet": 0, "roi": 1, "stage_fuse": 0, "stage_order": 1, "host_threads": -1, "two_lanes": 1}
-
     def set_option(self, name, value):
         self.check(self.L.nvca_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_int(0)
+        self.check(self.L.nvca_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def options(self, **kw):
-        """context manager: the given switches for the duration of a with-block, the defaults afterwards"""
+        """context manager: the given switches for the duration of a with-block; afterwards every one of them holds what it held
+        on entry (the process environment's value or an earlier set_option), not a table of defaults"""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
+            before = {k: self.get_option(k) for k in kw}
             for k, v in kw.items():
                 self.set_option(k, v)
             try:
                 yield self
             finally:
-                for k in kw:
-                    self.set_option(k, self.OPTION_DEFAULTS[k])
+                for k, v in before.items():
+                    self.set_option(k, v)
         return scope()
 
     def synchronize(self):

@@ -107,7 +107,7 @@ def part_template(name, win=WIN):
 
 
 def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open_stages=4,
-                 agree_lo=0.52, agree_hi=0.60, tmpl=None):
+                 agree_lo=0.52, agree_hi=0.60, tmpl=None, calib=None):
     """Returns a dict describing a stump cascade (see cascade_to_xml).
 
     Every stump separates TEMPLATE's normalised feature value v_T from zero
@@ -116,6 +116,12 @@ def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open
     bulk of the work on any frame, as with a trained cascade); later stages
     additionally demand that agree_lo..agree_hi of the vote weight sides with
     the template, which makes the cascade specific.
+
+    calib: a WindowSample (below) -- windows of real frame content at the scan's own scales.  The stage thresholds are then
+    chosen stage by stage on the windows that passed every stage before (what haartraining does with its negatives): each
+    stage lets ~pass_rate of what reaches it through, for as many stages as the sample still holds a few hundred windows;
+    the stages behind them keep the template-agreement rule.  Features, stump thresholds and votes are the same as without
+    calib (same seed, same draws).
     """
     stages = list(FRONTALFACE_ALT_STAGES if stages is None else stages)
     rng = np.random.default_rng(seed)
@@ -141,15 +147,26 @@ def make_cascade(seed=2016, stages=None, win=WIN, n_mc=3000, pass_rate=0.5, open
             else:
                 lv.append(a); rv.append(-a)
         coefs = np.stack(coefs)
-        v = _norm_values(coefs, negs)
-        votes = np.where(v >= np.array(thr)[None], np.array(rv)[None], np.array(lv)[None]).sum(axis=1)
-        # achievable vote sums are discrete: take the cut whose noise pass rate is closest
-        cand = np.unique(votes)
-        rates = np.array([(votes >= cnd).mean() for cnd in cand])
-        st_thr = cand[np.argmin(np.abs(rates - pass_rate))] - 1e-3
         s_T = sum(abs(a) for a in rv)
-        if si >= open_stages:
-            frac = agree_lo + (agree_hi - agree_lo) * min(1.0, (si - open_stages) / 6.0)
+        calibrated = False
+        if calib is not None and calib.alive_count() >= 256:
+            # the votes are float32 in the file and in every evaluator: calibrate on exactly those
+            votes = calib.stage_votes(feats, thr, np.float32(lv).astype(np.float64), np.float32(rv).astype(np.float64))
+            cand = np.unique(votes)
+            rates = np.array([(votes >= cnd).mean() for cnd in cand])
+            st_thr = cand[np.argmin(np.abs(rates - pass_rate))] - 1e-3
+            st_thr = min(st_thr, 0.6 * s_T)
+            calib.keep(votes >= float(np.float32(st_thr)) - 1e-4)
+            calibrated = True
+        else:
+            v = _norm_values(coefs, negs)
+            votes = np.where(v >= np.array(thr)[None], np.array(rv)[None], np.array(lv)[None]).sum(axis=1)
+            # achievable vote sums are discrete: take the cut whose noise pass rate is closest
+            cand = np.unique(votes)
+            rates = np.array([(votes >= cnd).mean() for cnd in cand])
+            st_thr = cand[np.argmin(np.abs(rates - pass_rate))] - 1e-3
+        if not calibrated and (si >= open_stages or calib is not None):
+            frac = agree_lo + (agree_hi - agree_lo) * min(1.0, max(0, si - open_stages) / 6.0)
             st_thr = max(st_thr, s_T * (2 * frac - 1))
         st_thr = min(st_thr, 0.6 * s_T)              # the template keeps a wide margin
         out_stages.append(dict(features=feats, thresholds=thr, left=lv, right=rv,
@@ -267,6 +284,120 @@ def generic_cascade_xml(**kw):
 
 def synthetic_cascade_xml(seed=2016, stages=None):
     return cascade_to_xml(make_cascade(seed=seed, stages=stages))
+
+
+# ------------------------------------------------------------------ calibration on frame content
+def equalize_np(g):
+    """cv::equalizeHist as numpy (workload generation only: the checker and the kernels have their own)."""
+    hist = np.bincount(g.ravel(), minlength=256)
+    nz = np.nonzero(hist)[0]
+    if len(nz) <= 1:
+        return g.copy()
+    i0 = nz[0]
+    scale = 255.0 / (g.size - hist[i0])
+    c = np.cumsum(hist) - hist[:i0 + 1].sum()
+    lut = np.clip(np.rint(np.maximum(c, 0) * scale), 0, 255).astype(np.uint8)
+    lut[:i0 + 1] = 0
+    return lut[g]
+
+
+def scan_ladder(ow, oh, cols, rows, scale_factor=1.1, min_size=(0, 0)):
+    """The factors cvHaarDetectObjectsForROC's scale-cascade branch evaluates."""
+    n, f = 0, 1.0
+    while f * ow < cols - 10 and f * oh < rows - 10:
+        n += 1; f *= scale_factor
+    out, f = [], 1.0
+    for _ in range(n):
+        if int(np.rint(ow * f)) >= min_size[0] and int(np.rint(oh * f)) >= min_size[1]:
+            out.append(f)
+        f *= scale_factor
+    return out
+
+
+class WindowSample:
+    """Every window a scale-cascade scan visits on a few gray images (OpenCV's grid: stride max(2, factor), origins cvRound(i * stride)),
+    with the arithmetic of cvSetImagesForHaarClassifierCascade / cvRunHaarClassifierCascadeSum in float64: scaled rectangles
+    cvRound(v * factor), weights over the variance window's area with rectangle 0 re-balanced, value compared with
+    threshold * std of the window.  make_cascade() walks it stage by stage, keeping the windows that pass."""
+
+    def __init__(self, images, win=WIN, scale_factor=1.1, min_size=None):
+        self.win = win
+        self.planes = []          # (S flat, pitch)
+        self.groups = []          # per (image, factor): dict(img, f, off [n] int64, vnf [n])
+        rnd = lambda v: int(np.rint(v))
+        for gi, g in enumerate(images):
+            g = np.asarray(g, np.uint8)
+            H, W = g.shape
+            S = np.zeros((H + 1, W + 1), np.int64); S[1:, 1:] = g.astype(np.int64).cumsum(0).cumsum(1)
+            Q = np.zeros((H + 1, W + 1), np.int64); Q[1:, 1:] = (g.astype(np.int64) ** 2).cumsum(0).cumsum(1)
+            P = W + 1
+            self.planes.append((S.ravel(), P))
+            ms = (W // 20, H // 20) if min_size is None else min_size
+            for f in scan_ladder(win, win, W, H, scale_factor, ms):
+                step = max(2.0, f)
+                ww = rnd(win * f)
+                ex = np.rint(np.arange(rnd((W - ww) / step)) * step).astype(np.int64)
+                ey = np.rint(np.arange(rnd((H - ww) / step)) * step).astype(np.int64)
+                if not len(ex) or not len(ey):
+                    continue
+                off = (ey[:, None] * P + ex[None, :]).ravel()
+                e0, ew = rnd(f), rnd((win - 2) * f)
+                inv = 1.0 / (ew * ew)
+                c = [off + e0 * P + e0, off + e0 * P + e0 + ew, off + (e0 + ew) * P + e0, off + (e0 + ew) * P + e0 + ew]
+                Sf, Qf = S.ravel(), Q.ravel()
+                mean = (Sf[c[0]] - Sf[c[1]] - Sf[c[2]] + Sf[c[3]]) * inv
+                var = (Qf[c[0]] - Qf[c[1]] - Qf[c[2]] + Qf[c[3]]) * inv - mean * mean
+                vnf = np.where(var >= 0, np.sqrt(np.maximum(var, 0)), 1.0)
+                self.groups.append(dict(img=gi, f=f, off=off, vnf=vnf, inv=inv))
+        self.total = self.alive_count()
+
+    def alive_count(self):
+        return int(sum(len(g["off"]) for g in self.groups))
+
+    def stage_votes(self, feats, thr, lv, rv):
+        rnd = lambda v: int(np.rint(v))
+        out = []
+        for g in self.groups:
+            Sf, P = self.planes[g["img"]]
+            f, off, inv = g["f"], g["off"], g["inv"]
+            tot = np.zeros(len(off))
+            if len(off):
+                for feat, t, a0, a1 in zip(feats, thr, lv, rv):
+                    rs, ws = [], []
+                    for (x, y, w, h, wt) in feat:
+                        tx, ty, tw, th = rnd(x * f), rnd(y * f), rnd(w * f), rnd(h * f)
+                        rs.append((tx, ty, tw, th)); ws.append(wt * inv)
+                    ws[0] = -sum(ws[k] * rs[k][2] * rs[k][3] for k in range(1, len(rs))) / (rs[0][2] * rs[0][3])
+                    val = np.zeros(len(off))
+                    for (tx, ty, tw, th), wk in zip(rs, ws):
+                        o = off + ty * P + tx
+                        val += wk * (Sf[o] - Sf[o + tw] - Sf[o + th * P] + Sf[o + th * P + tw])
+                    tot += np.where(val >= np.float32(t) * g["vnf"], a1, a0)
+            out.append(tot)
+        return np.concatenate(out) if out else np.zeros(0)
+
+    def keep(self, mask):
+        k = 0
+        for g in self.groups:
+            n = len(g["off"]); m = mask[k:k + n]; k += n
+            g["off"] = g["off"][m]; g["vnf"] = g["vnf"][m]
+
+
+_CALIB_CACHE = {}
+
+
+def calibrated_cascade_xml(seed=2016, stages=None, W=1920, H=1080, n_images=2, content="natural", scale_factor=1.1):
+    """The stand-in cascade with its stage thresholds calibrated on the bench's own content: every stage lets about half of
+    the windows that reach it through (windows of the equalised 1/f field at the scan's own scales -- haartraining's
+    false-alarm target per stage), for as many stages as the sample supports (ten at 2 x 1080p); pasted templates still pass
+    everything.  A trained cascade's selectivity profile: monotone, no stage that a re-ordering could exploit."""
+    key = (seed, tuple(stages) if stages else None, W, H, n_images, content, scale_factor)
+    if key not in _CALIB_CACHE:
+        imgs = [equalize_np(make_gray(W, H, frame_seed(0, 1000 + i), content)) for i in range(n_images)]
+        c = make_cascade(seed=seed, stages=stages, calib=WindowSample(imgs, scale_factor=scale_factor))
+        c["name"] = "synthetic_frontalface_calibrated"
+        _CALIB_CACHE[key] = cascade_to_xml(c)
+    return _CALIB_CACHE[key]
 
 
 PART_STAGES = [3, 9, 14, 19, 20, 27, 31, 34, 37, 42, 47, 50]     # a shorter cascade, like the mcs_* files

@@ -88,6 +88,8 @@ typedef struct {
     int64_t stumps;         /* weak classifiers evaluated             */
     int64_t raw_hits;       /* candidates before grouping             */
     int     n_scales;       /* scales actually evaluated              */
+    int     pad_;
+    int64_t stage_enter[64]; /* windows that entered stage i (i < 64): the per-stage selectivity of a cascade on a frame */
 } orc_stats;
 
 /* cv::CascadeClassifier::detectMultiScale for an old-format cascade

@@ -32,7 +32,7 @@ class Rect(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("windows", C.c_int64), ("stumps", C.c_int64), ("raw_hits", C.c_int64),
-                ("n_scales", C.c_int)]
+                ("n_scales", C.c_int), ("pad_", C.c_int), ("stage_enter", C.c_int64 * 64)]
 
 
 class CCascade(C.Structure):

@@ -186,6 +186,7 @@ static int hid_run(hid_cascade *h, int x, int y)
     for (int i = 0; i < c->n_stages; i++) {
         const hid_stage *st = &h->stages[i];
         double stage_sum = 0.0;
+        if (h->stats && i < 64) h->stats->stage_enter[i]++;
         if (h->is_stump_based) {
             int pair = (h->policy == ORC_SUM_F32PAIR) && st->two_rects;
             for (int j = 0; j < st->ncls; j++) {

@@ -52,6 +52,13 @@ def synth_xml():
 
 
 @pytest.fixture(scope="session")
+def calibrated_xml():
+    """bench.py's headline cascade: stage thresholds calibrated on the bench's own content (every early stage rejects about half)"""
+    from nubovca import synth
+    return synth.calibrated_cascade_xml()
+
+
+@pytest.fixture(scope="session")
 def small_xml():
     """6-stage cascade: fast enough for exhaustive CPU checks."""
     from nubovca import synth

@@ -65,6 +65,36 @@ def test_face_batch_1080p_band_kernel_vs_oracle(ctx, casc, orc_cascade):
     fs.close()
 
 
+def test_face_batch_1080p_calibrated_cascade_vs_oracle(ctx, calibrated_xml):
+    """the headline workload with the headline CASCADE (bench.py --cascade calibrated: every early stage lets about half of what
+    reaches it through, so thousands of windows per frame are still alive behind stage 5 and the tile kernels' late-stage walk
+    carries real load): 8 consecutive 1080p frames through k_band, then the same frames with the late stages split off to
+    k_deep (deep_stage 6) and through the per-tile kernel pair -- boxes and ids against the oracle every time"""
+    import orc
+    from nubovca import capi, synth
+    W, H, N = 1920, 1080, 8
+    casc = ctx.load_cascade_xml(calibrated_xml)
+    oc = orc.parse_cascade_xml(calibrated_xml)
+    frames = [synth.make_bgr(W, H, synth.frame_seed(0, i), "natural", [(x + 8 * i, y, s) for (x, y, s) in FACES_1080] if i % 5 != 3 else [])
+              for i in range(N)]
+    keep, fr = _device_frames(frames)
+    ofs = orc.FaceStream(oc, width_to_process=W, scale_factor_pct=10)
+    exp = [ofs.process(f) for f in frames]
+    assert sum(len(b) for b, _ in exp) >= 4 * (N - 2)
+    for opts, kern in (({"band": 1}, "cascade_band"), ({"band": 1, "deep_stage": 6}, "cascade_band"), ({"band": 0}, "cascade_tile"), ({"band": 0, "deep_stage": 8}, "cascade_tile")):
+        fs = capi.FaceStream(ctx, casc, width_to_process=W, multi_scale_factor=10)
+        ctx.enable_kernel_timing(1)
+        with ctx.options(**opts):
+            res = ctx.face_batch_process([fs] * N, fr)
+        kt = ctx.kernel_timing()
+        ctx.enable_kernel_timing(0)
+        assert _launched(kt, kern) == 1, (opts, kt)
+        assert (_launched(kt, "cascade_deep") > 0) == ("deep_stage" in opts), (opts, kt)
+        for i in range(N):
+            assert np.array_equal(res[i][0], exp[i][0]) and np.array_equal(res[i][1], exp[i][1]), (opts, i, res[i][0], exp[i][0])
+        fs.close()
+
+
 def test_face_batch_1080p_serving_loop_vs_oracle(ctx, casc, orc_cascade):
     """the loop bench.py times by default: nvca_face_batch_submit / _collect with two batches of the ONE stream in flight
     (batch k + 1 is queued before batch k is unpacked; the temporal logic of a stream runs in collect order), 10 frames of
@@ -162,9 +192,9 @@ def test_face_tracker_batch_8x1080p_vs_oracle(ctx, casc, orc_cascade):
 
 @pytest.mark.parametrize("env,N", [({"band": 1}, 5), ({"band": 1, "band_map": 1}, 8),
                                    ({"band": 1, "band_map": 2}, 16),
-                                   # the early stages in the cascade's own order on every tile, in both tile kernels (the default walks
-                                   # them in the order the previous tile found cheapest: the survivors must not depend on it)
-                                   ({"band": 1, "stage_order": 0}, 6), ({"band": 0, "stage_order": 0}, 6), ({"band": 0}, 6)])
+                                   # both tile kernels with the late stages split off to k_deep (plans whose tiles cannot hold every
+                                   # stage's samples) and walking the whole cascade themselves (the default)
+                                   ({"band": 1, "deep_stage": 6}, 6), ({"band": 0, "deep_stage": 6}, 6), ({"band": 0}, 6)])
 def test_band_kernel_batched_slots(ctx, casc, orc_cascade, env, N):
     """k_band decodes (band, frame slot) from the block index (and NVCA_BAND_MAP remaps it): frames of DIFFERENT content
     in one geometry, forced through the band kernel, each checked against the oracle (a slot / plane mix-up would
