@@ -204,6 +204,9 @@ static Switches read_switches()
     w.pyr_off = set("NVCA_PYR_OFF");
     if (set("NVCA_PART_STATS")) { const int n = num("NVCA_PART_STATS", 0); w.part_stats = n > 0 ? n : 8; }
     w.ingest_chunk = num("NVCA_INGEST_CHUNK", 8);
+    w.stage_order = num("NVCA_STAGE_ORDER", 0) != 0;
+    w.spec_pairs = std::max(1, num("NVCA_SPEC_PAIRS", 1536));
+    w.pair_max = num("NVCA_PAIR_MAX", 32);
     w.deep_stage = set("NVCA_DEEP_STAGE") ? std::max(1, num("NVCA_DEEP_STAGE", 0)) : 0;
     w.tiles = num("NVCA_TILES", 1) != 0;
     w.plan_debug = set("NVCA_PLAN_DEBUG");
@@ -315,7 +318,7 @@ struct GeomPlan {
 DetectPlan::~DetectPlan()
 {
     release_tables();
-    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_blob.release();
+    d_scales.release(); d_stages.release(); d_strips.release(); d_pos.release(); d_order.release(); d_tasks.release(); d_tiles.release(); d_tile_order.release(); d_tcoords.release(); d_bands.release(); d_band_order.release(); d_deeprecs.release(); d_stage_hint.release(); d_stage_first.release(); d_stage_thr.release(); d_blob.release();
 }
 
 int DetectPlan::upload(nvca_ctx *ctx)
@@ -333,6 +336,9 @@ int DetectPlan::upload(nvca_ctx *ctx)
         {&d_bands, bands.data(), bands.size() * sizeof(BandRec)},
         {&d_band_order, band_order.data(), band_order.size() * sizeof(int)},
         {&d_deeprecs, deeprecs.data(), deeprecs.size() * sizeof(DeepRec)},
+        {&d_stage_hint, nullptr, tiles.empty() ? (size_t)0 : 8 * sizeof(int)},          // zero: nothing known yet
+        {&d_stage_first, stage_first.data(), stage_first.size() * sizeof(int)},
+        {&d_stage_thr, stage_thr.data(), stage_thr.size() * sizeof(float)},
     };
     // one device allocation and one copy for all tables (a FIND_BIGGEST scan builds a plan per scale, per call)
     size_t total = 0;
@@ -544,13 +550,13 @@ static int cascade_enqueue(nvca_ctx *ctx, DetectPlan &dp, size_t sum_slot, int s
         a.order = dp.d_order.as<int>(); a.blocks_per_frame = dp.blocks_per_frame;
         a.tasks = dp.d_tasks.as<unsigned>(); a.ntasks = (int)dp.tasks.size();
         a.failbits = ws.ln().failbits.as<unsigned long long>(); a.vnf = ws.ln().vnf.as<double>();
-        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR;
+        a.nstages = (int)dp.stages.size(); a.pair_policy = ctx->policy == NVCA_SUM_F32PAIR; a.stage_order = ctx->sw.stage_order ? 1 : 0; a.stage_hint = dp.d_stage_hint.as<int>(); a.stage_first = dp.d_stage_first.as<int>(); a.stage_thr = dp.d_stage_thr.as<float>(); a.spec_pairs = ctx->sw.spec_pairs; a.pair_max = std::min(32, std::max(0, ctx->sw.pair_max));
         a.deep_stage = dp.deep_stage; a.deep = ws.ln().deep.as<unsigned long long>(); a.deep_cap = deep_cap;
         a.hits = job.d_hits; a.hit_cap = cap;
         a.tiles = dp.d_tiles.as<TileRec>(); a.tile_order = dp.d_tile_order.as<int>();
         a.tile_blocks_per_frame = dp.tile_blocks_per_frame;
         a.tcoords = dp.d_tcoords.as<unsigned short>(); a.tile_lds = dp.tile_lds;
-        a.nscales = (int)dp.scales.size();
+        a.nscales = (int)dp.scales.size(); a.key_sy = dp.key_sy; a.key_ss = dp.key_ss;
         a.bands = dp.d_bands.as<BandRec>(); a.band_order = dp.d_band_order.as<int>(); a.band_blocks_per_frame = dp.band_blocks_per_frame; a.batch = batch;
         { const int bm = ctx->sw.band_map; a.band_map = (bm > 0 && batch % (8 * bm) == 0) ? bm : 0; }
         a.deeprecs = dp.deeprecs.empty() ? nullptr : dp.d_deeprecs.as<DeepRec>(); a.deep_lds = dp.deep_lds;
@@ -665,7 +671,7 @@ static int cascade_collect(nvca_ctx *ctx, DetectPlan &dp, const CascadeJob &job,
         const int slot = (int)slot_u;
         if (!job.dev_group || !(*grouped)[slot]) {
             raw[slot].push_back(dp.hit_rect((unsigned)hh[1 + i]));
-            if (scale_of) (*scale_of)[slot].push_back((int)((unsigned)hh[1 + i] >> 26));
+            if (scale_of) (*scale_of)[slot].push_back((int)((unsigned)hh[1 + i] >> dp.key_ss));
         }
     }
     return NVCA_OK;
@@ -690,62 +696,150 @@ static void group_all(std::vector<std::vector<nvca_rect>> &raw, int min_neighbor
         if (min_neighbors != 0) group_rectangles(r, std::max(min_neighbors, 1), GROUP_EPS);
 }
 
-// Small host images do not go to the runtime as the caller's (pageable) pointers: they pass through page-locked memory of the
-// context's own, rows packed at the device pitch, and cross as ONE 1-D copy.  (a) A 2-D asynchronous copy from pageable memory
-// makes the runtime pin the caller's pages for the length of the copy -- tens of microseconds of system calls for an 8 KB image;
-// (b) under PyTorch's bundled ROCm 7.0 runtime exactly such a copy -- a 97 x 83 numpy image, two tests after frames of the same heap
-// had been page-locked and released again -- ended now and then in "Memory access fault by GPU ... on address <a page of the
-// host heap>" (DESIGN 6a): whatever the runtime remembers about host ranges it has seen, the library no longer depends on it.
-static constexpr size_t kHostStageBytes = 8u << 20, kHostStageMaxImage = 2u << 20;
-static uint8_t *host_stage_take(nvca_ctx *ctx, size_t need)
+// ---- caller host memory -------------------------------------------------------------------------------------------------------
+// A caller's host pointer reaches the HIP runtime as it stands ONLY while the memory lies inside a range the caller page-locked
+// through nvca_host_register (ctx->host_ranges): a copy of pageable memory makes the runtime pin the caller's pages behind the
+// library's back, and under PyTorch's bundled ROCm 7.0 runtime exactly such a copy -- a 97 x 83 numpy image, two tests after frames
+// of the same heap had been page-locked and released again -- ended now and then in "Memory access fault by GPU ... on address <a
+// page of the host heap>" (DESIGN 6a).  Whatever the runtime remembers about host ranges it has seen, the library does not depend
+// on it: everything else is copied by the CPU into / out of page-locked slots of the context's own (ctx->bounce) and crosses
+// from there.  A slot carries the event of the last copy that used it and is waited for before it is used again, so the CPU
+// copy of piece k + 1 runs beside the DMA of piece k.
+static int stream_id(const nvca_ctx *ctx, hipStream_t st)
 {
-    if (need > kHostStageMaxImage) return nullptr;
-    if (!ctx->host_stage.p) {
-        if (ctx->host_stage.ensure(kHostStageBytes)) { (void)hipGetLastError(); return nullptr; }
-        memset(ctx->host_stage.p, 0, kHostStageBytes);
-        ctx->host_stage_used = 0;
+    for (int l = 0; l < kLanes; l++) if (st == ctx->lane_streams[l]) return l;
+    if (st == ctx->copy_stream) return kLanes;
+    if (st == ctx->pre_streams[0]) return kLanes + 1;
+    if (st == ctx->pre_streams[1]) return kLanes + 2;
+    return 63;
+}
+static hipStream_t stream_of_id(const nvca_ctx *ctx, int id)
+{
+    if (id < kLanes) return ctx->lane_streams[id];
+    if (id == kLanes) return ctx->copy_stream;
+    if (id == kLanes + 1) return ctx->pre_streams[0];
+    if (id == kLanes + 2) return ctx->pre_streams[1];
+    return nullptr;
+}
+static int bounce_take(nvca_ctx *ctx, uint8_t **p, int *slot)
+{
+    BounceRing &b = ctx->bounce;
+    if (!b.buf.p) {
+        if (b.buf.ensure(BounceRing::kSlot * BounceRing::kSlots)) { (void)hipGetLastError(); ctx->set_error("allocation failed (page-locked staging)"); return NVCA_ERR_NOMEM; }
+        for (hipEvent_t &e : b.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->set_error("hipEventCreate failed (page-locked staging)"); return NVCA_ERR_HIP; }
     }
-    const size_t al = (need + 255) & ~(size_t)255;
-    if (ctx->host_stage_used + al > kHostStageBytes) { (void)hipDeviceSynchronize(); ctx->host_stage_used = 0; }     // copies out of the old contents may still be queued
-    uint8_t *p = ctx->host_stage.as<uint8_t>() + ctx->host_stage_used;
-    ctx->host_stage_used += al;
-    return p;
+    const int k = b.next;
+    b.next = (k + 1) % BounceRing::kSlots;
+    if (b.pending[k]) { NVCA_HIP_CHECK(ctx, hipEventSynchronize(b.ev[k])); b.pending[k] = false; }
+    *p = b.buf.as<uint8_t>() + (size_t)k * BounceRing::kSlot; *slot = k;
+    return NVCA_OK;
+}
+static int bounce_used(nvca_ctx *ctx, int slot, hipStream_t st)
+{
+    NVCA_HIP_CHECK(ctx, hipEventRecord(ctx->bounce.ev[slot], st));
+    ctx->bounce.pending[slot] = true;
+    return NVCA_OK;
+}
+// large pieces are copied by the context's helper threads too (the PCIe link moves ~50 GB/s; one core's memcpy a fifth of that)
+static void host_copy(nvca_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    static constexpr size_t kPiece = 512u << 10;
+    if (bytes < 2 * kPiece || !ctx->pool) { memcpy(dst, src, bytes); return; }
+    struct Arg { uint8_t *d; const uint8_t *s; size_t n; } arg{(uint8_t *)dst, (const uint8_t *)src, bytes};
+    work_pool_run(ctx->pool, (int)((bytes + kPiece - 1) / kPiece), [](void *a, int i) {
+        const Arg *g = (const Arg *)a;
+        const size_t o = (size_t)i * kPiece;
+        memcpy(g->d + o, g->s + o, std::min(kPiece, g->n - o));
+    }, &arg);
+}
+static void ensure_pool(nvca_ctx *ctx)
+{
+    if (ctx->pool || ctx->pool_tried) return;
+    ctx->pool_tried = true;
+    int t = ctx->sw.host_threads;
+    if (t < 0) { const int hc = (int)std::thread::hardware_concurrency(); t = std::min(8, hc / 2) - 1; }
+    ctx->pool = work_pool_create(t);
+}
+int caller_h2d(nvca_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return NVCA_OK;
+    if (ctx->host_ranges.note_copy(src, bytes, stream_id(ctx, st))) {
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return NVCA_OK;
+    }
+    if (bytes >= (1u << 20)) ensure_pool(ctx);
+    for (size_t o = 0; o < bytes; o += BounceRing::kSlot) {
+        const size_t len = std::min(BounceRing::kSlot, bytes - o);
+        uint8_t *h; int slot, rc;
+        if ((rc = bounce_take(ctx, &h, &slot))) return rc;
+        host_copy(ctx, h, (const uint8_t *)src + o, len);
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)dst + o, h, len, hipMemcpyHostToDevice, st));
+        if ((rc = bounce_used(ctx, slot, st))) return rc;
+    }
+    return NVCA_OK;
+}
+// rows of `width` bytes, spitch apart in the caller's memory, to rows dpitch apart on the device
+int caller_h2d_rows(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st)
+{
+    if (!rows || !width) return NVCA_OK;
+    if (width > BounceRing::kSlot) { ctx->set_error("row too long for the page-locked staging"); return NVCA_ERR_ARG; }
+    if (ctx->host_ranges.note_copy(src, spitch * (rows - 1) + width, stream_id(ctx, st))) {
+        NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, st));
+        return NVCA_OK;
+    }
+    const size_t per = std::max<size_t>(1, BounceRing::kSlot / width);
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t nr = std::min(per, rows - r0);
+        uint8_t *h; int slot, rc;
+        if ((rc = bounce_take(ctx, &h, &slot))) return rc;
+        if (spitch == width) host_copy(ctx, h, (const uint8_t *)src + r0 * spitch, nr * width);
+        else for (size_t y = 0; y < nr; y++) memcpy(h + y * width, (const uint8_t *)src + (r0 + y) * spitch, width);
+        if (dpitch == width) NVCA_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)dst + r0 * dpitch, h, nr * width, hipMemcpyHostToDevice, st));
+        else NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync((uint8_t *)dst + r0 * dpitch, dpitch, h, width, width, nr, hipMemcpyHostToDevice, st));
+        if ((rc = bounce_used(ctx, slot, st))) return rc;
+    }
+    return NVCA_OK;
+}
+int caller_d2h_rows(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st)
+{
+    if (!rows || !width) { NVCA_HIP_CHECK(ctx, hipStreamSynchronize(st)); return NVCA_OK; }
+    if (width > BounceRing::kSlot) { ctx->set_error("row too long for the page-locked staging"); return NVCA_ERR_ARG; }
+    if (ctx->host_ranges.note_copy(dst, dpitch * (rows - 1) + width, stream_id(ctx, st))) {
+        NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, st));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        return NVCA_OK;
+    }
+    const size_t per = std::max<size_t>(1, BounceRing::kSlot / width);
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t nr = std::min(per, rows - r0);
+        uint8_t *h; int slot, rc;
+        if ((rc = bounce_take(ctx, &h, &slot))) return rc;
+        if (spitch == width) NVCA_HIP_CHECK(ctx, hipMemcpyAsync(h, (const uint8_t *)src + r0 * spitch, nr * width, hipMemcpyDeviceToHost, st));
+        else NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(h, width, (const uint8_t *)src + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost, st));
+        NVCA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (size_t y = 0; y < nr; y++) memcpy((uint8_t *)dst + (r0 + y) * dpitch, h + y * width, width);
+    }
+    return NVCA_OK;
 }
 // copy a host/device 2-D byte image into device memory with a pitch
 static int stage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
                     size_t height, int mem)
 {
-    if (mem == NVCA_MEM_HOST && height > 0 && width_bytes <= dpitch) {
-        const size_t need = dpitch * (height - 1) + width_bytes;
-        if (uint8_t *h = host_stage_take(ctx, need)) {
-            for (size_t y = 0; y < height; y++) memcpy(h + y * dpitch, (const uint8_t *)src + y * spitch, width_bytes);
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(dst, h, need, hipMemcpyHostToDevice, ctx->cs()));
-            return NVCA_OK;
-        }
-    }
-    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
-                                         mem == NVCA_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                                         ctx->cs()));
+    if (mem == NVCA_MEM_HOST) return caller_h2d_rows(ctx, dst, dpitch, src, spitch, width_bytes, height, ctx->cs());
+    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->cs()));
     return NVCA_OK;
 }
 static int unstage_2d(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
                       size_t height, int mem)
 {
     NVCA_LAUNCH_CHECK(ctx);
-    if (mem == NVCA_MEM_HOST && height > 0 && width_bytes <= spitch) {          // out through the context's page-locked memory (see stage_2d)
-        const size_t need = spitch * (height - 1) + width_bytes;
-        if (uint8_t *h = host_stage_take(ctx, need)) {
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(h, src, need, hipMemcpyDeviceToHost, ctx->cs()));
-            NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
-            for (size_t y = 0; y < height; y++) memcpy((uint8_t *)dst + y * dpitch, h + y * spitch, width_bytes);
-            drain_timer(ctx);
-            return NVCA_OK;
-        }
+    if (mem == NVCA_MEM_HOST) {
+        const int rc = caller_d2h_rows(ctx, dst, dpitch, src, spitch, width_bytes, height, ctx->cs());
+        if (!rc) drain_timer(ctx);
+        return rc;
     }
-    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
-                                         mem == NVCA_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                                         ctx->cs()));
-    if (mem == NVCA_MEM_DEVICE && ctx->defer_device_sync > 0) return NVCA_OK;   // consumer is queued on the same stream
+    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->cs()));
+    if (ctx->defer_device_sync > 0) return NVCA_OK;   // consumer is queued on the same stream
     NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     drain_timer(ctx);
     return NVCA_OK;
@@ -793,6 +887,9 @@ static GeomPlan *store_plan(nvca_ctx *ctx, const std::string &key, std::unique_p
 static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, int stride, int cn, int cols, int rows,
                          double sf, int minw, int minh, int maxw, int maxh, GeomPlan **out)
 {
+    // multi-scale-factor 0 (scaleFactor 1.0): OpenCV's assertion fires in detectMultiScale, the reference logs it and passes the frame on
+    // untouched (FACE/kmsfacedetect.cpp:540-542 installs the property with range 0 .. 51); every other value is a ladder that ends
+    if (!(sf > 1.0)) { ctx->set_error("scaleFactor must be greater than 1 (multi-scale-factor 0)"); return NVCA_ERR_ARG; }
     char key[256];
     snprintf(key, sizeof(key), "F|%llu|%d|%d|%d|%d|%d|%d|%.17g|%d|%d|%d|%d", (unsigned long long)casc->c.uid, W, H, stride,
              cn, cols, rows, sf, minw, minh, maxw, maxh);
@@ -806,7 +903,6 @@ static int get_face_plan(nvca_ctx *ctx, const nvca_cascade *casc, int W, int H, 
     std::string err;
     rc = gp->det.build_scale_cascade(ctx, casc->c, cols, rows, gp->g.spitch, sf, minw, minh, maxw, maxh, err);
     if (rc) { ctx->set_error(err); return rc; }
-    if (gp->det.scales.size() > 63) { ctx->set_error("too many scales"); return NVCA_ERR_ARG; }
     rc = gp->det.upload(ctx);
     if (rc) return rc;
     gp->has_det = true;
@@ -828,7 +924,7 @@ nvca_ctx::~nvca_ctx()
     trk.release_all();
     part.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
-    host_stage.release();
+    bounce.release();
     nvca::work_pool_destroy(pool); pool = nullptr;
     overlay_img.release();
     for (auto &kv : roi_stage_recs) { kv.second->release(); delete kv.second; }
@@ -924,6 +1020,9 @@ try {
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "pre_cus") w.pre_cus = value > 0 ? value : 0;
     else if (n == "plan_debug") w.plan_debug = value != 0;
+    else if (n == "stage_order") w.stage_order = value != 0;
+    else if (n == "spec_pairs") w.spec_pairs = value > 0 ? value : 1;
+    else if (n == "pair_max") w.pair_max = value;
     else if (n == "pyr_off") { w.pyr_off = value != 0; replan = true; }
     else if (n == "tiles") { w.tiles = value != 0; replan = true; }
     else if (n == "deep_stage") { w.deep_stage = value > 0 ? value : 0; replan = true; }
@@ -961,6 +1060,9 @@ try {
     else if (n == "host_threads") *value = w.host_threads;
     else if (n == "pre_cus") *value = w.pre_cus;
     else if (n == "plan_debug") *value = w.plan_debug;
+    else if (n == "stage_order") *value = w.stage_order;
+    else if (n == "spec_pairs") *value = w.spec_pairs;
+    else if (n == "pair_max") *value = w.pair_max;
     else if (n == "pyr_off") *value = w.pyr_off;
     else if (n == "tiles") *value = w.tiles;
     else if (n == "deep_stage") *value = w.deep_stage;
@@ -1001,16 +1103,35 @@ try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ptr || !bytes) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
-    NVCA_HIP_CHECK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    if (ctx->host_ranges.covering(ptr, 1) >= 0 || !ctx->host_ranges.add(ptr, bytes)) { ctx->set_error("nvca_host_register: the range overlaps one that is registered"); return NVCA_ERR_ARG; }
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        bool found; (void)ctx->host_ranges.remove(ptr, &found); ctx->host_ranges.retired.pop_back();       // never was
+        ctx->set_error(std::string("hipHostRegister: ") + hipGetErrorString(e));
+        return NVCA_ERR_HIP;
+    }
+    if (alloc_log()) fprintf(stderr, "[nvca alloc] host register   %p .. %p (%zu bytes)%s\n", ptr, (void *)((char *)ptr + bytes), bytes, ctx->host_ranges.was_registered(ptr, bytes) ? " -- overlaps a range released earlier" : "");
     return NVCA_OK;
 }
 NVCA_API_CATCH(ctx)
+// The pages are released only when every stream that carried a copy of the range since it was registered has drained: the
+// batched face path copies host frames on the copy stream and on the lanes of the two batches in flight, not only on the
+// context's own stream -- an unregister behind a failed or abandoned batch must not pull pages from under a copy.
 int nvca_host_unregister(nvca_ctx *ctx, void *ptr)
 try {
     NVCA_LOCK_OR_FAIL(ctx);
     if (!ptr) return NVCA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
-    NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+    const int i = ctx->host_ranges.find(ptr);
+    if (i < 0) { ctx->set_error("nvca_host_unregister: not a pointer nvca_host_register was given"); return NVCA_ERR_ARG; }
+    const uint64_t streams = ctx->host_ranges.live[(size_t)i].streams;
+    for (int id = 0; id < 64; id++)
+        if ((streams >> id) & 1ull) {
+            hipStream_t st = stream_of_id(ctx, id);
+            if (st) NVCA_HIP_CHECK(ctx, hipStreamSynchronize(st)); else NVCA_HIP_CHECK(ctx, hipDeviceSynchronize());
+        }
+    bool found; (void)ctx->host_ranges.remove(ptr, &found);
+    if (alloc_log()) fprintf(stderr, "[nvca alloc] host unregister %p (streams drained: 0x%llx)\n", ptr, (unsigned long long)streams);
     NVCA_HIP_CHECK(ctx, hipHostUnregister(ptr));
     return NVCA_OK;
 }
@@ -1221,23 +1342,19 @@ static int stage_frames(nvca_ctx *ctx, const nvca_frame *frames, const int *idx,
         const nvca_frame &f = frames[idx ? idx[i] : i];
         if (f.mem == NVCA_MEM_HOST) {
             uint8_t *d = ws.res[ws.cur_res].staging.as<uint8_t>() + off;
+            int rc;
             if (rows) {
                 // only the rows the resize reads; a run that ends on the frame's last row is copied without the row padding
                 // (the caller's buffer need not extend past the last pixel)
                 const size_t pitch = (size_t)rows->period * f.stride, start = (size_t)rows->first * f.stride;
                 const bool tail = rows->first + (rows->count - 1) * rows->period + rows->run == f.height;
                 const int full = tail ? rows->count - 1 : rows->count;
-                if (full > 0)
-                    NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync(d + start, pitch, (const uint8_t *)f.data + start, pitch, (size_t)rows->run * f.stride,
-                                                         (size_t)full, hipMemcpyHostToDevice, st));
+                if (full > 0 && (rc = caller_h2d_rows(ctx, d + start, pitch, (const uint8_t *)f.data + start, pitch, (size_t)rows->run * f.stride, (size_t)full, st))) return rc;
                 if (tail) {
                     const size_t o = start + (size_t)full * pitch;
-                    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d + o, (const uint8_t *)f.data + o, (size_t)(rows->run - 1) * f.stride + (size_t)f.width * bpp,
-                                                       hipMemcpyHostToDevice, st));
+                    if ((rc = caller_h2d(ctx, d + o, (const uint8_t *)f.data + o, (size_t)(rows->run - 1) * f.stride + (size_t)f.width * bpp, st))) return rc;
                 }
-            } else
-            NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp,
-                                               hipMemcpyHostToDevice, st));
+            } else if ((rc = caller_h2d(ctx, d, f.data, (size_t)f.stride * (f.height - 1) + (size_t)f.width * bpp, st))) return rc;
             hp[i] = d;
             off += round_up((size_t)f.stride * f.height, 256);
         } else
@@ -1421,7 +1538,7 @@ try {
     int rc;
     const size_t bytes = (size_t)ov->stride * (ov->height - 1) + (size_t)ov->width * ov->channels;
     if (ctx->overlay_img.ensure(bytes + 64)) { ctx->set_error("allocation failed (overlay image)"); return NVCA_ERR_NOMEM; }
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->overlay_img.p, ov->data, bytes, hipMemcpyHostToDevice, ctx->cs()));
+    if ((rc = caller_h2d(ctx, ctx->overlay_img.p, ov->data, bytes, ctx->cs()))) return rc;
     for (int b = 0; b < n; b++) {            // in order: a later box overwrites an earlier one where they overlap
         const OverlayPlace p = overlay_place(boxes[b], *ov);
         if (p.w <= 0 || p.h <= 0) continue;
@@ -1759,7 +1876,6 @@ static int fb_enqueue_first(nvca_ctx *ctx, DetectJob &j, int r0, int total)
         const double inv = 1. / j.sf; factor *= inv;
         for (; n_factors-- > 0; factor *= inv) j.ladder.push_back(FbStep{factor, std::max(2., factor), cv_round(c.ow * factor), cv_round(c.oh * factor)});
     }
-    if (j.ladder.size() > 63) { ctx->set_error("too many scales"); return NVCA_ERR_ARG; }
     j.hits.assign(j.ladder.size(), {}); j.have.assign(j.ladder.size(), 0);
     j.all.clear(); j.scanROI = nvca_rect{0, 0, 0, 0}; j.narrowed_done = false; j.fb_i = 0; j.cur_minw = j.minw; j.cur_minh = j.minh;
     char key[256];
@@ -2401,12 +2517,7 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             // the jobs with the most candidates first: the helpers take indices in order, the long ones must not come last
             auto weight = [](const DetectJob *j) { size_t w = 0; for (int k = 0; k < j->nimg; k++) w += j->rkeys[k].size(); return w; };
             std::stable_sort(par.begin(), par.end(), [&](const DetectJob *x, const DetectJob *y) { return weight(x) > weight(y); });
-            if (!ctx->pool && !ctx->pool_tried) {
-                ctx->pool_tried = true;
-                int t = ctx->sw.host_threads;
-                if (t < 0) { const int hc = (int)std::thread::hardware_concurrency(); t = std::min(8, hc / 2) - 1; }
-                ctx->pool = work_pool_create(t);
-            }
+            ensure_pool(ctx);
             struct Arg { nvca_ctx *ctx; DetectJob **jobs; std::atomic<int> rc; } arg{ctx, par.data(), {0}};
             work_pool_run(ctx->pool, (int)par.size(), [](void *a, int i) {
                 Arg *g = (Arg *)a;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_gen_rest(CascadeArgs a)
     base = __shfl(base, 0);
     if (alive) {
         const unsigned long long pos = base + __popcll(hm & ((1ull << lane) - 1ull));
-        const unsigned key = ((unsigned)s << 26) | ((unsigned)iy << 13) | (unsigned)ix;
+        const unsigned key = ((unsigned)s << a.key_ss) | ((unsigned)iy << a.key_sy) | (unsigned)ix;
         if (pos < a.hit_cap) a.hits[1 + pos] = ((unsigned long long)slot << 32) | key;
     }
 }
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_strip(CascadeArgs a)
     for (int i = tid; i < nh; i += 256) {
         const int w = q[cur][i];
         const int r = w / endX, ix = ix0 + (w - r * endX);
-        const unsigned key = ((unsigned)strip.scale << 26) | ((unsigned)(strip.iy0 + r) << 13) | (unsigned)ix;
+        const unsigned key = ((unsigned)strip.scale << a.key_ss) | ((unsigned)(strip.iy0 + r) << a.key_sy) | (unsigned)ix;
         if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
     }
 }
@@ -586,29 +586,27 @@ __device__ __forceinline__ int lane_rect(unsigned cm, unsigned rm, unsigned xx, 
     const int r0 = lds_u16(rm + (yy & 0xffffu)), r1 = lds_u16(rm + (yy >> 16));
     return lds_sample(r0, c0) - lds_sample(r0, c1) - lds_sample(r1, c0) + lds_sample(r1, c1);
 }
-// the vote of the lane's stump on the lane's window: the file's float (a0 / a1), selected exactly as tile_vote_s selects it
-template <bool PAIR>
-__device__ __forceinline__ float lane_vote(unsigned cm, unsigned rm, double vnf, const LRec &f)
+// The vote of the lane's stump on the lane's window, as the f64 OpenCV adds to the stage sum.  Lanes of one wave may hold
+// stumps of different stages: whether the SSE2 pair form applies (a stage of two-rectangle stumps under NVCA_SUM_F32PAIR) is
+// a mark in the record (xx2 == 0, yy2 == 1) and selected per lane.
+__device__ __forceinline__ double lane_vote(unsigned cm, unsigned rm, double vnf, const LRec &f, int pair_policy)
 {
     const int s0 = lane_rect(cm, rm, (unsigned)f.a.x, (unsigned)f.a.y);
     const int s1 = lane_rect(cm, rm, (unsigned)f.a.z, (unsigned)f.a.w);
     const double t = (double)__int_as_float(f.c.y) * vnf;          // node->threshold * variance_norm_factor
-    const float w0 = __int_as_float(f.b.z), w1 = __int_as_float(f.b.w);
-    double v;
-    if (PAIR) v = (double)((float)s0 * w0 + (float)s1 * w1);
-    else {
-        v = (double)((float)s0 * w0);
-        v += (double)((float)s1 * w1);
-        if (f.b.x | f.b.y) v += (double)((float)lane_rect(cm, rm, (unsigned)f.b.x, (unsigned)f.b.y) * __int_as_float(f.c.x));
-    }
-    return __int_as_float(v >= t ? f.c.w : f.c.z);
+    const float p0 = (float)s0 * __int_as_float(f.b.z), p1 = (float)s1 * __int_as_float(f.b.w);
+    double v = (double)p0;
+    v += (double)p1;
+    if (f.b.x) v += (double)((float)lane_rect(cm, rm, (unsigned)f.b.x, (unsigned)f.b.y) * __int_as_float(f.c.x));
+    else if (pair_policy && f.b.y == 1) v = (double)(p0 + p1);
+    return (double)__int_as_float(v >= t ? f.c.w : f.c.z);
 }
 
 #ifdef NVCA_STAMPS
 // diagnostic build: thread 0 of the first 64 workgroups leaves s_memtime stamps per tile and phase (64 words per tile, 16 tiles)
-#define NVCA_STAMP(a, tile, id) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) { unsigned long long t__; \
+#define NVCA_STAMP(a, tile, id) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (id) < 64 && (a).dbg) { unsigned long long t__; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = t__; } } while (0)
-#define NVCA_STAMP_VAL(a, tile, id, v) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (a).dbg) (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = (unsigned long long)(v); } while (0)
+#define NVCA_STAMP_VAL(a, tile, id, v) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (tile) < 16 && (id) < 64 && (a).dbg) (a).dbg[((size_t)blockIdx.x * 16 + (tile)) * 64 + (id)] = (unsigned long long)(v); } while (0)
 #else
 #define NVCA_STAMP(a, tile, id) do { } while (0)
 #define NVCA_STAMP_VAL(a, tile, id, v) do { } while (0)
@@ -616,11 +614,8 @@ __device__ __forceinline__ float lane_vote(unsigned cm, unsigned rm, double vnf,
 
 // LDS carve-up of a tile (tile_lds_bytes() on the host sizes exactly this)
 struct TileLds {
-    double *vnf_s;                // [kTileSlots] variance normaliser per window
-    unsigned *xyw;                // [kTileSlots] window origin relative to the tile's: 2 xw | 2 yw << 16 (byte offsets into the maps)
-    unsigned short *wl;           // [waves][64] the windows a wave still carries (window id = ry * 32 + rx), compacted
-    unsigned short *winx, *winy;  // [kTileWin] each: window origins of the tile's columns / rows (k_tile)
-    int *scratch;                 // 16 words
+    double *acc;                  // [kTileSlots] stage accumulators (viewed as int or double per stage), all zero outside a stage
+    unsigned short *q0, *winx, *winy; int *qn; double *vnf_s;
     unsigned short *cmap, *rmap; int *T; int pitchT;
     int tword;                    // absolute LDS word address of T: the row map holds tword + r * pitchT
     unsigned cmA, rmA;            // LDS byte addresses of the maps
@@ -628,12 +623,12 @@ struct TileLds {
 __device__ __forceinline__ TileLds carve_tile(unsigned char *lds, const TileRec &t)
 {
     TileLds L;
-    L.vnf_s = (double *)lds;
-    L.xyw = (unsigned *)(L.vnf_s + kTileSlots);
-    L.wl = (unsigned short *)(L.xyw + kTileSlots);
-    L.winx = L.wl + (kTileThreads / 64) * 64; L.winy = L.winx + kTileWin;
-    L.scratch = (int *)(L.winy + kTileWin);
-    L.cmap = (unsigned short *)(L.scratch + 16);
+    L.acc = (double *)lds;
+    L.q0 = (unsigned short *)(lds + kTileSlots * 8);
+    L.winx = L.q0 + 2 * kTileSlots; L.winy = L.winx + kTileWin;
+    L.qn = (int *)(L.winy + kTileWin);                       // qn[0..2] rotating queue counters, qn[3] = list base, qn[4 ..] stage statistics
+    L.vnf_s = (double *)((unsigned char *)L.qn + 64);
+    L.cmap = (unsigned short *)(L.vnf_s + kTileSlots);
     L.rmap = L.cmap + ((t.span_x + 3) & ~3);
     L.T = (int *)(L.rmap + ((t.span_y + 3) & ~3));
     L.pitchT = tile_pitch(t.ncol);
@@ -682,125 +677,306 @@ __device__ __forceinline__ void tile_commit(const CascadeArgs &a, const TileRec 
             if (k < nk && lane + 64 * k < t.ncol)
                 __builtin_amdgcn_global_load_lds((gptr_t)(rowp + c.xcb[k]), (lptr_t)(dst + 64 * k), 4, 0, 0);
     }
+    if (tid < 3) L.qn[tid] = 0;          // the three rotating queue counters (qn[3]: list base scratch)
     if (tid < t.nx) L.winx[tid] = (unsigned short)(c.wx - t.x0);
     if (tid >= 64 && tid < 64 + t.ny) L.winy[tid - 64] = (unsigned short)(c.wy - t.y0);
     if (c.mapc >= 0) L.cmap[c.mapc - t.x0] = (unsigned short)(tid * 4);
     if (c.mapr >= 0) L.rmap[c.mapr - t.y0] = (unsigned short)(L.tword + tid * L.pitchT);     // absolute word address of the row: a corner address is one shift-add
 }
 
-// ---- the walk of a wave through the cascade -----------------------------------------------------------------------------
-// After stage 0 a wave carries k <= 64 windows of its own two window rows (compacted in L.wl, its 64-entry list) and takes them
-// through stages 1 .. last-1 BY ITSELF: no workgroup barrier, no shared queue -- the waves of a tile run independently (and
-// overlap each other's latencies) until the tile's samples are replaced.  Per stage, with G = 64 / k:
-//   G >= 2  lane l = (window j = l % k, stump group cc = l / k): step t evaluates stump t * G + cc of the stage on window j --
-//           G stumps of every window per step, records per lane (LStumpRec, three 16-byte loads from L1 / L2), k * G of the 64
-//           lanes busy whatever k is.  A lane keeps one window for the whole stage and sums its stumps' votes privately; the G
-//           partial sums of a window then meet in lane j over log2(G) cross-lane steps.  Exact: the stage's votes are integers
-//           of a common unit (StageRec flag bit 2: i32 sums) or at least sums that are exact in f64 in any order (flag bit 1).
-//   G == 1  (more than 32 windows: the first stages) a window per lane, the stage's stumps one after the other as wave-uniform
-//           records in scalar registers.  Also any stage whose votes may not be re-ordered (neither flag bit), in OpenCV's order.
-// The windows that pass are re-compacted in place (a lane reads its entry before any lane writes).  Whoever is left after
-// stage last-1 goes to the candidate list (the cascade ends here: the usual plan, every stage runs out of the tile) or to
-// the late-stage kernel's list (plans whose tiles cannot hold the late stages' samples).
-template <bool PAIR, class Sum>
-__device__ __forceinline__ bool walk_stage_lanes(const TileLds &L, unsigned short *wl, int k, int G, const LStumpRec *lrecs, const StageRec &st)
+// the same when every lane that may keep a window sits in ONE wave (a round of at most 64 windows: wave 0 decides them all) and
+// *count is zero and nobody else's: positions and count come straight from the ballot -- no returning atomic, one LDS round
+// trip less in a round that is a chain of such round trips
+__device__ __forceinline__ void queue_push_wave0(bool keep, int w, unsigned short *q, int *count)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const unsigned long long km = __ballot(keep);
+    if (keep) q[__popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
+    if (lane == 0) *count = __popcll(km);
+}
+__device__ __forceinline__ void queue_push(bool keep, int w, unsigned short *q, int *count)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned inv = 65535u / (unsigned)k + 1u;              // floor(l / k) = l * inv >> 16 for l < 64, k <= 64 (error < 64 / 65536 * k)
-    const int cc = (int)(((unsigned)lane * inv) >> 16), j = lane - cc * k;
-    const bool on = cc < G;
-    unsigned cm = L.cmA, rm = L.rmA; double vnf = 1.;
-    if (on) {
-        const int w = wl[j];
-        const unsigned xy = L.xyw[w];
-        cm += xy & 0xffffu; rm += xy >> 16;
-        vnf = L.vnf_s[w];
+    const unsigned long long km = __ballot(keep);
+    if (km) {
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(count, __popcll(km));
+        wbase = __shfl(wbase, 0);
+        if (keep) q[wbase + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
     }
-    Sum acc = 0;
-    const int C = st.count;
-    const LStumpRec *base = lrecs + st.first;
-    int c = cc;
-    LRec f;
-    if (on && c < C) f = load_lrec(base + c);
-    for (; __any(on && c < C); c += G) {
-        const bool act = on && c < C;
-        LRec fn = f;
-        if (on && c + G < C) fn = load_lrec(base + c + G);        // the next step's record is on its way under this step's LDS work
-        if (act) {
-            const float a = lane_vote<PAIR>(cm, rm, vnf, f);
-            if (sizeof(Sum) == sizeof(int)) acc += (Sum)(int)ldexpf(a, -st.vote_exp);       // exact: a is a multiple of 2^vote_exp below 2^31 of them
-            else acc += (Sum)(double)a;
-        }
-        f = fn;
-    }
-    for (int sft = 1; sft < G; sft <<= 1) {
-        const Sum o = __shfl(acc, lane + sft * k);
-        if (cc + sft < G) acc += o;
-    }
-    if (sizeof(Sum) == sizeof(int)) return (int)acc >= st.thr_i;
-    return !((double)acc < (double)st.thr);
 }
 
-template <bool VNF_OUT>
-__device__ __forceinline__ void wave_walk(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int k, int ti = 0)
+// ---- the stages behind stage 0 on the windows queued in q0[0 .. qn[0]) (window id = ry * 32 + rx) -----------------------------
+// One round per stage (several stages per round once few windows are left), the queue re-compacted after every round; whoever is
+// left after stage last-1 goes to the candidate list (last == nstages: the usual plan -- every stage runs out of the tile, there
+// is no late-stage kernel) or to k_deep's list (plans whose tiles cannot hold the late stages' samples).
+// A round's work is the grid (windows of the queue) x (stumps of the stage); three ways of dealing it to the workgroup's waves:
+//   * more than 32 windows, votes exact in any order (StageRec flag bit 1; bit 2: as 32-bit integers of a common unit): the grid of
+//     (64-window groups) x (stumps) goes to the waves as equal contiguous runs, a window per lane, the stump records wave-uniform
+//     in scalar registers; a wave adds its run's sum to the window's accumulator in LDS (ds_add_u32 / ds_add_f64 -- every partial
+//     sum is exactly representable, so any order and grouping gives the f64 sum OpenCV forms, bit for bit).
+//   * at most 32 windows (n): every wave holds ALL n windows, G = 64 / n stumps at a time -- lane = (window l % n, stump l / n) -- and
+//     takes every NW-th block of G stumps, records per lane (LStumpRec: three 16-byte loads from L1 / L2).  Lanes stay busy
+//     whatever n is: a late stage of 50 .. 213 stumps on a handful of windows is ONE step of the workgroup, not a chain of stumps
+//     walked by a handful of lanes.  With few windows left a round takes several stages at once (as many as fit one step of
+//     the workgroup: 768 window-stump pairs): the stumps of stages s+1, s+2 .. are evaluated for every window of the queue before
+//     it is known whether it passes stage s -- no side effects, and a window goes on iff it passes them all, exactly as if they
+//     had run one after the other; the rounds a surviving window waits for (a barrier pair and a round trip of records each)
+//     shrink from one per stage to one per 2 .. 7 stages.
+//   * votes that may not be re-ordered (neither flag bit): a window per thread, the stage's stumps in OpenCV's order.
+// The early stages 1 .. 5 may be walked in the order the PREVIOUS tile of the band found cheapest (stump count per window
+// killed, from that tile's entered / passed counts: stat words behind the queue counters, two sets used alternately): a window
+// goes on iff it passes all of them, and which of them it fails first is seen by nobody.  Switch "stage_order".
+static constexpr int kStatStages = 6;         // stages 0 .. 5 take part in the adaptive order
+static constexpr int kPairMax = 32;           // windows up to which a round runs lane = (window, stump)
+template <bool VNF_LDS>
+__device__ __forceinline__ void tile_stages(const CascadeArgs &a, const TileRec &t, const ScaleRec &sc, int slot, const TileLds &L, int ti = 0, int par = 0)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned short *wl = L.wl + wave * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int *stat_r = L.qn + 4 + par * kStatStages;       // what the previous tile saw
+    int *stat_w = L.qn + 4 + (par ^ 1) * kStatStages;       // what this tile sees
+    constexpr int NW = kTileThreads / 64;
+    const TStumpRec *urecs = sc.trecs;
+    const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
+    const double *__restrict__ vnfp = a.vnf + vbase;
+    auto vnf_of = [&](int w) {
+        if (VNF_LDS) return L.vnf_s[w];
+        const int ix = t.ix0 + (w & 31);
+        return vnfp[((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)];
+    };
+    int *acci = (int *)L.acc;
+    int cur = 0;
+    // queue counters rotate over three words: a round reads qn[cin], appends to qn[cout] and clears the third one, which
+    // nobody touches during this round and which the next round appends to
+    int cin = 0;
     const int last = a.deep_stage < a.nstages ? a.deep_stage : a.nstages;
-    k = __builtin_amdgcn_readfirstlane(k);
-    for (int s = 1; s < last && k > 0; s++) {
-        NVCA_STAMP(a, ti, 8 + 2 * s); NVCA_STAMP_VAL(a, ti, 9 + 2 * s, k);
-        const StageRec st = load_const(a.stages + s);
-        const bool pair = a.pair_policy && (st.flags & 1);
-        const int G = 64 / k;
-        bool pass;
-        if (G >= 2 && (st.flags & 6)) {
-            if (st.flags & 4) pass = pair ? walk_stage_lanes<true, int>(L, wl, k, G, sc.lrecs, st) : walk_stage_lanes<false, int>(L, wl, k, G, sc.lrecs, st);
-            else pass = pair ? walk_stage_lanes<true, double>(L, wl, k, G, sc.lrecs, st) : walk_stage_lanes<false, double>(L, wl, k, G, sc.lrecs, st);
-        } else {
-            pass = false;
-            if (lane < k) {
-                const int w = wl[lane];
-                const unsigned xy = L.xyw[w];
-                pass = tile_stage_pass(L.cmA + (xy & 0xffffu), L.rmA + (xy >> 16), L.vnf_s[w], sc.trecs, st, pair);
-            }
-        }
-        // survivors move to the front of the list: every lane reads its entry before any lane writes
-        const int mine = lane < k ? (int)wl[lane] : 0;
-        const unsigned long long pm = __ballot(lane < k && pass);
-        asm volatile("" ::: "memory");
-        if (lane < k && pass) wl[__popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)mine;
-        asm volatile("" ::: "memory");
-        k = __popcll(pm);
+    const int m = (last < kStatStages ? last : kStatStages) - 1;          // stages 1 .. m: the adaptive prefix
+    const bool adapt = a.stage_order && m >= 2;
+    unsigned ordpack = 0x54321u;
+    if (adapt) {
+        // (the word may come from the plan's hint words, which other workgroups write as they go: it is used only if its first m
+        // positions name each of the stages 1 .. m once)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(stat_r[0]);
+        unsigned seen = 0;
+        for (int q = 0; q < m; q++) seen |= 1u << ((o >> (4 * q)) & 15u);
+        if (seen == (2u << m) - 2u) ordpack = o;
     }
+    int kpos = 0, prev = 0; unsigned entered = 0;          // wave-uniform; kpos: stages behind stage 0 already walked
+    auto stage_at = [&](int kp) { return __builtin_amdgcn_readfirstlane((adapt && kp < m) ? (int)((ordpack >> (4 * kp)) & 15u) : kp + 1); };
+    // the record of the round's first stage is requested one round ahead (behind the previous round's barrier it would stand
+    // at the head of a chain of dependent round trips that IS the round when few windows are left)
+    struct I8 { int v[8]; };
+    struct F8 { float v[8]; };
+    const int s_first = last > 1 ? stage_at(0) : 0;
+    StageRec st = load_const(a.stages + s_first);
+    I8 F = load_const((const I8 *)(a.stage_first + s_first));      // first stump of stages s .. s + 7 (the table is padded with INT_MAX); constant indices only: the words stay in scalar registers
+    F8 TH = load_const((const F8 *)(a.stage_thr + s_first));       // the thresholds of stages s .. s + 7
+    while (kpos < last - 1) {
+        const bool in_prefix = adapt && kpos < m;
+        const int s = stage_at(kpos);
+        __syncthreads();             // queue complete (first pass: tile and maps staged as well)
+        NVCA_STAMP(a, ti, 8 + 8 * s);
+        const int n = __builtin_amdgcn_readfirstlane(L.qn[cin]);
+        if (adapt && tid == 0 && prev) stat_w[prev] |= n;        // what the stage before let through
+        if (n == 0) break;
+        NVCA_STAMP_VAL(a, ti, 8 + 8 * s + 7, n);
+        const int cout = cin == 2 ? 0 : cin + 1;
+        if (tid == 0) L.qn[cout == 2 ? 0 : cout + 1] = 0;
+        const unsigned short *qi = L.q0 + cur * kTileSlots;
+        unsigned short *qo = L.q0 + (cur ^ 1) * kTileSlots;
+        const bool pair = a.pair_policy && (st.flags & 1);
+        int adv = 1;
+        if (n <= a.pair_max && (st.flags & 2)) {
+            // ---- lane = (window, stump): all n windows in every wave, G stumps at a time; several stages per round when few windows are left
+            const int G = 64 / n;
+            int mm = 1;
+            if (!in_prefix) {
+                int lim = st.spec_run < last - s ? st.spec_run : last - s;        // consecutive stages from s on whose votes are exact in any order
+                if (lim > 7) lim = 7;
+#pragma unroll
+                for (int q = 1; q < 7; q++)
+                    if (mm == q && q < lim && n * (F.v[q + 1] - F.v[0]) <= a.spec_pairs) mm = q + 1;
+            }
+            const int g0 = F.v[0];
+            int g1 = F.v[1];
+#pragma unroll
+            for (int q = 2; q < 8; q++) if (mm >= q) g1 = F.v[q];
+            const unsigned inv = 65535u / (unsigned)n + 1u;              // floor(l / n) = l * inv >> 16 for l < 64, n <= 64
+            const int cc = (int)(((unsigned)lane * inv) >> 16), j = lane - cc * n;
+            if (cc < G) {
+                const int w = qi[j];
+                const unsigned cm = L.cmA + 2 * L.winx[w & 31], rm = L.rmA + 2 * L.winy[w >> 5];
+                const double vnf = vnf_of(w);
+                for (int g = g0 + wave * G + cc; g < g1; g += NW * G) {
+                    const LRec f = load_lrec(sc.lrecs + g);
+                    const int r = (g >= F.v[1]) + (g >= F.v[2]) + (g >= F.v[3]) + (g >= F.v[4]) + (g >= F.v[5]) + (g >= F.v[6]);      // which of the round's stages (entries behind the round's last stage are larger than any g of the round)
+                    atomicAdd(&L.acc[r * kPairMax + j], lane_vote(cm, rm, vnf, f, a.pair_policy));
+                }
+            }
+            NVCA_STAMP(a, ti, 8 + 8 * s + 1);
+            __syncthreads();
+            NVCA_STAMP(a, ti, 8 + 8 * s + 2);
+            bool pass = false; int w = 0;
+            if (tid < n) {
+                pass = true;
+#pragma unroll
+                for (int r = 0; r < 7; r++)
+                    if (r < mm) {
+                        const double sum = L.acc[r * kPairMax + tid];
+                        L.acc[r * kPairMax + tid] = 0.;
+                        pass = pass && !(sum < (double)TH.v[r]);
+                    }
+                w = qi[tid];
+            }
+            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
+            queue_push_wave0(pass, w, qo, &L.qn[cout]);
+            adv = mm;
+            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
+        } else if (st.flags & 6) {
+            // ---- a window per lane: balanced runs over (window group, stump), accumulators in LDS (integers where flag bit 2 says so, f64 otherwise).
+            // The queue's last, partial group of 64 does not idle its empty lanes: with rem <= 32 windows in it, lane = (window l % rem,
+            // stump l / rem) as in the rounds above -- Gr = 64 / rem stumps of the stage per item instead of one (a third to a half of a
+            // round's items at 60 .. 300 windows were such mostly empty groups)
+            const bool ints = (st.flags & 4) != 0;
+            const int C = st.count;
+            const int rem = n & 63, nfull = n >> 6;
+            const bool rem_pair = rem > 0 && rem <= a.pair_max;
+            const int Gr = rem_pair ? 64 / rem : 1;
+            const int lead = (rem_pair ? nfull : (n + 63) >> 6) * C;          // items of the groups that run a window per lane
+            const int items = lead + (rem_pair ? (C + Gr - 1) / Gr : 0), K = (items + NW - 1) / NW;
+            const double vscale = ints ? __hiloint2double((1023 - st.vote_exp) << 20, 0) : 1.;      // 2^-vote_exp: a vote times it is the integer the record's a0i / a1i hold
+            int e = wave * K;
+            const int e1 = e + K < items ? e + K : items;
+            while (e < e1 && e < lead) {           // at most two window groups per wave (K <= C), wave-uniform
+                const int top = e1 < lead ? e1 : lead;
+                const int wg = e / C, c0 = e - wg * C, c1 = (C - c0 < top - e) ? C : c0 + (top - e);
+                const int i = wg * 64 + lane;
+                if (i < n) {
+                    const int w = qi[i];
+                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                    const double vnf = vnf_of(w);
+                    const unsigned cm = L.cmA + 2 * xw, rm = L.rmA + 2 * yw;
+                    if (ints) {
+                        const int v = pair ? tile_stage_sum<true, int>(cm, rm, vnf, urecs + st.first, c0, c1, 1) : tile_stage_sum<false, int>(cm, rm, vnf, urecs + st.first, c0, c1, 1);
+                        atomicAdd(&acci[i], v);
+                    } else {
+                        const double v = pair ? tile_stage_sum<true, double>(cm, rm, vnf, urecs + st.first, c0, c1, 1) : tile_stage_sum<false, double>(cm, rm, vnf, urecs + st.first, c0, c1, 1);
+                        atomicAdd(&L.acc[i], v);
+                    }
+                }
+                e += c1 - c0;
+            }
+            if (e < e1) {                          // blocks of Gr stumps on the partial group
+                const unsigned inv = 65535u / (unsigned)rem + 1u;
+                const int cc = (int)(((unsigned)lane * inv) >> 16), j = lane - cc * rem;
+                if (cc < Gr) {
+                    const int i = nfull * 64 + j;
+                    const int w = qi[i];
+                    const unsigned cm = L.cmA + 2 * L.winx[w & 31], rm = L.rmA + 2 * L.winy[w >> 5];
+                    const double vnf = vnf_of(w);
+                    double sum = 0.;
+                    for (int c = (e - lead) * Gr + cc; c < (e1 - lead) * Gr && c < C; c += Gr)
+                        sum += lane_vote(cm, rm, vnf, load_lrec(sc.lrecs + st.first + c), a.pair_policy);        // exact in any order (flag bit 1)
+                    if (ints) atomicAdd(&acci[i], (int)(sum * vscale)); else atomicAdd(&L.acc[i], sum);
+                }
+            }
+            NVCA_STAMP(a, ti, 8 + 8 * s + 1);
+            __syncthreads();
+            NVCA_STAMP(a, ti, 8 + 8 * s + 2);
+            bool pass = false; int w = 0;
+            if (tid < n) {
+                if (ints) { const int sa = acci[tid]; acci[tid] = 0; pass = sa >= st.thr_i; }
+                else { const double sa = L.acc[tid]; L.acc[tid] = 0.; pass = !(sa < (double)st.thr); }
+                w = qi[tid];
+            }
+            if (s < kStatStages && tid == 0) stat_w[s] = adapt ? n << 16 : n;
+            if (n <= 64) queue_push_wave0(pass, w, qo, &L.qn[cout]); else queue_push(pass, w, qo, &L.qn[cout]);
+            NVCA_STAMP(a, ti, 8 + 8 * s + 3);
+        } else {
+            // votes whose sums depend on the order (neither flag bit: not seen with f32 votes): window per thread, the stage's stumps in OpenCV's order
+            for (int base = 0; base < n; base += kTileThreads) {
+                const int i = base + tid;
+                bool pass = false; int w = 0;
+                if (i < n) {
+                    w = qi[i];
+                    const int xw = L.winx[w & 31], yw = L.winy[w >> 5];
+                    const double vnf = vnf_of(w);
+                    pass = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, urecs, st, pair);
+                }
+                queue_push(pass, w, qo, &L.qn[cout]);
+            }
+            if (tid == 0 && s < kStatStages) stat_w[s] = adapt ? n << 16 : n;
+        }
+        cur ^= 1; cin = cout;
+        if (in_prefix) { prev = s; entered |= 1u << s; } else prev = 0;
+        kpos += adv;
+        if (kpos < last - 1) {
+            const int sn = stage_at(kpos);
+            st = load_const(a.stages + sn); F = load_const((const I8 *)(a.stage_first + sn)); TH = load_const((const F8 *)(a.stage_thr + sn));
+        }
+    }
+    __syncthreads();
     NVCA_STAMP(a, ti, 6);
-    if (k == 0) return;
+    const int nh = L.qn[cin];
+    if (adapt && tid == 0) {
+        if (prev) stat_w[prev] |= nh;           // the prefix was the whole walk: its last stage's survivors
+        // the order for the next tile.  A stage this tile did not reach, or met with a handful of windows only, keeps what was
+        // known about it; cost of a stage = its stumps per window killed (x 64: integer arithmetic)
+        int key[kStatStages - 1], id[kStatStages - 1];
+        bool known = true;
+#pragma unroll
+        for (int q = 1; q < kStatStages; q++) {
+            int v = stat_w[q];
+            const int old = stat_r[q];
+            if (q <= m && (!((entered >> q) & 1u) || ((v >> 16) < 16 && old != 0))) { v = old; stat_w[q] = v; }
+            const int ent = v >> 16, pas = v & 0xffff, cnt = L.qn[4 + 2 * kStatStages - 1 + q] /* stumps of stage q, left by the kernel's prologue */;
+            if (q <= m && ent == 0) known = false;
+            const int killed = ent - pas > 0 ? ent - pas : 0;
+            key[q - 1] = q > m ? 0x7fffffff : (killed ? (cnt * ent * 64) / killed : 0x7ffffff0);
+            id[q - 1] = q;
+        }
+#pragma unroll
+        for (int pass_i = 0; pass_i < kStatStages - 2; pass_i++)
+#pragma unroll
+            for (int q = 0; q + 1 < kStatStages - 1 - pass_i; q++)
+                if (key[q] / 2 > key[q + 1]) { const int tk = key[q];       /* a stage moves ahead of its predecessor only where it is at least twice as cheap per window killed: the counts are taken at whatever position a stage ran, a near-tie re-ordered on them only stirs the walk */ key[q] = key[q + 1]; key[q + 1] = tk; const int ti2 = id[q]; id[q] = id[q + 1]; id[q + 1] = ti2; }
+        unsigned pack = 0;
+#pragma unroll
+        for (int q = 0; q < kStatStages - 1; q++) pack |= (unsigned)id[q] << (4 * q);
+        stat_w[0] = known ? (int)pack : 0;
+        if (known && a.stage_hint) {            // plain stores of an intentionally racy hint: any mixture of finished tiles' words is a usable start (the order word is validated before use)
+#pragma unroll
+            for (int q = 1; q < kStatStages; q++) a.stage_hint[q] = stat_w[q];
+            a.stage_hint[0] = (int)pack;
+        }
+    }
+    if (nh == 0) return;
     // survivors: final candidates if the cascade ends here, otherwise work for k_deep
     unsigned long long *list = last == a.nstages ? a.hits : a.deep;
     const unsigned cap = last == a.nstages ? a.hit_cap : a.deep_cap;
-    unsigned gb = 0;
-    if (lane == 0) gb = (unsigned)atomicAdd(list, (unsigned long long)k);
-    gb = (unsigned)__shfl((int)gb, 0);
-    if (lane < k) {
-        const int w = wl[lane], ix = t.ix0 + (w & 31);
-        const unsigned key = ((unsigned)t.scale << 26) | ((unsigned)(t.iy0 + (w >> 5)) << 13) | (unsigned)ix;
-        if (gb + lane < cap) list[1 + gb + lane] = ((unsigned long long)slot << 32) | key;
-        if (VNF_OUT && last != a.nstages) {
-            const size_t vbase = ((size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr) * 64;
-            a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
-        }
+    if (tid == 0) L.qn[3] = (int)(unsigned)atomicAdd(list, (unsigned long long)nh);
+    __syncthreads();
+    const unsigned gb = (unsigned)L.qn[3];
+    const unsigned short *qi = L.q0 + cur * kTileSlots;
+    for (int i = tid; i < nh; i += kTileThreads) {
+        const int w = qi[i], ix = t.ix0 + (w & 31);
+        const unsigned key = ((unsigned)t.scale << a.key_ss) | ((unsigned)(t.iy0 + (w >> 5)) << a.key_sy) | (unsigned)ix;
+        if (gb + i < cap) list[1 + gb + i] = ((unsigned long long)slot << 32) | key;
+        if (VNF_LDS && last != a.nstages) a.vnf[vbase + ((size_t)(w >> 5) * sc.wpr + (ix >> 6)) * 64 + (ix & 63)] = L.vnf_s[w];
     }
+    NVCA_STAMP(a, ti, 7);
 }
 
-// the windows a wave keeps after stage 0 (keep: this lane's window is visited and passed) -> its list; returns their number
-__device__ __forceinline__ int wave_list(const TileLds &L, bool keep, int w)
+// the per-workgroup words tile_stages expects before a band's / tile's first round: zero accumulators, the plan's stage
+// statistics (the adaptive order's starting point), the stump counts of stages 1 .. 5
+__device__ __forceinline__ void tile_prologue(const CascadeArgs &a, const TileLds &L)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long km = __ballot(keep);
-    if (keep) L.wl[wave * 64 + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)w;
-    asm volatile("" ::: "memory");
-    return __popcll(km);
+    const int tid = threadIdx.x;
+    L.acc[tid] = 0.;
+    if (tid < 2 * kStatStages) L.qn[4 + tid] = (tid < kStatStages && a.stage_hint) ? a.stage_hint[tid] : 0;
+    if (tid >= 1 && tid < kStatStages) L.qn[4 + 2 * kStatStages - 1 + tid] = tid < a.nstages ? a.stages[tid].count : 0;      // qn[16 .. 20]: behind the two sets of stat words
 }
 
 __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(CascadeArgs a)
@@ -815,31 +991,28 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_tile(C
     const TileLds L = carve_tile(lds, t);
     const TileCoords tc = tile_coords(a, t, sc);
     tile_commit(a, t, sc, slot, L, tc);
+    tile_prologue(a, L);
     const unsigned long long *__restrict__ bits = a.failbits + (size_t)slot * a.ntasks + sc.task_off + (size_t)t.iy0 * sc.wpr;
-    // this thread's window (window id = ry * 32 + rx = tid: a wave holds two window rows): the pre-pass's verdict on it and its
-    // normaliser, under the tile's transfers
+    // this thread's window (window id = ry * 32 + rx = tid): the pre-pass's verdict on it, under the tile's transfers
     const int w = tid, ry = w >> 5, rx = w & 31;
-    bool keep = false; double vnf = 1.;
+    bool keep = false;
     if (ry < t.ny && rx < t.nx) {
         const int ix = t.ix0 + rx;
         const unsigned long long *rb = bits + (size_t)ry * sc.wpr;
         if (!((rb[ix >> 6] >> (ix & 63)) & 1ull)) keep = sc.adaptive ? visited(rb, ix) : true;
-        if (keep) vnf = a.vnf[(((size_t)slot * a.ntasks + sc.task_off + (size_t)(t.iy0 + ry) * sc.wpr) + (ix >> 6)) * 64 + (ix & 63)];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's transfers have landed
-    __syncthreads();                 // maps, origins and samples staged
-    if (keep) { L.xyw[w] = 2u * L.winx[rx] | (2u * L.winy[ry]) << 16; L.vnf_s[w] = vnf; }
-    const int k = wave_list(L, keep, w);
-    wave_walk<false>(a, t, sc, slot, L, k);
+    __syncthreads();                 // qn zeroed, maps and samples staged
+    queue_push(keep, w, L.q0, &L.qn[0]);
+    tile_stages<false>(a, t, sc, slot, L);
 }
 
-// ---- K5: the whole early cascade of a band of window rows in one workgroup ---------------------------------------
+// ---- K5: the whole cascade of a band of window rows in one workgroup ---------------------------------------
 // The workgroup walks the band's tiles left to right.  Per tile: stage the samples, evaluate the window variance and
 // stage 0 for every window from LDS (only the squared-integral corners are global reads), resolve the adaptive x step
 // inside the wave -- a wave holds two whole window rows of the tile, so the reject bits it needs are its own ballot, and the
-// parity of the reject run that reaches the tile's left edge is carried from tile to tile in a register -- then every wave
-// takes its windows through the remaining stages on its own (wave_walk).  Two workgroup barriers per tile: before the tile's
-// samples are replaced and after they have landed.  No stage-0 pre-pass, no per-window global intermediates.
+// parity of the reject run that reaches the tile's left edge is carried from tile to tile in a register -- then run the
+// remaining stages as k_tile does.  No stage-0 pre-pass, no per-window global intermediates.
 __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(CascadeArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -870,10 +1043,11 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
     // head of every tile (768 threads leave the registers for it)
     TileRec t = load_const(a.tiles + b.first_tile);
     TileCoords tc = tile_coords(a, t, sc);
+    tile_prologue(a, carve_tile(lds, t));                  // the fixed part of the carve-up does not depend on the tile
     int oxw = 0, oyw = 0;
     if (ry < t.ny && rx < t.nx) { oxw = a.pos[sc.xpos_off + t.ix0 + rx]; oyw = a.pos[sc.ypos_off + t.iy0 + ry]; }
     for (int ti = 0; ti < b.ntiles; ti++) {
-        __syncthreads();             // every wave is done with the previous tile's LDS
+        __syncthreads();             // previous tile completely done with LDS
         NVCA_STAMP(a, ti, 0);
         const TileLds L = carve_tile(lds, t);
         // this thread's window: the four (eight) squared-integral corners -- uncoalesced global reads -- are requested before the
@@ -890,6 +1064,7 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
         }
         NVCA_STAMP(a, ti, 1);
         tile_commit(a, t, sc, slot, L, tc);
+        if (tid < kStatStages) L.qn[4 + ((ti + 1) & 1) * kStatStages + tid] = 0;       // the survivor counts this tile will write
         TileRec tn = t; TileCoords tcn = tc; int nxw = 0, nyw = 0;
         if (ti + 1 < b.ntiles) {                                 // the next tile's coordinates
             tn = load_const(a.tiles + b.first_tile + ti + 1);
@@ -914,7 +1089,6 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             vnf = vnf * sc.inv_area - mean * mean;
             vnf = vnf >= 0. ? sqrt(vnf) : 1.;
             L.vnf_s[w] = vnf;
-            L.xyw[w] = 2u * (unsigned)xw | (2u * (unsigned)yw) << 16;
             pass0 = tile_stage_pass(L.cmA + 2 * xw, L.rmA + 2 * yw, vnf, sc.trecs, st0, pair0);
         }
         // OpenCV's adaptive x step: a window is visited iff the run of stage-0 rejects immediately left of it in its
@@ -928,8 +1102,8 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
             else {
                 int ones = 0;
                 if (rx > 0) {
-                    const unsigned m = ~(R << (32 - rx));                 // window rx-1 at the MSB, rejects are 0 now
-                    ones = m ? __clz((int)m) : 32;
+                    const unsigned mk = ~(R << (32 - rx));                // window rx-1 at the MSB, rejects are 0 now
+                    ones = mk ? __clz((int)mk) : 32;
                     if (ones > rx) ones = rx;
                 }
                 const int cbit = (int)((carry >> (lane >> 5)) & 1u);
@@ -942,18 +1116,17 @@ __global__ __launch_bounds__(kTileThreads, 2 * kTileThreads / 256) void k_band(C
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const unsigned Rh = h ? (unsigned)(fb >> 32) : (unsigned)fb;
-                const unsigned m = ~(Rh << (32 - t.nx));
-                int ones = m ? __clz((int)m) : 32;
+                const unsigned mk = ~(Rh << (32 - t.nx));
+                int ones = mk ? __clz((int)mk) : 32;
                 if (ones > t.nx) ones = t.nx;
                 const unsigned p = ones == t.nx ? ((unsigned)t.nx + ((carry >> h) & 1u)) & 1u : (unsigned)ones & 1u;
                 nc |= p << h;
             }
             carry = (unsigned)__builtin_amdgcn_readfirstlane((int)nc);
         }
-        const int k = wave_list(L, keep, w);
-        NVCA_STAMP(a, ti, 4); NVCA_STAMP_VAL(a, ti, 5, k);
-        wave_walk<true>(a, t, sc, slot, L, k, ti);
-        NVCA_STAMP(a, ti, 7);
+        queue_push(keep, w, L.q0, &L.qn[0]);
+        NVCA_STAMP(a, ti, 5);
+        tile_stages<true>(a, t, sc, slot, L, ti, ti & 1);
         t = tn; tc = tcn; oxw = nxw; oyw = nyw;
     }
 }
@@ -985,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_deep(CascadeArgs a)
         const unsigned long long e = a.deep[1 + i];
         const int slot = (int)(e >> 32);
         const unsigned key = (unsigned)e;
-        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+        const int s = key >> a.key_ss, iy = (key >> a.key_sy) & ((1u << (a.key_ss - a.key_sy)) - 1u), ix = key & ((1u << a.key_sy) - 1u);
         const ScaleRec &sc = a.scales[s];
         const int *__restrict__ sum = a.sum + (size_t)slot * a.sum_slot + sc.plane_off;
         const unsigned off = (unsigned)(a.pos[sc.ypos_off + iy] * sc.pitch + a.pos[sc.xpos_off + ix]);
@@ -1122,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_group(CascadeArgs a, const int *__restr
     // ---- rectangles + singleton sets
     for (int i = tid; i < n; i += 256) {
         const unsigned key = keys[i];
-        const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+        const int s = key >> a.key_ss, iy = (key >> a.key_sy) & ((1u << (a.key_ss - a.key_sy)) - 1u), ix = key & ((1u << a.key_sy) - 1u);
         const ScaleRec &sc = a.scales[s];
         rects[i] = make_int4(a.pos[sc.xpos_off + ix], a.pos[sc.ypos_off + iy], sc.winw, sc.winh);
         parent[i] = i;

@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include "../../include/nubovca.h"
+#include "host_ranges.h"
 
 namespace nvca {
 
@@ -53,7 +54,9 @@ struct StageRec {
                             // the f64 sum OpenCV forms, whatever the order
     int thr_i;              // pass  <=>  integer sum >= thr_i   (== !(sum * 2^vote_exp < (double)thr))
     int vote_exp;
-    int pad0, pad1;
+    int spec_run;           // stages from this one on, this one included, whose votes are exact in any order (flag bit 1): how far a
+                            // round of the tile kernels may look ahead (tile_stages, several stages per round)
+    int pad1;
 };
 
 struct ScaleRec {           // one evaluated scale
@@ -140,11 +143,11 @@ static constexpr int kTileLdsBudget = 76 * 1024;   // two tiles resident per CU 
 static constexpr int kTileMaxCols = 256;            // staged columns per tile (4 per lane)
 // LDS bytes the tile kernel needs for a tile (host sizing and kernel carve-up agree through these)
 __host__ __device__ inline int tile_pitch(int ncol) { return ncol | 1; }
-// fixed part (carve_tile in kernels_cascade.hip): per-window variance normaliser f64 | per-window map offsets u32 | one window list
-// of 64 u16 per wave | window origins u16 (k_tile) | scratch
+// fixed part (carve_tile in kernels_cascade.hip): stage accumulators (8 B a queue slot) | two window queues | window origins |
+// counters and stage statistics (32 words) | per-window variance normaliser
 __host__ __device__ inline int tile_lds_fixed()
 {
-    return kTileSlots * 8 + kTileSlots * 4 + (kTileThreads / 64) * 64 * 2 + 4 * kTileWin + 64;
+    return kTileSlots * 8 + 2 * kTileSlots * 2 + 4 * kTileWin + 128 + kTileSlots * 8;
 }
 __host__ __device__ inline int tile_lds_bytes(int ncol, int nrow, int span_x, int span_y)
 {
@@ -188,6 +191,9 @@ struct Switches {
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
+    bool stage_order = false;        // NVCA_STAGE_ORDER=1 (0, the default: the cascade's own order on every tile -- the cheapest one for a cascade whose stages each reject about half, as trained ones do; a round then may take two stages at once): the tile kernels walk the early stages 1 .. 5 in the cascade's order on every tile (1: in the order the previous tile of the band found cheapest -- cost per window killed; the set of survivors is the same.  A cascade whose stages each reject about half, as trained ones do, keeps its own order either way)
+    int  pair_max = 32;              // NVCA_PAIR_MAX=n (<= 32): windows up to which a round of the tile kernels runs lane = (window, stump) instead of a window per lane
+    int  spec_pairs = 1536;          // NVCA_SPEC_PAIRS=n: with at most 32 windows left a round takes as many stages as stay within n (window, stump) pairs (768 = one step of the workgroup)
     int  pre_cus = 0;                // NVCA_PRE_CUS=n: a submitted face batch's pre-processing runs on a stream confined to n CUs (hipExtStreamCreateWithCUMask), beside the other batch's band kernel (0: behind it, on the lane's own stream)
     bool quiet = false;              // NVCA_QUIET: no one-time notes on stderr (a plan that falls back to the row-strip kernel)
     const char *stamps_out = nullptr;   // NVCA_STAMPS_OUT (diagnostic build only)
@@ -217,6 +223,15 @@ struct PinnedBuf {
     int ensure(size_t n);
     void release();
     template <class T> T *as() const { return (T *)p; }
+};
+
+// Page-locked memory of the context's own that caller host memory crosses through when it is not page-locked by the caller
+// (nvca_host_register): a ring of fixed slots, each with the event of the last copy that read or wrote it (api.cpp, caller_h2d ...).
+struct BounceRing {
+    static constexpr size_t kSlot = 4u << 20;
+    static constexpr int kSlots = 16;
+    PinnedBuf buf; hipEvent_t ev[kSlots] = {}; bool pending[kSlots] = {}; int next = 0;
+    void release() { for (hipEvent_t &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } buf.release(); }
 };
 
 // tracker workspace (tracker.cpp): slot table, labels, per-root accumulators, component list, frame staging
@@ -281,9 +296,8 @@ struct nvca_ctx {
     hipStream_t pre_streams[2] = {nullptr, nullptr};   // CU-masked streams for the pre-processing of the two face batches in flight ("pre_cus"), created on first use
     int pre_streams_cus = 0;                  // the CU count they were created for
     hipEvent_t pre_done[2] = {nullptr, nullptr};
-    // small host images on their way in and out (api.cpp stage_2d / unstage_2d): page-locked memory of the context's own, handed
-    // out front to back; when it is used up the device is drained and it starts over
-    nvca::PinnedBuf host_stage; size_t host_stage_used = 0;
+    nvca::HostRangeTable host_ranges;         // what the caller page-locked through nvca_host_register (host_ranges.h: the only caller memory a copy is handed as it stands)
+    nvca::BounceRing bounce;                  // everything else crosses through here
     hipStream_t copy_stream = nullptr;        // H2D of the next chunk of host frames while the current one computes
     std::vector<hipEvent_t> chunk_events;
     nvca::FaceTicket *face_tickets[3] = {nullptr, nullptr, nullptr};   // [0] synchronous calls, [1] / [2] submit / collect
@@ -454,10 +468,17 @@ struct CascadeArgs {
     unsigned long long *failbits;             // [batch][ntasks] stage-0 reject bits
     double *vnf;                              // [batch][ntasks*64] variance normaliser per window
     int nstages; int pair_policy;  // 1 = F32PAIR
+    int stage_order;               // Switches::stage_order
+    int *stage_hint;               // [8] per plan: the stat words (order | entered << 16 | passed per stage) the last tile that finished left -- where a band's first tile and the per-tile kernel start from (an intentionally racy hint: plain stores, validated before use)
+    int spec_pairs;                // Switches::spec_pairs
+    int pair_max;                  // Switches::pair_max (<= kPairMax)
+    const float *stage_thr;        // [nstages + 8]: StageRec::thr of every stage (tile_stages reads eight at once)
+    const int *stage_first;        // [nstages + 1 + 8]: first stump of every stage, the stump count, then INT_MAX padding (tile_stages reads eight entries at once)
     int deep_stage;                // first stage evaluated by k_deep (== nstages: the tile kernels walk the whole cascade, k_deep is not launched)
     int deep_lds;                  // bytes of k_deep's largest window patch (dynamic LDS)
     unsigned long long *deep;      // deep[0] = count, then (slot << 32) | key
     unsigned deep_cap;
+    int key_sy, key_ss;            // a candidate's key = scale << key_ss | iy << key_sy | ix: the plan sizes the three fields for its own grids (DetectPlan::key_sy / key_ss), so a ladder of hundreds of scales (multi-scale-factor 1 .. 4) fits next to small grids and a 4K grid next to 25 scales
     unsigned long long *hits;      // hits[0] = running count, hits[1..cap] = (slot << 32) | key
     unsigned hit_cap;
     // general cascades (kernels_cascade.hip)
@@ -546,6 +567,11 @@ void launch_overlay(hipStream_t st, uint8_t *frame, int W, int H, int stride, co
                     int mode, const int *xofs, const short *ialpha, const int *yofs, const short *ibeta, int xmax);
 void launch_draw_shapes(hipStream_t st, uint8_t *data, int w, int h, int stride, int channels, const nvca_shape *d_shapes, int n,
                         int bx0, int by0, int bx1, int by1);
+
+// ---- caller host memory <-> device (api.cpp): direct only inside a range the caller registered, otherwise through the bounce ring
+int caller_h2d(nvca_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st);
+int caller_h2d_rows(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st);
+int caller_d2h_rows(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st);   // returns with dst filled (the stream is drained)
 
 // ---- working images of a batched part call (api.cpp), all on the current lane
 // N images of one launch set: image k = [equalizeHist](resize(source k)) at dst + k * slot, pitch dw.  BGR sources: gray of the frame

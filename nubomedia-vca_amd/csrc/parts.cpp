@@ -368,7 +368,7 @@ try {
         for (FrameGroup &fg : groups) {
             fg.bgr = fg.data;
             if (fg.mem == NVCA_MEM_HOST) {
-                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(arena + fg.upload_at, fg.data, (size_t)fg.stride * (fg.h - 1) + (size_t)fg.w * 3, hipMemcpyHostToDevice, ctx->cs()));
+                CK(caller_h2d(ctx, arena + fg.upload_at, fg.data, (size_t)fg.stride * (fg.h - 1) + (size_t)fg.w * 3, ctx->cs()));
                 fg.bgr = arena + fg.upload_at;
             }
         }

@@ -176,6 +176,8 @@ void build_scale_table(const Cascade &c, double factor, ScaleTable &t)
     std::vector<StageRec> st;
     build_stage_recs(c, st);
     for (const StageRec &sr : st) {
+        if (sr.flags & 1)               // a stage of two-rectangle stumps: where the SSE2 pair form applies, marked in the per-lane records (lane_vote)
+            for (int j = 0; j < sr.count; j++) t.lhost[sr.first + j].yy2 = 1;
         if (!(sr.flags & 4)) continue;
         for (int j = 0; j < sr.count; j++) {
             TStumpRec &r = t.host[sr.first + j];
@@ -217,13 +219,15 @@ void build_stage_recs(const Cascade &c, std::vector<StageRec> &out)
         r.flags = (two_rects ? 1 : 0) | (order_free ? 2 : 0);
         // integer votes: every vote an exact multiple of 2^emin, the sum of their magnitudes (hence every partial sum of every
         // subset) below 2^31 multiples, and the threshold comparable as an integer:  !(S * 2^e < T)  <=>  S >= ceil(T / 2^e)
-        r.thr_i = 0; r.vote_exp = 0; r.pad0 = r.pad1 = 0;
+        r.thr_i = 0; r.vote_exp = 0; r.spec_run = 0; r.pad1 = 0;
         if (finite && emin != INT_MAX && emin != INT_MIN && emin > -1000 && emin < 1000 && std::ldexp(bound, -emin) < 2147483000.0) {
             const double tq = std::ceil(std::ldexp((double)r.thr, -emin));
             if (std::isfinite(tq) && std::fabs(tq) < 2147483000.0) { r.flags |= 4 | 2; r.thr_i = (int)tq; r.vote_exp = emin; }
         }
         out.push_back(r);
     }
+    for (int i = (int)out.size() - 1; i >= 0; i--)
+        out[i].spec_run = (out[i].flags & 2) ? 1 + (i + 1 < (int)out.size() ? out[i + 1].spec_run : 0) : 0;
 }
 
 // Dispatch order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 shares an XCD), each with its
@@ -252,13 +256,13 @@ static int build_xcd_order(const std::vector<long long> &weight, std::vector<int
 
 bool DetectPlan::hit_valid(unsigned key) const
 {
-    const size_t s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+    const size_t s = key >> key_ss, iy = (key >> key_sy) & ((1u << (key_ss - key_sy)) - 1u), ix = key & ((1u << key_sy) - 1u);
     return s < specs.size() && ix < specs[s].xs.size() && iy < specs[s].ys.size();
 }
 
 nvca_rect DetectPlan::hit_rect(unsigned key) const
 {
-    const int s = key >> 26, iy = (key >> 13) & 8191, ix = key & 8191;
+    const int s = key >> key_ss, iy = (key >> key_sy) & ((1u << (key_ss - key_sy)) - 1u), ix = key & ((1u << key_sy) - 1u);
     const ScaleSpec &sp = specs[s];
     const int x = sp.xs[ix], y = sp.ys[iy];
     if (sp.out_factor != 0) return nvca_rect{cv_round(x * sp.out_factor), cv_round(y * sp.out_factor), sp.out_w, sp.out_h};
@@ -295,7 +299,16 @@ int DetectPlan::build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, 
     if (generic) use_tiles = false;              // the LDS tile kernels are built around upright stumps
     (void)allow_tiles;
     tcoords.clear(); tile_lds = 0; bands.clear(); band_order.clear(); band_blocks_per_frame = 0;
-    if (specs.size() > 63) { err = "too many scales"; return NVCA_ERR_ARG; }
+    {   // the candidate key: scale | row | column of the window, each field as wide as THIS plan's grids need (the reference installs
+        // multi-scale-factor with range 0 .. 51 and no clamp, FACE/kmsfacedetect.cpp:540-542: 1.01 on a 640 x 360 working image is a
+        // ladder of 288 scales -- next to grids of at most 310 x 170 windows that is 9 + 8 + 9 bits)
+        auto bits = [](size_t n) { int b = 1; while ((1ull << b) < n) b++; return b; };
+        size_t mx = 1, my = 1;
+        for (const ScaleSpec &sp : specs) { mx = std::max(mx, sp.xs.size()); my = std::max(my, sp.ys.size()); }
+        const int bx = bits(mx), by = bits(my), bs = bits(std::max<size_t>(specs.size(), 1));
+        if (bx + by + bs > 32 || specs.size() > 4095) { err = "scan too large for the candidate key (scales x rows x columns of windows beyond 2^32)"; return NVCA_ERR_ARG; }
+        key_sy = bx; key_ss = bx + by;
+    }
     if (c.stage_rec_cache.empty()) {            // once per cascade
         std::vector<StageRec> tmp; build_stage_recs(c, tmp);
         c.stage_rec_cache.resize(tmp.size() * sizeof(StageRec));
@@ -303,6 +316,13 @@ int DetectPlan::build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, 
     }
     stages.resize(c.stage_rec_cache.size() / sizeof(StageRec));
     if (!stages.empty()) memcpy(stages.data(), c.stage_rec_cache.data(), c.stage_rec_cache.size());
+    stage_first.clear();
+    for (const StageRec &sr : stages) stage_first.push_back(sr.first);
+    stage_first.push_back(stages.empty() ? 0 : stages.back().first + stages.back().count);
+    stage_first.insert(stage_first.end(), 8, INT_MAX);
+    stage_thr.clear();
+    for (const StageRec &sr : stages) stage_thr.push_back(sr.thr);
+    stage_thr.insert(stage_thr.end(), 8, 0.f);
     std::vector<long long> strip_w, tile_w;
     // A scan with few windows (the part detectors' working images and ROIs) cannot fill the GPU with 32 x 32-window tiles: a
     // handful of workgroups would each walk a long chain of stages.  Smaller tiles give more workgroups and, with the same 1024
@@ -341,7 +361,7 @@ int DetectPlan::build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, 
         }
         sr.plane_off = sp.plane_off; sr.pitch = pitch; sr.adaptive = sp.adaptive;
         sr.endX = (int)sp.xs.size(); sr.endY = (int)sp.ys.size();
-        if (sr.endX > 8191 || sr.endY > 8191) { err = "image too large for the candidate key"; return NVCA_ERR_ARG; }
+        if (sr.endY > 8191) { err = "image too large for the task key"; return NVCA_ERR_ARG; }
         sr.xpos_off = (int)pos.size(); pos.insert(pos.end(), sp.xs.begin(), sp.xs.end());
         sr.ypos_off = (int)pos.size(); pos.insert(pos.end(), sp.ys.begin(), sp.ys.end());
         sr.task_off = (int)tasks.size();

@@ -53,6 +53,8 @@ struct DetectPlan {
     std::vector<ScaleTable *> tabs;   // per scale (referenced: refs++ / refs-- in release_tables)
     void release_tables();
     std::vector<StageRec> stages;
+    std::vector<float> stage_thr;     // StageRec::thr of every stage + padding (CascadeArgs::stage_thr)
+    std::vector<int> stage_first;     // first stump of every stage, the stump count, INT_MAX padding (CascadeArgs::stage_first)
     std::vector<StripRec> strips;
     std::vector<int> pos;
     std::vector<unsigned> tasks; // stage-0 wave tasks
@@ -72,11 +74,12 @@ struct DetectPlan {
     std::vector<int> order;      // dispatch slot -> strip (-1 = padding); 8 equal-work chunks, one per XCD
     int blocks_per_frame = 0;
     // device copies
-    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_blob;   // the table buffers are views into d_blob
+    DevBuf d_scales, d_stages, d_strips, d_pos, d_order, d_tasks, d_tiles, d_tile_order, d_tcoords, d_bands, d_band_order, d_deeprecs, d_stage_hint, d_stage_first, d_stage_thr, d_blob;   // the table buffers are views into d_blob (d_stage_hint: 8 words the tile kernels keep their stage statistics in, zero at upload)
 
     std::vector<ScaleSpec> specs;      // host copy (hit -> rectangle)
     int build_custom(nvca_ctx *ctx, const Cascade &c, std::vector<ScaleSpec> &&specs, bool allow_tiles, std::string &err);
     int build_tables(nvca_ctx *ctx, const Cascade &c, bool allow_tiles, std::string &err);      // from `specs` and `deep_stage`
+    int key_sy = 13, key_ss = 26;                   // candidate key layout: scale << key_ss | iy << key_sy | ix (sized per plan in build_tables)
     int min_tile_side = 0, max_tile_side = 0;       // smallest tile side (windows) any scale got / the side asked for
     nvca_rect hit_rect(unsigned key) const;
     bool hit_valid(unsigned key) const;   // the key names a window of this plan's scan grids (a device result is checked before it indexes host tables)

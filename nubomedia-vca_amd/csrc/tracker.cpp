@@ -110,7 +110,7 @@ try {
             memset(&s, 0, sizeof(s));
             if (f.mem == NVCA_MEM_HOST) {
                 uint8_t *d = ws.staging.as<uint8_t>() + off;
-                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(d, f.data, (size_t)f.stride * (H - 1) + (size_t)W * 4, hipMemcpyHostToDevice, ctx->cs()));
+                if (int rc = caller_h2d(ctx, d, f.data, (size_t)f.stride * (H - 1) + (size_t)W * 4, ctx->cs())) return rc;
                 s.src = d; off += ((size_t)f.stride * H + 255) / 256 * 256;
             } else s.src = (const uint8_t *)f.data;
             s.prev = t->prev.as<uint8_t>(); s.mhi = t->mhi.as<float>();

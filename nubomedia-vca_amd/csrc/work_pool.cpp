@@ -26,6 +26,7 @@ void work_pool_run(WorkPool *p, int n, void (*fn)(void *arg, int i), void *arg);
 struct WorkPool {
     std::vector<std::thread> th;
     std::mutex m; std::condition_variable cv;
+    std::mutex run_mu;                                  // one run at a time (the pool is shared by the process's contexts)
     void (*fn)(void *, int) = nullptr; void *arg = nullptr; int n = 0;
     std::atomic<int> next{0}, finished{0}, inside{0}, sleepers{0};
     std::atomic<uint64_t> gen{0};                       // odd: a run is open
@@ -65,35 +66,60 @@ struct WorkPool {
         }
     }
 };
+// One pool per PROCESS, shared by every context that asks for helpers (the GStreamer shim holds a context per GPU slot, a bench
+// may hold several): the first caller sizes it, later callers get the same threads -- contexts do not multiply spinning helpers
+// on an oversubscribed host.  A run is exclusive; a caller that finds the pool busy with another context's run does its own
+// work alone instead of waiting.
+static std::mutex g_pool_mu;
+static WorkPool *g_pool = nullptr;
+static int g_pool_refs = 0;
 WorkPool *work_pool_create(int threads)
 {
     if (threads <= 0) return nullptr;
-    WorkPool *p = new (std::nothrow) WorkPool();
-    if (!p) return nullptr;
-    if (const char *e = getenv("NVCA_HOST_SPIN_US")) p->spin_us = std::max(0, atoi(e));
-    try { for (int i = 0; i < threads; i++) p->th.emplace_back([p] { p->worker(); }); }
-    catch (...) { }                                     // fewer threads than asked for (or none): the caller works anyway
-    return p;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool) {
+        WorkPool *p = new (std::nothrow) WorkPool();
+        if (!p) return nullptr;
+        if (const char *e = getenv("NVCA_HOST_SPIN_US")) p->spin_us = std::max(0, atoi(e));
+        try { for (int i = 0; i < threads; i++) p->th.emplace_back([p] { p->worker(); }); }
+        catch (...) { }                                     // fewer threads than asked for (or none): the caller works anyway
+        g_pool = p;
+    }
+    g_pool_refs++;
+    return g_pool;
 }
 void work_pool_destroy(WorkPool *p)
 {
     if (!p) return;
-    { std::lock_guard<std::mutex> lk(p->m); p->stop.store(true); }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (p != g_pool || --g_pool_refs > 0) return;
+    { std::lock_guard<std::mutex> lk2(p->m); p->stop.store(true); }
     p->cv.notify_all();
     for (std::thread &t : p->th) t.join();
     delete p;
+    g_pool = nullptr;
+}
+// the caller spins briefly for a helper that has taken an index (a run's items are tens of microseconds), then yields the core:
+// a helper descheduled on an oversubscribed host is not waited for at full tilt
+static void wait_until(const std::atomic<int> &v, int target, bool at_least)
+{
+    for (int spins = 0; at_least ? v.load() < target : v.load() != target; spins++) {
+        if (spins < 4096) WorkPool::relax(); else std::this_thread::yield();
+    }
 }
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *, int), void *arg)
 {
     if (!p || p->th.empty() || n < 4) { for (int i = 0; i < n; i++) fn(arg, i); return; }
+    std::unique_lock<std::mutex> run(p->run_mu, std::try_to_lock);
+    if (!run.owns_lock()) { for (int i = 0; i < n; i++) fn(arg, i); return; }      // another context's run is open
     p->fn = fn; p->arg = arg; p->n = n; p->next.store(0); p->finished.store(0);          // (no helper is inside: the previous run waited for that)
     const uint64_t g = p->gen.load() + 1;
     p->gen.store(g);
     if (p->sleepers.load() > 0) { { std::lock_guard<std::mutex> lk(p->m); } p->cv.notify_all(); }      // (through the mutex: a helper between its check and its wait is not missed)
     for (int i; (i = p->next.fetch_add(1)) < n;) { fn(arg, i); p->finished.fetch_add(1); }              // the caller takes part
-    while (p->finished.load() < n) WorkPool::relax();
+    wait_until(p->finished, n, true);
     p->gen.store(g + 1);
-    while (p->inside.load() != 0) WorkPool::relax();
+    wait_until(p->inside, 0, false);
 }
 
 } // namespace nvca

@@ -123,6 +123,21 @@ static int add_branch(GstElement *pipe, int k, int argc, char **argv, const char
         const size_t eq = kv.find('=');
         if (eq == std::string::npos) continue;
         gst_util_set_object_arg(G_OBJECT(el), kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str());
+        // what the element holds afterwards, read back through GObject ("prop <name>=<value>"): a server wrapper's remote method is a
+        // g_object_set on the property it names -- the test double (nubovca/kurento_double.py) checks the round trip
+        if (k == 0) {
+            GParamSpec *ps = g_object_class_find_property(G_OBJECT_GET_CLASS(el), kv.substr(0, eq).c_str());
+            if (!ps) printf("prop %s=<no such property>\n", kv.substr(0, eq).c_str());
+            else {
+                GValue v = G_VALUE_INIT;
+                g_value_init(&v, G_PARAM_SPEC_VALUE_TYPE(ps));
+                g_object_get_property(G_OBJECT(el), ps->name, &v);
+                gchar *txt = g_strdup_value_contents(&v);
+                printf("prop %s=%s\n", kv.substr(0, eq).c_str(), txt);      // under the name the caller used (GObject holds it with '-' for '_')
+                g_free(txt); g_value_unset(&v);
+            }
+            fflush(stdout);
+        }
     }
     gst_bin_add_many(GST_BIN(pipe), src, parse, chain, sink, NULL);
     if (!gst_element_link_many(src, parse, chain, sink, NULL)) { fprintf(stderr, "link failed\n"); return 4; }

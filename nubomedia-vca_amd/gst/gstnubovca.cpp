@@ -42,6 +42,16 @@ static void nvca_gst_caught(const char *where) noexcept
 }
 #define NVCA_GST_CATCH(where, ret) catch (...) { nvca_gst_caught(where); return ret; }
 #define NVCA_GST_CATCH_VOID(where) catch (...) { nvca_gst_caught(where); }
+// The element mutex inside a guarded callback is held through this: when an exception unwinds the try block the mutex is released
+// BEFORE the handler runs -- a streaming thread that caught bad_alloc must not keep the element's GRecMutex locked for good (a
+// property set from the application thread, or finalize, would block on it forever).
+struct NvcaRecLock {
+    GRecMutex *m;
+    explicit NvcaRecLock(GRecMutex *mu) : m(mu) { g_rec_mutex_lock(m); }
+    ~NvcaRecLock() { g_rec_mutex_unlock(m); }
+    NvcaRecLock(const NvcaRecLock &) = delete;
+    NvcaRecLock &operator=(const NvcaRecLock &) = delete;
+};
 #define GST_CAT_DEFAULT nubovca_debug
 
 #define OPENCV_CASCADE_DIR "/usr/share/opencv/haarcascades"     /* FACE/kmsfacedetect.cpp:40 */
@@ -329,7 +339,7 @@ static void face_sync_params(NvcaFace *f) { if (f->stream) nvca_face_stream_set_
 static void nvca_face_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
 try {
     NvcaFace *f = (NvcaFace *)o;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     switch (id) {
     case FP_VIEW: f->view_faces = g_value_get_int(v); break;
     case FP_DETECT_EVENT: f->p.detect_event = g_value_get_int(v); break;
@@ -349,13 +359,12 @@ try {
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
     face_sync_params(f);
-    g_rec_mutex_unlock(&f->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_face_set_property")
 static void nvca_face_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
 try {
     NvcaFace *f = (NvcaFace *)o;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     switch (id) {
     case FP_VIEW: g_value_set_int(v, f->view_faces); break;
     case FP_DETECT_EVENT: g_value_set_int(v, f->p.detect_event); break;
@@ -371,7 +380,6 @@ try {
     case FP_OVERLAY: g_value_set_boxed(v, f->image_to_overlay); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
-    g_rec_mutex_unlock(&f->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_face_get_property")
 
@@ -417,7 +425,7 @@ static void face_lazy_init(NvcaFace *f)
 static GstFlowReturn nvca_face_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
 try {
     NvcaFace *f = (NvcaFace *)filter;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     face_lazy_init(f);
     if (f->stream && f->p.width_to_process > 0) {
         // upstream "motion" messages arm the detector when detect-event = 1
@@ -476,7 +484,6 @@ try {
             }
         }
     }
-    g_rec_mutex_unlock(&f->mutex);
     return GST_FLOW_OK;                                     /* always: FACE/kmsfacedetect.cpp:897 */
 }
 NVCA_GST_CATCH("nvca_face_transform_frame_ip", GST_FLOW_OK)
@@ -562,7 +569,7 @@ static guint trk_signal = 0;
 static void nvca_trk_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
 try {
     NvcaTrk *t = (NvcaTrk *)o;
-    g_rec_mutex_lock(&t->mutex);
+    NvcaRecLock nvca_lock_(&t->mutex);
     switch (id) {
     case TP_THRESHOLD: t->p.threshold = g_value_get_int(v); break;
     case TP_MIN_AREA: t->p.min_area = g_value_get_int(v); break;
@@ -574,13 +581,12 @@ try {
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
     if (t->trk) nvca_tracker_set_params(t->trk, &t->p);
-    g_rec_mutex_unlock(&t->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_trk_set_property")
 static void nvca_trk_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
 try {
     NvcaTrk *t = (NvcaTrk *)o;
-    g_rec_mutex_lock(&t->mutex);
+    NvcaRecLock nvca_lock_(&t->mutex);
     switch (id) {
     case TP_THRESHOLD: g_value_set_int(v, t->p.threshold); break;
     case TP_MIN_AREA: g_value_set_int(v, t->p.min_area); break;
@@ -591,14 +597,13 @@ try {
     case TP_EVENTS_MS: g_value_set_int(v, t->events_ms); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
-    g_rec_mutex_unlock(&t->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_trk_get_property")
 
 static GstFlowReturn nvca_trk_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
 try {
     NvcaTrk *t = (NvcaTrk *)filter;
-    g_rec_mutex_lock(&t->mutex);
+    NvcaRecLock nvca_lock_(&t->mutex);
     if (!t->trk) { if (!t->slot) t->slot = take_slot(); nvca_ctx *ctx = t->slot->ctx; if (ctx && nvca_tracker_create(ctx, &t->p, &t->trk) != NVCA_OK) t->trk = nullptr; }
     if (t->trk) {
         note_frame_memory(t->slot, frame);
@@ -635,7 +640,6 @@ try {
         }
         g_free(bx);
     }
-    g_rec_mutex_unlock(&t->mutex);
     return GST_FLOW_OK;
 }
 NVCA_GST_CATCH("nvca_trk_transform_frame_ip", GST_FLOW_OK)
@@ -718,7 +722,7 @@ enum { PP_0, PP_VIEW, PP_DETECT_EVENT, PP_META, PP_WIDTH, PP_X_EVERY_4, PP_SCALE
 static void nvca_part_set_property(GObject *o, guint id, const GValue *v, GParamSpec *ps)
 try {
     NvcaPart *f = (NvcaPart *)o;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     switch (id) {
     case PP_VIEW: f->view = g_value_get_int(v); break;
     case PP_DETECT_EVENT: f->p.detect_event = g_value_get_int(v); break;
@@ -735,13 +739,12 @@ try {
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
     if (f->stream) nvca_part_stream_set_params(f->stream, &f->p);
-    g_rec_mutex_unlock(&f->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_part_set_property")
 static void nvca_part_get_property(GObject *o, guint id, GValue *v, GParamSpec *ps)
 try {
     NvcaPart *f = (NvcaPart *)o;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     switch (id) {
     case PP_VIEW: g_value_set_int(v, f->view); break;
     case PP_DETECT_EVENT: g_value_set_int(v, f->p.detect_event); break;
@@ -754,7 +757,6 @@ try {
     case PP_OVERLAY: g_value_set_boxed(v, f->image_to_overlay); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, ps); break;
     }
-    g_rec_mutex_unlock(&f->mutex);
 }
 NVCA_GST_CATCH_VOID("nvca_part_get_property")
 
@@ -783,7 +785,7 @@ try {
     NvcaPart *f = (NvcaPart *)trans;
     if (GST_EVENT_TYPE(event) == GST_EVENT_CUSTOM_DOWNSTREAM && f->desc->kind != NVCA_PART_EAR) {
         const GstStructure *m = gst_event_get_structure(event);
-        g_rec_mutex_lock(&f->mutex);
+        NvcaRecLock nvca_lock_(&f->mutex);
         if (m && f->p.detect_event) {
             part_lazy_init(f);
             nvca_rect faces[64]; int n = 0;
@@ -803,7 +805,6 @@ try {
             }
             if (f->stream) nvca_part_stream_push_faces(f->stream, faces, n);
         }
-        g_rec_mutex_unlock(&f->mutex);
     }
     return GST_BASE_TRANSFORM_CLASS(f->desc->parent_class)->sink_event(trans, event);
 }
@@ -826,7 +827,7 @@ static std::string box_str(const nvca_rect &r)
 static GstFlowReturn nvca_part_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
 try {
     NvcaPart *f = (NvcaPart *)filter;
-    g_rec_mutex_lock(&f->mutex);
+    NvcaRecLock nvca_lock_(&f->mutex);
     part_lazy_init(f);
     if (f->stream && f->p.width_to_process > 0) {
         note_frame_memory(f->slot, frame);
@@ -906,7 +907,6 @@ try {
             }
         }
     }
-    g_rec_mutex_unlock(&f->mutex);
     return GST_FLOW_OK;
 }
 NVCA_GST_CATCH("nvca_part_transform_frame_ip", GST_FLOW_OK)

@@ -125,13 +125,17 @@ static int check_plan(const Cascade &c, const DetectPlan &dp, int cols, int rows
     // candidate keys round-trip through hit_valid / hit_rect for every scale's last window, and junk keys are refused
     for (size_t s = 0; s < dp.specs.size(); s++) {
         if (dp.specs[s].xs.empty() || dp.specs[s].ys.empty()) continue;
-        const unsigned key = ((unsigned)s << 26) | ((unsigned)(dp.specs[s].ys.size() - 1) << 13) | (unsigned)(dp.specs[s].xs.size() - 1);
+        const unsigned key = ((unsigned)s << dp.key_ss) | ((unsigned)(dp.specs[s].ys.size() - 1) << dp.key_sy) | (unsigned)(dp.specs[s].xs.size() - 1);
         if (!dp.hit_valid(key)) return fail("hit_valid refuses a real window");
         const nvca_rect r = dp.hit_rect(key);
         if (r.x + r.w > cols || r.y + r.h > rows) return fail("window outside the image");
-        if (dp.hit_valid(key + 1) || dp.hit_valid(key + (1u << 13))) return fail("hit_valid accepts a window beyond the grid");
+        // one past the grid in x / in y, where the key's field can express it (the fields are sized for the plan's largest grid: a
+        // full field would carry into the next one and name another, real window)
+        const size_t nx = dp.specs[s].xs.size(), ny = dp.specs[s].ys.size();
+        if (nx < (1u << dp.key_sy) && dp.hit_valid(key + 1)) return fail("hit_valid accepts a window beyond the grid (x)");
+        if (ny < (1u << (dp.key_ss - dp.key_sy)) && dp.hit_valid(key + (1u << dp.key_sy))) return fail("hit_valid accepts a window beyond the grid (y)");
     }
-    if (dp.hit_valid(63u << 26)) return fail("hit_valid accepts an unknown scale");
+    if (dp.key_ss < 32 && dp.hit_valid((unsigned)dp.specs.size() << dp.key_ss)) return fail("hit_valid accepts an unknown scale");
     (void)c;
     return 0;
 }

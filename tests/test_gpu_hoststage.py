@@ -1,6 +1,8 @@
-"""Small host images go in and out through page-locked memory of the context (csrc/api.cpp stage_2d / unstage_2d: 8 MB handed out
-front to back, the device drained when it is used up).  More than that in one context -- odd widths, images of every size up
-to the 2 MB limit and one beyond it (the runtime's own 2-D copy) -- every result against the oracle."""
+"""Caller host memory reaches the HIP runtime as a raw pointer only inside a range the caller registered (nvca_host_register);
+everything else crosses through page-locked slots of the context's own (csrc/api.cpp caller_h2d / caller_h2d_rows / caller_d2h_rows:
+16 slots of 4 MB, each waited for before it is used again).  More than the ring holds in one context -- odd widths, images
+from one pixel row to several slots -- and memory that WAS registered and is pageable again (the history of the round-3 memory
+access fault); every result against the oracle."""
 import numpy as np
 import pytest
 
@@ -28,4 +30,46 @@ def test_more_small_host_images_than_the_staging_memory_holds(ctx):
             s, q = ctx.integral(img)
             es, eq = orc.integral(img)
             assert np.array_equal(s, es) and np.array_equal(q, eq), (it, w, h)
-    assert moved > 3 * (8 << 20)            # the staging memory was used up and started over several times
+    assert moved > 3 * (8 << 20)            # several turns of the ring
+
+
+@pytest.mark.gpu
+def test_released_ranges_are_pageable_memory_again(ctx, synth_xml):
+    """the order of calls that preceded the round-3 fault: host frames page-locked, used by a batched call, released; then small and
+    large images out of the SAME heap memory through the pageable path (detectMultiScale on a 97 x 83 image among them).  Registering
+    a range twice, or releasing a pointer that was never registered, is an argument error, not a call into the runtime."""
+    import orc
+    from nubovca import capi, synth
+    casc = ctx.load_cascade_xml(synth_xml)
+    oc = orc.parse_cascade_xml(synth_xml)
+    W, H, N = 400, 300, 10
+    pool = np.empty((N, H, W, 3), np.uint8)                      # one block: the frames, later the small images, live in the same pages
+    for i in range(N):
+        pool[i] = synth.make_bgr(W, H, 1900 + i, "natural", [(20 + 10 * i, 30, 120)])
+    for rep in range(3):
+        for i in range(N):
+            ctx.host_register(pool[i])
+        with pytest.raises(capi.NvcaError):
+            ctx.host_register(pool[0])                           # already registered
+        streams = [capi.FaceStream(ctx, casc, width_to_process=W, multi_scale_factor=10) for _ in range(N)]
+        tk = ctx.face_batch_submit(streams, [capi.make_frame(pool[i]) for i in range(N)])
+        for i in range(N):
+            ctx.host_unregister(pool[i])                         # with the batch still in flight: every stream that carried a copy is drained first
+        res = ctx.face_batch_collect(tk)
+        for i in range(N):
+            eb, eid = orc.FaceStream(oc, width_to_process=W, scale_factor_pct=10).process(pool[i])
+            assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (rep, i)
+        with pytest.raises(capi.NvcaError):
+            ctx.host_unregister(pool[0])                         # not registered any more
+        # the same pages as pageable memory: views into the block
+        small = pool.reshape(-1)[: 97 * 83].reshape(83, 97)
+        g = synth.make_gray(97, 83, 77 + rep, "natural", [(10, 8, 60)])
+        small[:] = g
+        got = ctx.detect_raw(casc, small, 1.1, capi.HAAR_SCALE_IMAGE, (3, 3))
+        exp = orc.detect_raw(oc, g, 1.1, orc.HAAR_SCALE_IMAGE, (3, 3))
+        assert np.array_equal(np.asarray(got).reshape(-1, 4), np.asarray(exp).reshape(-1, 4)), rep
+        big = pool.reshape(-1)[: 1100 * 2048].reshape(1100, 2048)
+        big[:] = np.random.default_rng(rep).integers(0, 256, size=big.shape, dtype=np.uint8)
+        assert np.array_equal(ctx.equalize_hist(big), orc.equalize_hist(big)), rep
+        for i in range(N):                                       # put the frames back for the next turn
+            pool[i] = synth.make_bgr(W, H, 1900 + i, "natural", [(20 + 10 * i, 30, 120)])

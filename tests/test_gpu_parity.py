@@ -550,6 +550,37 @@ def test_face_batch_registered_host_frames(ctx, casc, orc_cascade):
             ctx.host_unregister(f)
 
 
+@pytest.mark.parametrize("w2p", [160, 640])
+@pytest.mark.parametrize("msf", [1, 2, 4])
+def test_face_stream_every_legal_multi_scale_factor(ctx, casc, orc_cascade, w2p, msf):
+    """multi-scale-factor is installed with range 0 .. 51 and no clamp (FACE/kmsfacedetect.cpp:540-542, 1084-1087): 1, 2 and 4 are ladders
+    of 73 .. 290 scales on the 160 x 90 and 640 x 360 working images -- more than the 63 a candidate key used to hold.  The key's
+    fields are sized per plan now; boxes and ids against the oracle.  Value 0 (scaleFactor 1.0: OpenCV's assertion) stays an error."""
+    import orc
+    from nubovca import capi, synth
+    W, H = 640, 360
+    frames = [synth.make_bgr(W, H, 4300 + i, "natural", [(60 + 12 * i, 40, 150 + 6 * i), (380, 120 + 5 * i, 110)]) for i in range(3)]
+    fs = capi.FaceStream(ctx, casc, width_to_process=w2p, multi_scale_factor=msf)
+    ofs = orc.FaceStream(orc_cascade, width_to_process=w2p, scale_factor_pct=msf)
+    seen = 0
+    for f in frames:
+        b, ids = fs.process(f)
+        eb, eid = ofs.process(f)
+        assert np.array_equal(b, eb) and np.array_equal(ids, eid), (w2p, msf, b, eb)
+        seen += len(eb)
+    assert seen >= 2
+    res = ctx.face_batch_process([fs] * 3, [capi.make_frame(f) for f in frames])       # the batched entry point on the same ladder
+    for i, f in enumerate(frames):
+        eb, eid = ofs.process(f)
+        assert np.array_equal(res[i][0], eb) and np.array_equal(res[i][1], eid), (w2p, msf, i)
+    fs.close()
+    bad = capi.FaceStream(ctx, casc, width_to_process=w2p, multi_scale_factor=0)
+    with pytest.raises(capi.NvcaError) as ei:
+        bad.process(frames[0])
+    assert ei.value.code == capi.ERR_ARG
+    bad.close()
+
+
 def test_face_stream_device_frames(ctx, casc, orc_cascade):
     """frames already resident in HBM (torch tensors) give the same boxes as host frames."""
     import orc

@@ -252,8 +252,8 @@ def test_part_batch_more_images_than_one_job_carries(env):
 
 
 def test_part_batch_late_failure_leaves_every_stream_untouched(env):
-    """A batched call that fails AFTER the gates have advanced (one eye stream whose face pass has more scales than a plan
-    carries: multi-scale-factor 1 -> 1.01) returns an error and leaves every stream of the call as it found it: frame gates,
+    """A batched call that fails AFTER the gates have advanced (one eye stream whose face pass cannot be planned: multi-scale-factor 0
+    is scaleFactor 1.0, where OpenCV's assertion fires) returns an error and leaves every stream of the call as it found it: frame gates,
     queued face events (detect-event streams) and result lists.  The streams then run on -- one by one, as the GStreamer shim
     does after a refused batch -- exactly like streams that never saw the failed call."""
     from nubovca import capi
@@ -261,7 +261,7 @@ def test_part_batch_late_failure_leaves_every_stream_untouched(env):
     frames = _scene(640, 480, 6, 5150)
     fs = capi.FaceStream(ctx, dev["face"])
     good = [_streams(env, "nose", process_x_every_4_frames=2), _streams(env, "mouth", detect_event=1), _streams(env, "ear")]
-    bad = capi.PartStream(ctx, 0, dev["face"], dev["righteye"], dev["lefteye"], multi_scale_factor=1)
+    bad = capi.PartStream(ctx, 0, dev["face"], dev["righteye"], dev["lefteye"], multi_scale_factor=0)
     tot = 0
     for t, f in enumerate(frames):
         boxes, _ = fs.process(f)

@@ -160,3 +160,18 @@ def test_work_pool_under_thread_sanitizer():
     r = subprocess.run([out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "pool ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_host_range_bookkeeping_under_sanitizers():
+    """which caller memory may reach the runtime as a raw pointer, and which streams nvca_host_unregister drains before the pages go
+    (csrc/host_ranges.h): direct copies only inside a range that is registered NOW, released ranges are bounced like any memory,
+    unregister waits for the copy stream and the lanes that carried copies of the range, not only the context's own stream"""
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ with sanitizer runtimes")
+    out = os.path.join(SAN, "build", "ranges_driver")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    src = os.path.join(SAN, "ranges_driver.cpp")
+    r = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-w", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ranges ok" in r.stdout, (r.stdout, r.stderr[-3000:])
