@@ -43,6 +43,17 @@ def algorithmic_bytes(W, H, w, h, n_boxes=0):
             "total": gray + integral + cascade}
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel and host sources of the library: what profiles/pmc_traffic.json was collected on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nubomedia-vca_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(xml, frames_np, params, budget_s=12.0, max_frames=48):
     """The CPU oracle (a restatement of the reference's OpenCV-2.4 path, NOT OpenCV itself) timed on this box's host
     cores on a bounded sample of the same workload: one stream per thread (the reference runs one element per streaming
@@ -111,7 +122,7 @@ def oracle_expected(xml, frames_np, params, rows, multi_stream):
     return last
 
 
-def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
+def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
     """Figures a pipeline sees that the headline (device-resident, F frames per call) does not show; each a few untimed-
     warm-up + timed calls, never `value`: one frame per call (latency mode), host frames incl. the PCIe copy (pageable and
     page-locked), and the content sweep of SURVEY.md 8d (uniform noise; gradient + K pasted templates)."""
@@ -230,45 +241,74 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
     f720, ms720, f720s, ms720s = multi(1280, 720, 32, False)
     ftrk, mstrk, ftrks, mstrks = multi(1920, 1080, 8, True)
     # BASELINE configs[2]: the face -> eye / nose / mouth / ear chain on V concurrent 1080p streams, batched entry points
-    def roi_chain(base, V=8, ticks=4, reps=6):
-        pcs = {nm: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(nm)) for nm in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
-        fcs = [capi.FaceStream(ctx, casc, width_to_process=1920, multi_scale_factor=props["multi_scale_factor"]) for _ in range(V)]
+    def roi_chain(base, V=8, ticks=4, reps=6, contexts=1, calibrated=True):
+        """V video streams x (face detector + eye + nose + mouth + ear detectors, own face pass each) per tick.  contexts = 2: the streams
+        are dealt to two contexts of this GPU, a serving thread each (what the GStreamer shim does with NVCA_VIRTUAL_GPUS=2: a
+        context per slot) -- one context's host work between its three waits runs beside the other's kernels."""
+        import threading
+        part_xml = synth.calibrated_part_cascade_xml if calibrated else synth.synthetic_part_cascade_xml
+        names = ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")
         kinds = [(0, "righteye", "lefteye"), (1, "nose", None), (2, "mouth", None), (3, "leftear", "rightear")]
-        parts = [capi.PartStream(ctx, k, casc, pcs[a], pcs[b] if b else None) for _ in range(V) for k, a, b in kinds]
         keep = [[torch.from_numpy(synth.make_bgr(1920, 1080, 40 + 5 * t + v, "natural", [(x + 8 * t + 6 * v, y + 3 * v, sz + 4 * ((t + v) % 3)) for x, y, sz in base])).to(dev) for v in range(V)]
                 for t in range(ticks)]
         torch.cuda.synchronize()
         frs = [[capi.make_frame(x.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for x in row] for row in keep]
-        found = [0]
+        cx = [ctx] + [capi.Context(dev.index or 0) for _ in range(contexts - 1)]
+        share = [list(range(c, V, contexts)) for c in range(contexts)]           # video streams of context c
+        S = []
+        for c, cc in enumerate(cx):
+            fcas = casc if c == 0 else cc.load_cascade_xml(xml_face)
+            pcs = {nm: cc.load_cascade_xml(part_xml(nm)) for nm in names}
+            fcs = [capi.FaceStream(cc, fcas, width_to_process=1920, multi_scale_factor=props["multi_scale_factor"]) for _ in share[c]]
+            parts = [capi.PartStream(cc, k, fcas, pcs[a], pcs[b] if b else None) for _ in share[c] for k, a, b in kinds]
+            S.append((cc, fcs, parts))
+        found = [0] * contexts
 
-        def tick(i):
-            fb = frs[i % ticks]
-            tk = ctx.face_batch_submit(fcs, fb)            # the face detector's batch runs under the part detectors' call
-            res = capi.part_batch_process(ctx, parts, [fb[v] for v in range(V) for _ in range(4)])
-            ctx.face_batch_collect(tk)
-            found[0] += sum(len(a) + len(b) for a, b in res)
-        for i in range(2 * ticks):                         # two turns through the frame sets: plans, tables and buffers are in place
-            tick(i)
-        ctx.synchronize()
-        found[0] = 0
+        def tick(c, i):
+            cc, fcs, parts = S[c]
+            fb = [frs[i % ticks][v] for v in share[c]]
+            tk = cc.face_batch_submit(fcs, fb)            # the face detector's batch runs under the part detectors' call
+            res = capi.part_batch_process(cc, parts, [f for f in fb for _ in range(4)])
+            cc.face_batch_collect(tk)
+            found[c] += sum(len(a) + len(b) for a, b in res)
+
+        def run(i0, i1):
+            if contexts == 1:
+                for i in range(i0, i1):
+                    tick(0, i)
+            else:
+                th = [threading.Thread(target=lambda c=c: [tick(c, i) for i in range(i0, i1)]) for c in range(contexts)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+            for cc, _, _ in S:
+                cc.synchronize()
+        run(0, 2 * ticks)                                  # two turns through the frame sets: plans, tables and buffers are in place
+        found[:] = [0] * contexts
         t0 = time.perf_counter()
-        for i in range(2 * ticks, 2 * ticks + reps * ticks):
-            tick(i)
-        ctx.synchronize()
+        run(2 * ticks, 2 * ticks + reps * ticks)
         dt = time.perf_counter() - t0
-        nparts = found[0] / (V * reps * ticks)
+        nparts = sum(found) / (V * reps * ticks)
         # launches per tick: a separate pass with an event pair on every launch (they serialise the launches: not the rate above)
-        ctx.enable_kernel_timing(1)
+        launches = 0
+        for c, (cc, _, _) in enumerate(S):
+            cc.enable_kernel_timing(1)
         for i in range(ticks):
-            tick(i)
-        ctx.synchronize()
-        kt = ctx.kernel_timing()
-        ctx.enable_kernel_timing(0)
-        launches = sum(v[1] for v in kt.values()) / ticks
-        for st in fcs:
-            st.close()
-        for pt in parts:
-            pt.close()
+            for c in range(contexts):
+                tick(c, i)
+        for cc, _, _ in S:
+            cc.synchronize()
+            kt = cc.kernel_timing()
+            cc.enable_kernel_timing(0)
+            launches += sum(v[1] for v in kt.values()) / ticks
+        for cc, fcs, parts in S:
+            for st in fcs:
+                st.close()
+            for pt in parts:
+                pt.close()
+        for cc in cx[1:]:
+            cc.close()
         # algorithmic bytes per video frame (SURVEY.md 8d's formula per working image): the face detector's 60.21 MB plus, per part
         # detector, BGR in + gray out / in, plus the small working images' integral pairs written and read
         alg = 60.21e6 + 4 * (3 * 1920 * 1080 + 2 * 1920 * 1080) + 4 * 25 * (320 * 180 + 160 * 90)
@@ -280,12 +320,20 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args):
     # 20-pixel windows on the 320-pixel working image: the search phase is loaded (11 parts per frame).  Round 2's workload -- four
     # faces of 120-300 pixels, whose parts stay below those windows: 0.3 parts per frame, the search phase idle -- is kept as
     # `roi_chain_sparse` for continuity with the figures quoted then
-    froi, msroi, nparts, roiroof = roi_chain([(150, 200, 560), (1100, 260, 620)]) if (W, H) == (1920, 1080) else (None, None, None, None)
-    fsp, mssp, npsp, rsp = roi_chain([(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]) if (W, H) == (1920, 1080) else (None, None, None, None)
+    big = [(150, 200, 560), (1100, 260, 620)]
+    on1080 = (W, H) == (1920, 1080)
+    froi, msroi, nparts, roiroof = roi_chain(big) if on1080 else (None, None, None, None)
+    froi2, msroi2, nparts2, roiroof2 = roi_chain(big, contexts=2) if on1080 else (None, None, None, None)
+    fold, msold, npold, rold = roi_chain(big, calibrated=False) if on1080 else (None, None, None, None)
+    fsp, mssp, npsp, rsp = roi_chain([(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)], calibrated=False) if on1080 else (None, None, None, None)
     tab["workloads"] = {"roi_chain": {"frames_per_s": froi, "ms_per_tick": msroi, "streams": 8, "parts_per_frame": nparts, "roofline": roiroof,
-                                      "note": "BASELINE configs[2]: 8 x 1080p streams x (face detector + eye + nose + mouth + ear, own face pass each), nvca_face_batch_submit/collect around nvca_part_batch_process; scripts/bench_roi_chain.py gives the breakdown"},
+                                      "note": "BASELINE configs[2]: 8 x 1080p streams x (face detector + eye + nose + mouth + ear, own face pass each), nvca_face_batch_submit/collect around nvca_part_batch_process, one context, one serving thread; part cascades calibrated on face regions (every early stage lets ~2/3 through); scripts/bench_roi_chain.py gives the breakdown"},
+                        "roi_chain_2ctx": {"frames_per_s": froi2, "ms_per_tick": msroi2, "streams": 8, "parts_per_frame": nparts2, "roofline": roiroof2,
+                                           "note": "the same 8 streams dealt to two contexts of this GPU with a serving thread each (the GStreamer shim's NVCA_VIRTUAL_GPUS=2): one context's host work between its waits runs beside the other's kernels"},
+                        "roi_chain_standin_parts": {"frames_per_s": fold, "ms_per_tick": msold, "streams": 8, "parts_per_frame": npold, "roofline": rold,
+                                                    "note": "as roi_chain with rounds 2-3's uncalibrated part cascades (their early stages let ~150 windows per face region through to the late stages)"},
                         "roi_chain_sparse": {"frames_per_s": fsp, "ms_per_tick": mssp, "streams": 8, "parts_per_frame": npsp, "roofline": rsp,
-                                             "note": "the same chain on round 2's frames (faces of 120-300 pixels: their parts never reach the part cascades' windows, the searches find almost nothing)"},
+                                             "note": "the same chain on round 2's frames (faces of 120-300 pixels: their parts never reach the part cascades' windows, the searches find almost nothing), uncalibrated part cascades"},
                         "streams720p": {"frames_per_s": f720, "ms_per_tick": ms720, "streams": 32, "frames_per_s_sync": f720s, "ms_per_tick_sync": ms720s,
                                         "note": "BASELINE configs[3] per GPU: 32 independent 1280x720 streams, one frame each per tick; serving loop as the headline (the next tick submitted before this one is collected); _sync: one synchronous call per tick"},
                         "face_tracker": {"frames_per_s": ftrk, "ms_per_tick": mstrk, "streams": 8, "frames_per_s_sync": ftrks, "ms_per_tick_sync": mstrks,
@@ -388,6 +436,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = torch.device("cpu") if rehearsal else dev
 
+    # helper threads of the library (per-job host work, host-frame copies): a rank takes its share of the box's cores, no more --
+    # N ranks x (a serving loop + up to 7 spinning helpers) would oversubscribe the host at N = 8
+    try:
+        _cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        _cores = os.cpu_count() or 1
+    os.environ.setdefault("NVCA_HOST_THREADS", str(max(0, min(7, _cores // max(world, 1) - 1))))
     from nubovca import capi, synth
     if args.workload == "streams720p":
         args.width, args.height = 1280, 720
@@ -407,15 +462,26 @@ def main():
 
     base_faces = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)][:args.faces]
     sx, sy = W / 1920.0, H / 1080.0
-    TICKS = 4 if multi_stream else 1
+    TICKS = 4
     frames_np = []          # [tick][slot]
     if not multi_stream:
-        # F consecutive synthetic frames of this rank's stream (stream id = rank), faces drifting 8 px/frame
-        row = []
-        for i in range(F):
-            faces = [(int((x + 8 * i) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in base_faces]
-            row.append(synth.make_bgr(W, H, synth.frame_seed(rank, i), args.content, faces))
-        frames_np.append(row)
+        # 4 x F consecutive synthetic frames of this rank's stream (stream id = rank), faces drifting 8 px/frame: four DISTINCT sets of F
+        # frames cycled through the timed steps -- 4 x 199 MB of input at 32 x 1080p, beyond the 256 MB Infinity Cache, so no step
+        # finds its frames on-die.  Sets 1 .. 3 are the 1/f fields of set 0 mirrored (left-right, top-bottom, both: other bytes at
+        # every address, the same statistics, a quarter of the generation time) with the templates pasted afterwards.
+        base = [synth.make_gray(W, H, synth.frame_seed(rank, i), args.content) for i in range(F)]
+        for r in range(TICKS):
+            row = []
+            for i in range(F):
+                g = base[i]
+                if r & 1:
+                    g = g[:, ::-1]
+                if r & 2:
+                    g = g[::-1]
+                k = r * F + i
+                faces = [(int(((x + 8 * k) % 1500) * sx), int(y * sy), int(s * min(sx, sy))) for (x, y, s) in base_faces]
+                row.append(synth.gray_to_bgr(synth.paste_faces(np.ascontiguousarray(g), faces, synth.frame_seed(rank, k)), synth.frame_seed(rank, k)))
+            frames_np.append(row)
     else:
         # F streams (ids rank*F..), static per-stream background, templates moving 8 px per tick
         bgs = [synth.make_gray(W, H, synth.frame_seed(rank * F + s, 0), args.content) for s in range(F)]
@@ -533,26 +599,30 @@ def main():
                                "alg_bytes_per_launch": bytes_per_launch,
                                "achieved_GBs": bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0}
         dom = max(kern, key=lambda k: kern[k]["ms_per_launch"]) if kern else None
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # the PMC-derived per-launch figures only describe the configuration they were collected on
-        pmc_ok = False
+        # The PMC-derived per-launch figures are NOT counters of this run: they come from profiles/pmc_traffic.json (separate
+        # rocprofv3 --pmc passes of this command line).  They are quoted only for the configuration AND the kernel sources they were
+        # collected on (a hash of csrc/ is stored with them), with their source named; otherwise traffic is null.
+        pmc_ok, pmc_doc = False, {}
         if os.path.exists(tpath):
             try:
-                cfg = json.load(open(tpath)).get("_config", {})
+                pmc_doc = json.load(open(tpath))
+                cfg = pmc_doc.get("_config", {})
                 pmc_ok = (cfg.get("workload") == args.workload and cfg.get("width") == W and cfg.get("height") == H and
-                          cfg.get("frames_per_launch") == F and not args.host_frames and (w, h) == (W, H))
+                          cfg.get("frames_per_launch") == F and not args.host_frames and (w, h) == (W, H) and
+                          cfg.get("cascade") == args.cascade and cfg.get("src_sha16") == source_hash())
             except Exception:
                 pmc_ok = False
         if dom and pmc_ok:
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+            traffic = pmc_doc.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s; kernel sources %s)" % (pmc_doc.get("_config", {}).get("collected", "?"), source_hash())
+        elif dom:
+            traffic_source = "none: profiles/pmc_traffic.json was collected on another configuration or on other kernel sources"
         lds = None
         if dom and pmc_ok:
             try:        # the dominant kernel works out of LDS: also price it against the LDS peak
-                lb = json.load(open(tpath)).get(dom, {}).get("lds_bytes_per_launch")
+                lb = pmc_doc.get(dom, {}).get("lds_bytes_per_launch")
                 if lb:
                     peak = 128.0 * 256 * 2.4                     # B/clk/CU x CUs x GHz = GB/s
                     ach = lb / (kern[dom]["ms_per_launch"] * 1e-3) / 1e9
@@ -564,7 +634,7 @@ def main():
         if dom:
             a = kern[dom]["achieved_GBs"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": a / HBM_PEAK_GBS, "traffic": traffic,
+                        "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                         "pipeline_achieved": ab["total"] * (fps / world) / 1e9,
                         "pipeline_frac": ab["total"] * (fps / world) / 1e9 / HBM_PEAK_GBS,
                         "kernels": kern, "lds": lds,
@@ -591,7 +661,7 @@ def main():
                                      "NuboFaceDetector + NuboTracker %dx%d, one frame of each of %d streams per GPU per step" % (W, H, F))
                                     ) % ((W, H) if not multi_stream else ()) +
                                    ", working image %dx%d, scaleFactor %.2f, minNeighbors 3, minSize (w/20,h/20)" % (w, h, 1 + args.scale_factor_pct / 100.0),
-                       "frames_per_step": F, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
+                       "frames_per_step": F, "frame_sets": TICKS, "input_bytes_cycled": TICKS * F * W * H * 3, "streams": world * (F if multi_stream else 1), "frames_resident": ("host-pinned" if args.pinned else "host") if args.host_frames else "hbm",
                        "boxes_per_frame": n_boxes, "parallelism": "stream-sharded x%d" % world, "ranks_seen": ranks_seen,
                        "batches_in_flight": 2 if pipelined else 1,
                        "cascade": ("calibrated: stage thresholds set on windows of this content, every early stage rejects about half of what reaches it"
@@ -618,7 +688,7 @@ def main():
                 out["cpu_baseline"]["opencv"] = {"available": False, "note": "probe not run: %s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_secondary and args.workload == "face1080p" and not args.host_frames:
             try:
-                out["secondary"] = secondary_table(ctx, casc, props, frames_np[0], W, H, F, dev, args)
+                out["secondary"] = secondary_table(ctx, casc, props, frames_np[0], W, H, F, dev, args, xml)
             except Exception as e:
                 out["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))

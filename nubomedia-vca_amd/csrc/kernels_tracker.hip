@@ -11,7 +11,7 @@
 //    symmetric, so the filled regions are exactly the connected components of that
 //    graph which contain a seed, ordered by their first seed pixel.  Zero pixels (which
 //    OpenCV swaps for a huge sentinel) only ever connect to each other and hold no seed.
-//    k_ccl_init / k_ccl_merge / k_ccl_flatten: lock-free union-find on pixel indices;
+//    k_ccl_tile / k_ccl_border / k_ccl_flatten: lock-free union-find on pixel indices, first inside 256 x 16 tiles out of LDS;
 //    k_ccl_reduce: bounding box + first seed per root (atomics once per horizontal run);
 //    k_ccl_collect: roots that own a seed -> component list (host sorts by first seed).
 // All HBM-bound streaming / atomic work; no MFMA.
@@ -119,6 +119,22 @@ __device__ __forceinline__ bool segment_live(const uint8_t *__restrict__ flags, 
 {
     return flags[((size_t)blockIdx.z * h + y) * seg_per_row(w) + blockIdx.x] != 0;
 }
+// which of the rows y0 .. y0 + n - 1 (n <= 16) of this block's 256-pixel column hold motion history: bit per row.  The flag bytes are
+// requested TOGETHER, ahead of the walk (one round trip): asked for row by row, behind an `if (dead) continue`, they were a
+// chain of dependent global loads that made up most of every component kernel on a mostly static scene (five kernels, 4 352
+// to 69 k blocks each)
+__device__ __forceinline__ unsigned live_rows(const uint8_t *__restrict__ flags, int w, int h, int y0, int n)
+{
+    const uint8_t *f = flags + ((size_t)blockIdx.z * h + y0) * seg_per_row(w) + blockIdx.x;
+    const int nseg = seg_per_row(w);
+    unsigned char b[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = k < n ? f[(size_t)k * nseg] : 0;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m |= (b[k] ? 1u : 0u) << k;
+    return m;
+}
 // A block of the component kernels walks kCclRows rows of its 256-pixel column: most segments of a frame hold no motion and
 // are skipped on their flag byte, and a grid of one block per segment (69 k blocks for 8 x 1080p) cost 30 us per kernel in
 // block dispatch alone -- five kernels a tick.
@@ -127,52 +143,90 @@ static constexpr int kCclRowsDefault = 8;
 // other (measured on 8 x 1080p: 1 / 2 / 4 / 8 rows -> trackers alone 0.261 / 0.250 / 0.259 / 0.274 ms per tick)
 static constexpr int kCclRowsUf = 2;
 
-// Labels start as horizontal runs: within a wave (64 consecutive pixels of a row) every pixel points at the first pixel
-// of its maximal run of joined neighbours, so the row direction needs no atomics except across wave boundaries.
-__global__ __launch_bounds__(256) void k_ccl_init(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags, int kCclRows)
+// ---- labelling, first inside tiles of 256 x 16 pixels out of LDS, then across the tiles' borders ------------------------------
+// A block takes a tile: the 16 rows' motion history goes to LDS, labels start as horizontal runs (within a wave every pixel points
+// at the first pixel of its maximal run of joined neighbours: ballot + count-leading-zeros), the runs are united across the
+// wave boundaries and from row to row by the same lock-free union-find as before -- but on LDS words, whose round trips cost a
+// hundred cycles instead of a global atomic's thousands -- and every pixel leaves with the GLOBAL index of its tile-local root
+// (the root of a set is its smallest index, and row-major order inside a tile is row-major order in the frame: the tile-local
+// root is the smallest pixel of the tile's part of the component).  k_ccl_border then unites across the tiles' top rows and left
+// columns only -- a sixteenth of the rows, a 256th of the columns -- on labels whose chains are as long as the number of tiles
+// a component spans, not the number of rows.  (Round 3: run labels per wave, then every vertical link of the frame as a global
+// union: k_ccl_merge + k_ccl_flatten were ~90 us of dependent global round trips per 8 x 1080p.)
+static constexpr int kCclTileRows = 16;
+__global__ __launch_bounds__(256) void k_ccl_tile(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags)
 {
+    __shared__ float m[kCclTileRows][256];
+    __shared__ int lab[kCclTileRows * 256];
     const TrkSlot s = slots[blockIdx.z];
-    int *lab = labels + (size_t)blockIdx.z * w * h;
-    const int x = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int *glab = labels + (size_t)blockIdx.z * w * h;
+    const int tx = threadIdx.x, lane = tx & 63, x = blockIdx.x * 256 + tx, y0 = blockIdx.y * kCclTileRows;
     const bool in = x < w;
-    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
-        if (!segment_live(flags, w, h, y)) continue;  // nothing but zeros here: no labels are written, and nobody will read any
-        const int i = y * w + x;
-        const float v = in ? s.mhi[i] : 0.f;
-        float l = __shfl_up(v, 1);
-        if (lane == 0) l = (in && x > 0) ? s.mhi[i - 1] : 0.f;
+    const int rows = min(kCclTileRows, h - y0);
+    const unsigned live = live_rows(flags, w, h, y0, rows);       // bit per row of the tile whose segment holds motion history (block-uniform)
+    if (!live) return;                                // nothing but zeros here: no labels are written, and nobody will read any
+    for (int ry = 0; ry < rows; ry++) m[ry][tx] = (((live >> ry) & 1u) && in) ? s.mhi[(size_t)(y0 + ry) * w + x] : 0.f;
+    __syncthreads();
+    for (int ry = 0; ry < rows; ry++) {
+        const float v = m[ry][tx], l = tx > 0 ? m[ry][tx - 1] : 0.f;
         const bool link = v != 0.f && l != 0.f && joined(v, l, s.seg);
         const unsigned long long starts = ~__ballot(link) | 1ull;                   // lanes that begin a run inside this wave
         const unsigned long long upto = starts & (~0ull >> (63 - lane));            // ... at or left of this lane
         const int head = 63 - __clzll((long long)upto);
-        if (in) lab[i] = v != 0.f ? i - (lane - head) : -1;
+        lab[ry * 256 + tx] = v != 0.f ? ry * 256 + tx - (lane - head) : -1;
+    }
+    __syncthreads();
+    for (int ry = 0; ry < rows; ry++) {
+        const int idx = ry * 256 + tx;
+        const float v = m[ry][tx];
+        if (v == 0.f) continue;
+        const float l = tx > 0 ? m[ry][tx - 1] : 0.f;
+        const bool link_l = l != 0.f && joined(v, l, s.seg);
+        if (lane == 0 && link_l) uf_union(lab, idx, idx - 1);                       // runs are cut at wave boundaries
+        if (ry > 0) {
+            const float u = m[ry - 1][tx];
+            if (u != 0.f && joined(v, u, s.seg)) {
+                // redundant when the left neighbour already ties the two rows together: v~l, l~ul, ul~u
+                const float ul = tx > 0 ? m[ry - 1][tx - 1] : 0.f;
+                const bool tied = link_l && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
+                if (!tied) uf_union(lab, idx, idx - 256);
+            }
+        }
+    }
+    __syncthreads();
+    if (!in) return;
+    for (int ry = 0; ry < rows; ry++) {
+        if (!((live >> ry) & 1u)) continue;
+        const int idx = ry * 256 + tx;
+        int g = -1;
+        if (lab[idx] >= 0) { const int r = uf_find(lab, idx); g = (y0 + (r >> 8)) * w + blockIdx.x * 256 + (r & 255); }
+        glab[(size_t)(y0 + ry) * w + x] = g;
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_merge(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags, int kCclRows)
+// the links that cross a tile's top row or its left column, as unions on the global labels (same redundancy rule: the links it
+// leans on are made by the neighbouring thread of this kernel or inside a tile)
+__global__ __launch_bounds__(256) void k_ccl_border(const TrkSlot *__restrict__ slots, int *__restrict__ labels, int w, int h, const uint8_t *__restrict__ flags)
 {
     const TrkSlot s = slots[blockIdx.z];
-    const int n = w * h;
-    int *lab = labels + (size_t)blockIdx.z * n;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= w) return;
-    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
-        if (!segment_live(flags, w, h, y)) continue;
-        const int i = y * w + x;
+    int *lab = labels + (size_t)blockIdx.z * w * h;
+    const int tx = threadIdx.x, x = blockIdx.x * 256 + tx, y0 = blockIdx.y * kCclTileRows;
+    if (y0 > 0 && x < w && segment_live(flags, w, h, y0)) {
+        const int i = y0 * w + x;
         const float v = s.mhi[i];
-        if (v == 0.f) continue;
-        const float l = x > 0 ? s.mhi[i - 1] : 0.f;
-        const bool link_l = l != 0.f && joined(v, l, s.seg);
-        if ((threadIdx.x & 63) == 0 && link_l) uf_union(lab, i, i - 1);             // runs are cut at wave boundaries
-        if (y > 0) {
-            const float u = s.mhi[i - w];
+        if (v != 0.f) {
+            const float u = s.mhi[i - w];             // (a segment without motion history holds zeros: no link into it)
             if (u != 0.f && joined(v, u, s.seg)) {
-                // redundant when the left neighbour already ties the two rows together: v~l, l~ul, ul~u
-                const float ul = x > 0 ? s.mhi[i - w - 1] : 0.f;
-                const bool tied = link_l && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
+                const float l = x > 0 ? s.mhi[i - 1] : 0.f, ul = x > 0 ? s.mhi[i - w - 1] : 0.f;
+                const bool tied = l != 0.f && joined(v, l, s.seg) && ul != 0.f && joined(l, ul, s.seg) && joined(u, ul, s.seg);
                 if (!tied) uf_union(lab, i, i - w);
             }
         }
+    }
+    if (blockIdx.x > 0 && tx < kCclTileRows && y0 + tx < h && segment_live(flags, w, h, y0 + tx)) {
+        const int i = (y0 + tx) * w + blockIdx.x * 256;
+        const float v = s.mhi[i], l = s.mhi[i - 1];
+        if (v != 0.f && l != 0.f && joined(v, l, s.seg)) uf_union(lab, i, i - 1);
     }
 }
 
@@ -184,8 +238,10 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ labels, C
     CompAcc *ac = acc + (size_t)blockIdx.z * n;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
-        if (!segment_live(flags, w, h, y)) continue;
+    const int yb = blockIdx.y * kCclRows;
+    const unsigned live = live_rows(flags, w, h, yb, min(kCclRows, h - yb));
+    for (int y = yb, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!((live >> (y - yb)) & 1u)) continue;
         const int i = y * w + x;
         if (lab[i] < 0) continue;
         const int r = uf_find(lab, i);
@@ -224,9 +280,21 @@ __global__ __launch_bounds__(256) void k_ccl_reduce(const TrkSlot *__restrict__ 
     // frame-sized component arrive first, and everything that follows fails the "would it still improve" test instead of
     // queueing up (0.76 -> 0.46 ms per 4 x 720p); otherwise top to bottom, which is kinder to memory (0.49 -> 0.42 ms per 8 x 1080p)
     const int bx = (int)blockIdx.x;
-    for (int v = blockIdx.y * kCclRows, v1 = min(v + kCclRows, h); v < v1; v++) {
+    const int vb = blockIdx.y * kCclRows;
+    unsigned live = 0;
+    {   // the rows' flag bytes in one round trip (see live_rows)
+        unsigned char b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int v = vb + k, by = (order & 1) ? ((v & 1) ? h - 1 - (v >> 1) : (v >> 1)) : v;
+            b[k] = (k < kCclRows && v < h) ? flags[((size_t)blockIdx.z * h + by) * nseg + bx] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) live |= (b[k] ? 1u : 0u) << k;
+    }
+    for (int v = vb, v1 = min(v + kCclRows, h); v < v1; v++) {
     const int by = (order & 1) ? ((v & 1) ? h - 1 - (v >> 1) : (v >> 1)) : v;
-    if (!flags[((size_t)blockIdx.z * h + by) * nseg + bx]) continue;
+    if (!((live >> (v - vb)) & 1u)) continue;
     const int x = bx * 256 + threadIdx.x, y = by, lane = threadIdx.x & 63;
     const int i = y * w + x;
     const int r = x < w ? lab[i] : -1;                // labels are final roots after k_ccl_flatten
@@ -271,8 +339,10 @@ __global__ __launch_bounds__(256) void k_ccl_collect(const TrkSlot *__restrict__
     const CompAcc *ac = acc + (size_t)slot * n;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    for (int y = blockIdx.y * kCclRows, y1 = min(y + kCclRows, h); y < y1; y++) {
-        if (!segment_live(flags, w, h, y)) continue;
+    const int yb = blockIdx.y * kCclRows;
+    const unsigned live = live_rows(flags, w, h, yb, min(kCclRows, h - yb));
+    for (int y = yb, y1 = min(y + kCclRows, h); y < y1; y++) {
+        if (!((live >> (y - yb)) & 1u)) continue;
         const int i = y * w + x;
         if (lab[i] != i) continue;
         const CompAcc c = ac[i];
@@ -297,11 +367,12 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
     if (vec4) NVCA_LAUNCH(k_trk_pixel4, gp, dim3(256), 0, st, slots, w, h, flags);
     else NVCA_LAUNCH(k_trk_pixel, gp, dim3(256), 0, st, slots, w, h, flags);
     if (!run_ccl) return;
-    static const int rows = [] { const char *e = getenv("NVCA_CCL_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 256 ? v : kCclRowsDefault; }();
-    static const int rows_uf = [] { const char *e = getenv("NVCA_CCL_ROWS_UF"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 256 ? v : kCclRowsUf; }();
+    static const int rows = [] { const char *e = getenv("NVCA_CCL_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 16 ? v : kCclRowsDefault; }();
+    static const int rows_uf = [] { const char *e = getenv("NVCA_CCL_ROWS_UF"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 16 ? v : kCclRowsUf; }();
     dim3 g2((w + 255) / 256, (h + rows - 1) / rows, batch), g3((w + 255) / 256, (h + rows_uf - 1) / rows_uf, batch);
-    NVCA_LAUNCH(k_ccl_init, g2, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags, rows);
-    NVCA_LAUNCH(k_ccl_merge, g3, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags, rows_uf);
+    dim3 gt((w + 255) / 256, (h + kCclTileRows - 1) / kCclTileRows, batch);
+    NVCA_LAUNCH(k_ccl_tile, gt, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
+    NVCA_LAUNCH(k_ccl_border, gt, dim3(256), 0, st, slots, labels, w, h, (const uint8_t *)flags);
     NVCA_LAUNCH(k_ccl_flatten, g3, dim3(256), 0, st, labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, rows_uf);
     // order (Switches::trk_order): -1: decided per frame on the device
     NVCA_LAUNCH(k_ccl_reduce, g2, dim3(256), 0, st, slots, (const int *)labels, (CompAcc *)acc, w, h, (const uint8_t *)flags, order, rows);

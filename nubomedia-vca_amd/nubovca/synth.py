@@ -491,3 +491,24 @@ def gray_to_bgr(g, seed, channels=3):
 def frame_seed(stream_id, frame_idx):
     """seed = 0xC0FFEE + stream_id*1000 + frame_idx."""
     return 0xC0FFEE + stream_id * 1000 + frame_idx
+
+
+def calibrated_part_cascade_xml(name, seed=None, n_images=8, pass_rate=0.65):
+    """A part detector's stand-in cascade with its stage thresholds calibrated the way calibrated_cascade_xml does it, on what the part
+    searches scan: face regions of the working image (the face TEMPLATE at 88 .. 104 pixels -- a 560 .. 620-pixel face of a 1080p frame
+    on the 320-pixel working image -- on the 1/f field, equalised), windows from 20 pixels up at OpenCV's grid.  Every early stage
+    lets about two thirds of what reaches it through (pass_rate 0.65: with 0.5 the parts of the bench's faces lose neighbours to the
+    stricter stages and a quarter of them falls below minNeighbors; the mcs_* files are short, lenient cascades too); the part's
+    own template keeps its margin."""
+    key = ("part", name, seed, n_images, pass_rate)
+    if key not in _CALIB_CACHE:
+        pseed = {"righteye": 101, "lefteye": 102, "nose": 103, "mouth": 104, "leftear": 105, "rightear": 106}[name] if seed is None else seed
+        imgs = []
+        for i in range(n_images):
+            size = 88 + 2 * i
+            g = make_gray(176, 176, 7000 + 13 * i + pseed, "natural", [(176 // 2 - size // 2, 176 // 2 - size // 2 + (i % 3) - 1, size)])
+            imgs.append(equalize_np(g))
+        c = make_cascade(seed=pseed, stages=PART_STAGES, tmpl=part_template(name), calib=WindowSample(imgs, scale_factor=1.1, min_size=(20, 20)), pass_rate=pass_rate)
+        c["name"] = "synthetic_%s_calibrated" % name
+        _CALIB_CACHE[key] = cascade_to_xml(c)
+    return _CALIB_CACHE[key]

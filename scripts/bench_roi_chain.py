@@ -9,8 +9,13 @@ from nubovca import capi, synth
 
 W, H, N = 1920, 1080, 16
 ctx = capi.Context(0)
-face_c = ctx.load_cascade_xml(synth.synthetic_cascade_xml())
-pc = {n: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+# calibrated cascades (bench.py's since round 4: every early stage rejects about half -- face -- or a third -- parts -- of what reaches it);
+# --standin: rounds 1-3's uncalibrated ones
+STANDIN = "--standin" in sys.argv
+FACE_XML = synth.synthetic_cascade_xml() if STANDIN else synth.calibrated_cascade_xml()
+PART_XML = synth.synthetic_part_cascade_xml if STANDIN else synth.calibrated_part_cascade_xml
+face_c = ctx.load_cascade_xml(FACE_XML)
+pc = {n: ctx.load_cascade_xml(PART_XML(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
 face = capi.FaceStream(ctx, face_c, width_to_process=W, multi_scale_factor=10)
 parts = {"eye": capi.PartStream(ctx, 0, face_c, pc["righteye"], pc["lefteye"], detect_event=1),
          "nose": capi.PartStream(ctx, 1, face_c, pc["nose"], None, detect_event=1),
@@ -172,8 +177,8 @@ for C in (() if "--no-contexts" in sys.argv else (2, 4)):
     per = V // C
     setups = []
     for cx in ctxs:
-        fc = cx.load_cascade_xml(synth.synthetic_cascade_xml())
-        pcs = {n: cx.load_cascade_xml(synth.synthetic_part_cascade_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+        fc = cx.load_cascade_xml(FACE_XML)
+        pcs = {n: cx.load_cascade_xml(PART_XML(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
         fv = [capi.FaceStream(cx, fc, width_to_process=W, multi_scale_factor=10) for _ in range(per)]
         pv = [capi.PartStream(cx, k, fc, pcs[a], pcs[b] if b else None) for _ in range(per) for k, a, b in kinds]
         setups.append((cx, fv, pv))
@@ -182,8 +187,9 @@ for C in (() if "--no-contexts" in sys.argv else (2, 4)):
         cx, fv, pv = setups[ci]
         for i in range(ticks):
             fb = [fr[(i + 3 * (ci * per + v)) % N] for v in range(per)]
-            cx.face_batch_process(fv, fb)
+            tk = cx.face_batch_submit(fv, fb)             # as tick_pipelined: the face detector's batch under the part detectors' call
             capi.part_batch_process(cx, pv, [fb[v] for v in range(per) for _ in range(4)])
+            cx.face_batch_collect(tk)
 
     def run(ticks):
         th = [threading.Thread(target=work, args=(ci, ticks)) for ci in range(C)]

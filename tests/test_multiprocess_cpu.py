@@ -82,6 +82,61 @@ def test_two_rank_sharding_matches_single_process(synth_xml):
     assert seen > 0
 
 
+def _worker4(rank, world, port, q):
+    """four ranks, two streams each, a different number of boxes on every stream and tick (0 .. more than the table holds): the gathered
+    table must carry every rank's rows in rank order with its stamp, and merge_by_stream must put stream s of the node where
+    stream_id % world says"""
+    for p in (ROOT, os.path.join(ROOT, "nubomedia-vca_amd")):
+        sys.path.insert(0, p)
+    from nubovca import sharding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n_streams, cap = 2 * world, 8
+    mine = sharding.streams_of_rank(n_streams, world, rank)
+    tg = sharding.TableGather()
+    ok = True
+    for tick in range(5):
+        def boxes_of(s):
+            n = (3 * s + 5 * tick + s * tick) % 12                      # 0 .. 11: some streams empty, some beyond cap
+            b = np.arange(4 * n, dtype=np.int32).reshape(n, 4) + 1000 * s + 100000 * tick
+            return b, np.arange(n)
+        tab = sharding.pack_boxes([boxes_of(s) for s in mine], cap, rank=rank)
+        g = sharding.gather_tables(tab)
+        ok = ok and g.shape == (world, len(mine), 1 + 4 * cap)
+        ok = ok and all((sharding.table_ranks(g)[r] == r).all() for r in range(world))
+        merged = sharding.merge_by_stream(g, n_streams, world)
+        for s in range(n_streams):
+            exp = boxes_of(s)[0][:cap]
+            ok = ok and np.array_equal(np.asarray(merged[s]).reshape(-1, 4), exp)
+        tg.submit(tab)
+        ok = ok and (tg.last() == g).all()
+    tg.finish()
+    dist.barrier()
+    if rank == 0:
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_four_rank_gather_with_unequal_box_counts():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    ok, t0 = None, time.time()
+    while ok is None and time.time() - t0 < 240:
+        try:
+            ok = q.get(timeout=2)
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a rank died"
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok is True
+
+
 def test_pack_unpack_roundtrip():
     from nubovca import sharding
     rng = np.random.default_rng(0)
