@@ -205,6 +205,7 @@ static Switches read_switches()
     if (set("NVCA_PART_STATS")) { const int n = num("NVCA_PART_STATS", 0); w.part_stats = n > 0 ? n : 8; }
     w.ingest_chunk = num("NVCA_INGEST_CHUNK", 8);
     w.stage_order = num("NVCA_STAGE_ORDER", 0) != 0;
+    w.trk_fold = num("NVCA_TRK_FOLD", 1) != 0;
     w.spec_pairs = std::max(1, num("NVCA_SPEC_PAIRS", 1536));
     w.pair_max = num("NVCA_PAIR_MAX", 32);
     w.deep_stage = set("NVCA_DEEP_STAGE") ? std::max(1, num("NVCA_DEEP_STAGE", 0)) : 0;
@@ -740,16 +741,19 @@ static int bounce_used(nvca_ctx *ctx, int slot, hipStream_t st)
     ctx->bounce.pending[slot] = true;
     return NVCA_OK;
 }
-// large pieces are copied by the context's helper threads too (the PCIe link moves ~50 GB/s; one core's memcpy a fifth of that)
+// large pieces are copied by the context's helper threads too (the PCIe link moves ~50 GB/s; one core's memcpy a fifth of that): as
+// many equal parts as there are threads, none below 256 KB
 static void host_copy(nvca_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-    static constexpr size_t kPiece = 512u << 10;
-    if (bytes < 2 * kPiece || !ctx->pool) { memcpy(dst, src, bytes); return; }
-    struct Arg { uint8_t *d; const uint8_t *s; size_t n; } arg{(uint8_t *)dst, (const uint8_t *)src, bytes};
-    work_pool_run(ctx->pool, (int)((bytes + kPiece - 1) / kPiece), [](void *a, int i) {
+    static constexpr size_t kMinPart = 256u << 10;
+    const int threads = work_pool_threads(ctx->pool) + 1;
+    const int parts = (int)std::min<size_t>((size_t)threads, bytes / kMinPart);
+    if (parts < 4 || !ctx->pool) { memcpy(dst, src, bytes); return; }
+    struct Arg { uint8_t *d; const uint8_t *s; size_t n, part; } arg{(uint8_t *)dst, (const uint8_t *)src, bytes, ((bytes + parts - 1) / parts + 63) & ~(size_t)63};
+    work_pool_run(ctx->pool, parts, [](void *a, int i) {
         const Arg *g = (const Arg *)a;
-        const size_t o = (size_t)i * kPiece;
-        memcpy(g->d + o, g->s + o, std::min(kPiece, g->n - o));
+        const size_t o = (size_t)i * g->part;
+        if (o < g->n) memcpy(g->d + o, g->s + o, std::min(g->part, g->n - o));
     }, &arg);
 }
 static void ensure_pool(nvca_ctx *ctx)
@@ -1014,6 +1018,7 @@ try {
     else if (n == "ingest_chunk") w.ingest_chunk = value;
     else if (n == "part_stats") w.part_stats = value;
     else if (n == "trk_order") w.trk_order = value;
+    else if (n == "trk_fold") w.trk_fold = value != 0;
     else if (n == "quiet") w.quiet = value != 0;
     else if (n == "roi") w.roi = value != 0;
     else if (n == "two_lanes") w.two_lanes = value != 0;
@@ -1054,6 +1059,7 @@ try {
     else if (n == "ingest_chunk") *value = w.ingest_chunk;
     else if (n == "part_stats") *value = w.part_stats;
     else if (n == "trk_order") *value = w.trk_order;
+    else if (n == "trk_fold") *value = w.trk_fold;
     else if (n == "quiet") *value = w.quiet;
     else if (n == "roi") *value = w.roi;
     else if (n == "two_lanes") *value = w.two_lanes;

@@ -187,6 +187,7 @@ struct Switches {
     bool tiles = true;               // NVCA_TILES=0: row-strip kernel
     bool plan_debug = false;         // NVCA_PLAN_DEBUG: per-scale tile sizes on stderr
     bool deep_lds = true;            // NVCA_DEEP_LDS_OFF: k_deep without LDS patches
+    bool trk_fold = true;            // NVCA_TRK_FOLD=0: NuboTracker's components through the per-pixel kernels (k_ccl_flatten / _reduce / _collect) instead of the per-tile reduction + fold of tile roots
     int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
@@ -228,16 +229,19 @@ struct PinnedBuf {
 // Page-locked memory of the context's own that caller host memory crosses through when it is not page-locked by the caller
 // (nvca_host_register): a ring of fixed slots, each with the event of the last copy that read or wrote it (api.cpp, caller_h2d ...).
 struct BounceRing {
-    static constexpr size_t kSlot = 4u << 20;
-    static constexpr int kSlots = 16;
+    static constexpr size_t kSlot = 8u << 20;      // a 1080p BGR frame (6.2 MB) is one slot: one CPU copy (shared by the helper threads) + one DMA
+    static constexpr int kSlots = 12;
     PinnedBuf buf; hipEvent_t ev[kSlots] = {}; bool pending[kSlots] = {}; int next = 0;
     void release() { for (hipEvent_t &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } buf.release(); }
 };
 
 // tracker workspace (tracker.cpp): slot table, labels, per-root accumulators, component list, frame staging
 struct TrkWorkspace {
-    DevBuf slots, labels, acc, out, staging, flags; PinnedBuf h_slots, h_out;
-    void release_all() { slots.release(); labels.release(); acc.release(); out.release(); staging.release(); flags.release(); h_slots.release(); h_out.release(); }
+    DevBuf slots, labels, acc, out, staging, flags, roots, tiles; PinnedBuf h_slots, h_out;
+    // the live-tile list's marks are stamped with the launch's tick and never cleared (kernels_tracker.hip, TileList): they are
+    // zeroed when the buffer's layout changes (frame size, batch) and when the tick would come round
+    int tick = 0, tiles_w = 0, tiles_h = 0, tiles_batch = 0;
+    void release_all() { slots.release(); labels.release(); acc.release(); out.release(); staging.release(); flags.release(); roots.release(); tiles.release(); h_slots.release(); h_out.release(); tiles_w = tiles_h = tiles_batch = 0; }
 };
 
 // batched part detectors (parts.cpp): working images of a call carved from one arena, the small tables its launches read
@@ -255,6 +259,7 @@ struct WorkPool;
 WorkPool *work_pool_create(int threads);
 void work_pool_destroy(WorkPool *p);
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *arg, int i), void *arg);     // p == nullptr: serial
+int work_pool_threads(const WorkPool *p);          // helper threads (0 for nullptr)
 
 struct DetectPlan;   // plan.cpp
 struct ScaleTable;   // plan.cpp: one cascade at one scale factor (geometry-independent stump records), cached in the context
@@ -447,8 +452,10 @@ struct CompAcc { int minx, miny, maxx, maxy, seed, pad; };   // per root, stored
 // out: [0] = component count, [1] unused, then 6 ints per component: slot, first seed index, x, y, w, h
 // flags: one byte per 256-pixel row segment and slot, set by the pixel pass where the motion history holds anything -- the
 // component kernels leave the other segments alone (a static scene with a few moving objects is mostly such segments)
+// roots: [0] = tile roots listed, [1] = the list overflowed, then one entry (slot * w * h + pixel) per tile root; mode: 0 folded component
+// path, 1 per-pixel component kernels, 2 the latter without the pixel pass (fallback behind an overflow of mode 0's list)
 void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h, bool vec4, int *labels, void *acc,
-                    int *out, int cap, bool run_ccl, uint8_t *flags, int order /* Switches::trk_order */);
+                    int *out, int cap, bool run_ccl, uint8_t *flags, int order /* Switches::trk_order */, int *roots, int roots_cap, int mode, int *tiles, int tick);
 inline size_t tracker_count_offset(int w, int h, int batch) { return ((size_t)((w + 255) / 256) * h * batch + 63) & ~(size_t)63; }
 inline size_t tracker_flag_bytes(int w, int h, int batch) { return tracker_count_offset(w, h, batch) + sizeof(int) * (size_t)batch; }   // flag bytes, then a live-segment count per slot
 

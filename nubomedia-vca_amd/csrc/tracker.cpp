@@ -97,10 +97,20 @@ try {
             if ((f.stride & 15) || (f.mem == NVCA_MEM_DEVICE && ((uintptr_t)f.data & 15))) vec4 = false;
             if (t->num_frames > 0) any_ccl = true;
         }
+        static const int roots_div = [] { const char *e = getenv("NVCA_TRK_ROOTS_DIV"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();      // diagnostic: the share of the pixels the root list holds (1 / n)
+        const int roots_cap = (int)std::min<size_t>(N * batch / roots_div, (size_t)1 << 30);
+        const size_t tiles_per_slot = (size_t)((W + 255) / 256) * ((H + 7) / 8), tile_bytes = sizeof(int) * (2 * tiles_per_slot + 2) * (size_t)batch;
+        const void *tiles_before = ws.tiles.p;
         if (ws.slots.ensure(sizeof(TrkSlot) * batch) || ws.h_slots.ensure(sizeof(TrkSlot) * batch) ||
             ws.labels.ensure(sizeof(int) * N * batch) || ws.acc.ensure(sizeof(CompAcc) * N * batch) || ws.flags.ensure(tracker_flag_bytes(W, H, batch) + 64) ||
             ws.out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) || ws.h_out.ensure(sizeof(int) * (2 + 6 * (size_t)kCompCap)) ||
+            ws.roots.ensure(sizeof(int) * (8 + (size_t)roots_cap + 64)) || ws.tiles.ensure(tile_bytes) ||
             (stage_bytes && ws.staging.ensure(stage_bytes))) { ctx->set_error("tracker workspace allocation failed"); return NVCA_ERR_NOMEM; }
+        if (ws.tiles.p != tiles_before || ws.tiles_w != W || ws.tiles_h != H || ws.tiles_batch != batch || ws.tick >= 0x7ffffffe) {
+            NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.tiles.p, 0, tile_bytes, ctx->cs()));       // marks of another layout (or of two billion ticks ago) mean nothing
+            ws.tiles_w = W; ws.tiles_h = H; ws.tiles_batch = batch; ws.tick = 0;
+        }
+        const int tick = ++ws.tick;
         TrkSlot *hs = ws.h_slots.as<TrkSlot>();
         size_t off = 0;
         for (int b = 0; b < batch; b++) {
@@ -121,10 +131,13 @@ try {
             s.min_area = t->p.min_area; s.max_area = (long long)t->p.max_area;
         }
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ws.slots.p, hs, sizeof(TrkSlot) * batch, hipMemcpyHostToDevice, ctx->cs()));
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->cs()));
-        NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->cs()));
+        // (the result header and the root list's header are cleared by the pixel kernel; the live-segment counts only steer the per-pixel
+        // kernels' visiting order)
+        if (!ctx->sw.trk_fold) NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->cs()));
+        const bool fold = ctx->sw.trk_fold;
         { TimedLaunch tl(ctx, NVCA_K_TRACKER);
-          launch_tracker(ctx->cs(), ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>(), ctx->sw.trk_order); }
+          launch_tracker(ctx->cs(), ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, any_ccl, ws.flags.as<uint8_t>(), ctx->sw.trk_order,
+                         ws.roots.as<int>(), roots_cap, fold ? 0 : 1, ws.tiles.as<int>(), tick); }
         NVCA_LAUNCH_CHECK(ctx);
         tp1 = std::chrono::steady_clock::now();
         int *ho = ws.h_out.as<int>();
@@ -133,6 +146,25 @@ try {
             const int first = 1024;
             NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->cs()));
             NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+            auto label_error = [&]() {
+                int dbg[4] = {0, 0, 0, 0};
+                (void)hipMemcpy(dbg, ws.roots.as<int>() + 2, 3 * sizeof(int), hipMemcpyDeviceToHost);
+                ctx->set_error("internal: tracker label walk met an unwritten word (" + std::to_string(dbg[0]) + " times; first at " + std::to_string(dbg[1]) + ", kernel " + std::to_string(dbg[2]) + ")");
+                return NVCA_ERR_INTERNAL;
+            };
+            if (ho[1] & 2) return label_error();
+            if (fold && (ho[1] & 1)) {
+                // more tile roots than the list holds (a frame of single-pixel components): the same motion history through the per-pixel kernels
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.out.p, 0, 2 * sizeof(int), ctx->cs()));
+                NVCA_HIP_CHECK(ctx, hipMemsetAsync(ws.flags.as<uint8_t>() + tracker_count_offset(W, H, batch), 0, sizeof(int) * (size_t)batch, ctx->cs()));
+                { TimedLaunch tl(ctx, NVCA_K_TRACKER);
+                  launch_tracker(ctx->cs(), ws.slots.p, batch, W, H, vec4, ws.labels.as<int>(), ws.acc.p, ws.out.as<int>(), kCompCap, true, ws.flags.as<uint8_t>(), ctx->sw.trk_order,
+                                 ws.roots.as<int>(), roots_cap, 2, ws.tiles.as<int>(), tick); }
+                NVCA_LAUNCH_CHECK(ctx);
+                NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ho, ws.out.p, sizeof(int) * (2 + 6 * (size_t)first), hipMemcpyDeviceToHost, ctx->cs()));
+                NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+                if (ho[1] & 2) return label_error();
+            }
             total = ho[0];
             if (total < 0) { ctx->set_error("internal: negative component count"); return NVCA_ERR_INTERNAL; }
             if (total > kCompCap) { ctx->set_error("tracker: more motion components than the list holds"); return NVCA_ERR_OVERFLOW; }

@@ -17,6 +17,7 @@ struct WorkPool;
 WorkPool *work_pool_create(int threads);
 void work_pool_destroy(WorkPool *p);
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *arg, int i), void *arg);
+int work_pool_threads(const WorkPool *p);
 
 // A run is opened by the calling thread (gen goes odd), worked on by the caller and by whichever helpers get there, and closed
 // (gen goes even) as soon as every index has been handled: the caller never waits for a helper to WAKE, only for the ones that
@@ -107,6 +108,7 @@ static void wait_until(const std::atomic<int> &v, int target, bool at_least)
         if (spins < 4096) WorkPool::relax(); else std::this_thread::yield();
     }
 }
+int work_pool_threads(const WorkPool *p) { return p ? (int)p->th.size() : 0; }
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *, int), void *arg)
 {
     if (!p || p->th.empty() || n < 4) { for (int i = 0; i < n; i++) fn(arg, i); return; }

@@ -136,3 +136,28 @@ def test_tracker_resolution_change_resets_state(ctx):
     a = moving_scene(320, 240, 3, 2, 1)
     for i, f in enumerate(a):
         assert np.array_equal(trk.process(f, 100.0 + 33 * i), otr.process(f, 100.0 + 33 * i))
+
+
+@pytest.mark.parametrize("fold", [1, 0])
+def test_tracker_component_paths_agree_and_root_list_overflow_falls_back(ctx, fold):
+    """the per-tile reduction + fold of tile roots (default) and the per-pixel component kernels ("trk_fold" 0) give the oracle's boxes on
+    the same frames; a frame of isolated moving pixels (a quarter of all pixels a component of its own: more tile roots than the list
+    holds) takes the fallback inside the call and still answers as the oracle does"""
+    import orc
+    from nubovca import capi
+    W, H = 640, 480
+    with ctx.options(trk_fold=fold):
+        trk, otr = capi.Tracker(ctx), orc.Tracker()
+        seq = moving_scene(W, H, 4, 6, 77, noise=20)
+        dots = np.zeros((H, W, 4), np.uint8); dots[..., 3] = 255
+        lit = dots.copy(); lit[::2, ::2, :3] = 255                      # every other pixel of every other row jumps: 76 800 one-pixel components
+        seq = seq[:2] + [dots, lit, dots] + seq[2:]
+        seen = 0
+        for i, f in enumerate(seq):
+            ts = 2000.0 + 33.3 * i
+            got = trk.process(f, ts)
+            exp = otr.process(f, ts, cap=1 << 16)
+            assert np.array_equal(np.asarray(got).reshape(-1, 4), np.asarray(exp).reshape(-1, 4)), (fold, i, len(got), len(exp))
+            seen += len(exp)
+        assert seen > 0
+        trk.close()
