@@ -15,6 +15,11 @@ LIBS = ["-L%s/lib" % CONDA, "-lgstvideo-1.0", "-lgstbase-1.0", "-lgstreamer-1.0"
         "-Wl,--disable-new-dtags", "-Wl,-rpath,/usr/lib/x86_64-linux-gnu:%s/lib" % CONDA]
 PLUGIN = os.path.join(HERE, "libgstnubovca.so")
 HARNESS = os.path.join(HERE, "gst_harness")
+# the reference's six plugins by their own library and plugin names (plugin_alias.cpp): (library, plugin name, element factory)
+ALIAS_DIR = os.path.join(PKG, "gst_reference_names")        # NOT below gst/: GStreamer scans a plugin path recursively
+ALIASES = [("nubofacedetector", "nubofacedetector", "nubofacedetector"), ("nuboeyedetector", "eyefilter", "nuboeyedetector"),
+           ("nubonosedetector", "nubonosedetector", "nubonosedetector"), ("nubomouthdetector", "nubomouthdetector", "nubomouthdetector"),
+           ("nuboeardetector", "earfilter", "nuboeardetector"), ("nubotracker", "nubotracker", "nubotracker")]
 
 
 def available():
@@ -35,18 +40,27 @@ def build(required=True):
     if _stale(PLUGIN, [src, hdr, __file__]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-deprecated-declarations", src, "-o", PLUGIN]
                               + INC + LIBS + ["-L" + PKG, "-lnubovca_hip", "-Wl,-rpath,$ORIGIN/.."])
+    alias_src = os.path.join(HERE, "plugin_alias.cpp")
+    os.makedirs(ALIAS_DIR, exist_ok=True)
+    for lib, plugin, factory in ALIASES:
+        out = os.path.join(ALIAS_DIR, "lib%s.so" % lib)
+        if _stale(out, [alias_src, PLUGIN, __file__]):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DNVCA_ALIAS_PLUGIN=%s" % plugin,
+                                   "-DNVCA_ALIAS_FACTORY=\"%s\"" % factory, "-DNVCA_ALIAS_LIB=%s" % lib]
+                                  + (["-DNVCA_ALIAS_LIB_DIFFERS"] if lib != plugin else []) + [alias_src, "-o", out] + INC + LIBS
+                                  + ["-L" + HERE, "-lgstnubovca", "-Wl,-rpath,$ORIGIN/../gst:$ORIGIN/.."])
     hs = os.path.join(HERE, "gst_harness.cpp")
     if _stale(HARNESS, [hs, __file__]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", hs, "-o", HARNESS] + INC + LIBS)
     return PLUGIN
 
 
-def env():
-    """environment for running pipelines with the shim"""
+def env(reference_names=False):
+    """environment for running pipelines with the shim (reference_names: the six plugins under the reference's names instead of the one)"""
     e = dict(os.environ)
-    e["GST_PLUGIN_PATH"] = HERE
+    e["GST_PLUGIN_PATH"] = ALIAS_DIR if reference_names else HERE
     e["GST_PLUGIN_SYSTEM_PATH"] = os.path.join(CONDA, "lib", "gstreamer-1.0")
-    e["GST_REGISTRY"] = os.path.join("/tmp", "nubovca-gst-registry-%d.bin" % os.getuid())
+    e["GST_REGISTRY"] = os.path.join("/tmp", "nubovca-gst-registry-%d%s.bin" % (os.getuid(), "-names" if reference_names else ""))
     sysstd = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
     if os.path.exists(sysstd):          # conda's gst tools would otherwise pull conda's older libstdc++ first
         e["LD_PRELOAD"] = sysstd + (":" + e["LD_PRELOAD"] if e.get("LD_PRELOAD") else "")

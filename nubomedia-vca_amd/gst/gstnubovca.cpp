@@ -973,13 +973,38 @@ static GType nvca_part_type(PartDesc *d)
 }
 
 // =====================================================================================
+static void debug_category_once()
+{
+    static gsize once = 0;
+    if (g_once_init_enter(&once)) {
+        GST_DEBUG_CATEGORY_INIT(nubovca_debug, "nubovca", 0, "NUBOMEDIA-VCA Haar path on MI355X");
+        g_once_init_leave(&once, 1);
+    }
+}
 static gboolean plugin_init(GstPlugin *plugin)
 {
-    GST_DEBUG_CATEGORY_INIT(nubovca_debug, "nubovca", 0, "NUBOMEDIA-VCA Haar path on MI355X");
+    debug_category_once();
     gboolean ok = gst_element_register(plugin, "nubofacedetector", GST_RANK_NONE, nvca_face_get_type()) &&
                   gst_element_register(plugin, "nubotracker", GST_RANK_NONE, nvca_trk_get_type());
     for (PartDesc &d : part_descs) ok = ok && gst_element_register(plugin, d.factory, GST_RANK_NONE, nvca_part_type(&d));
     return ok;
+}
+// One element under a plugin of its own: the reference ships six plugins (libnubofacedetector.so with plugin name
+// nubofacedetector, libnuboeyedetector.so / eyefilter, libnubonosedetector.so / nubonosedetector, libnubomouthdetector.so /
+// nubomouthdetector, libnuboeardetector.so / earfilter, libnubotracker.so / nubotracker -- modules/nubo_*/.../src/gst-plugins/
+// nubo*.c, GST_PLUGIN_DEFINE), and deployments that name them (GST_PLUGIN_PATH entries, `gst-inspect-1.0 <plugin>`, registry
+// checks) find the same six here: gst_reference_names/lib<name>.so are stubs (plugin_alias.cpp) that register their element
+// through this entry point.  The element types, the batching state and the contexts live in THIS library once, whichever plugin
+// registered the factory: branches of different elements are still combined into batched calls.
+extern "C" __attribute__((visibility("default"))) gboolean nvca_gst_register_element(GstPlugin *plugin, const char *factory)
+{
+    debug_category_once();
+    if (!plugin || !factory) return FALSE;
+    if (!strcmp(factory, "nubofacedetector")) return gst_element_register(plugin, factory, GST_RANK_NONE, nvca_face_get_type());
+    if (!strcmp(factory, "nubotracker")) return gst_element_register(plugin, factory, GST_RANK_NONE, nvca_trk_get_type());
+    for (PartDesc &d : part_descs)
+        if (!strcmp(factory, d.factory)) return gst_element_register(plugin, factory, GST_RANK_NONE, nvca_part_type(&d));
+    return FALSE;
 }
 
 #ifndef PACKAGE

@@ -24,8 +24,8 @@ def shim():
     return build_gst.build(required=True)
 
 
-def _inspect(name):
-    r = subprocess.run([GST_INSPECT, name], env=build_gst.env(), capture_output=True, text=True, timeout=120)
+def _inspect(name, reference_names=False):
+    r = subprocess.run([GST_INSPECT, name], env=build_gst.env(reference_names), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stdout
 
@@ -48,8 +48,9 @@ def test_tracker_element_surface(shim):
     assert "Range: 0 - 255 Default: 20" in out and "Range: 0 - 300000 Default: 30000" in out
 
 
-def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None, extra_env=None, dump_frames=False):
-    """frames: one list of frames, or a list of such lists (one pipeline branch per list)"""
+def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_cascades=None, extra_env=None, dump_frames=False, reference_names=False):
+    """frames: one list of frames, or a list of such lists (one pipeline branch per list); reference_names: the plugin path holds
+    the six plugins under the reference's library / plugin names instead of the one shim plugin"""
     with tempfile.TemporaryDirectory() as td:
         branches = frames if isinstance(frames[0], (list, tuple)) else [frames]
         raws = []
@@ -59,7 +60,7 @@ def _run_harness(element, fmt, W, H, frames, props=(), cascade_xml=None, extra_c
                 for fr in seq:
                     f.write(np.ascontiguousarray(fr).tobytes())
         raw = ",".join(raws)
-        env = build_gst.env()
+        env = build_gst.env(reference_names)
         env.update(extra_env or {})
         if cascade_xml is not None:
             with open(os.path.join(td, "haarcascade_frontalface_alt.xml"), "w") as f:
@@ -554,3 +555,46 @@ def test_element_driven_as_the_server_wrapper_drives_it(shim, synth_xml, kind):
             assert boxes in ev_boxes, (kind, boxes, ev_boxes[:3])
         else:
             assert boxes and all(w > 0 and h > 0 for _, _, w, h in boxes), boxes
+
+
+# ---- the reference's six plugins under their own names (gst_reference_names, plugin_alias.cpp) -------------------------------------
+REFERENCE_PLUGINS = [("nubofacedetector", "libnubofacedetector.so", "nubofacedetector"), ("eyefilter", "libnuboeyedetector.so", "nuboeyedetector"),
+                     ("nubonosedetector", "libnubonosedetector.so", "nubonosedetector"), ("nubomouthdetector", "libnubomouthdetector.so", "nubomouthdetector"),
+                     ("earfilter", "libnuboeardetector.so", "nuboeardetector"), ("nubotracker", "libnubotracker.so", "nubotracker")]
+
+
+@pytest.mark.parametrize("plugin,library,factory", REFERENCE_PLUGINS)
+def test_reference_plugin_names_hold_their_elements(shim, plugin, library, factory):
+    """modules/nubo_*/.../src/gst-plugins/nubo*.c GST_PLUGIN_DEFINE + CMakeLists add_library: plugin name, library file and the one
+    element each registers -- `gst-inspect-1.0 <plugin>` finds the plugin in that file with that element, and the element itself
+    has the surface of the shim's (same type: the stub registers it out of the shim library)"""
+    out = _inspect(plugin, reference_names=True)
+    if plugin != factory:            # (where plugin and element share a name gst-inspect prints the element)
+        assert "Name" in out and plugin in out and library in out and factory + ":" in out, out[-1500:]
+    el = _inspect(factory, reference_names=True)
+    assert library in el and "Factory Details" in el, el[-1500:]
+    assert el.split("Factory Details")[1].split("Plugin Details")[0].strip() == _inspect(factory).split("Factory Details")[1].split("Plugin Details")[0].strip()
+    props = el.split("Element Properties")[1] if "Element Properties" in el else el
+    assert props == (_inspect(factory).split("Element Properties")[1] if "Element Properties" in el else "")
+
+
+def test_reference_named_plugins_pass_frames_through_without_gpu(shim):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    frames = [np.zeros((48, 64, 3), np.uint8)] * 3
+    r = _run_harness("nubofacedetector ! nuboeyedetector name=el detect-event=1", "BGR", 64, 48, frames, reference_names=True)
+    assert r.returncode == 0 and "done 0" in r.stdout, r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_face_to_eye_chain_under_the_reference_plugin_names(shim, synth_xml, orc_cascade):
+    """two of the six stub plugins in one pipeline: their elements come out of the one shim library and give what the single plugin gives"""
+    frames = _scene(8)
+    files = _part_files()
+    desc = "nubofacedetector ! nuboeyedetector name=el detect-event=1"
+    a = _run_harness(desc, "BGR", 640, 480, frames, cascade_xml=synth_xml, extra_cascades=files)
+    b = _run_harness(desc, "BGR", 640, 480, frames, cascade_xml=synth_xml, extra_cascades=files, reference_names=True)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1000:], b.stderr[-1000:])
+    ev = lambda r: [l for l in r.stdout.splitlines() if l.startswith("event ")]
+    assert ev(a) == ev(b) and any("eye" in l for l in ev(b))
