@@ -148,14 +148,18 @@ __device__ unsigned long long g_roi_phase[16];
 #define ROI_STAMP_ARGS
 #define ROI_STAMP_PASS
 #endif
-static constexpr int kRoiDeep = 4;
+static constexpr int kRoiDeep = 4;            // (diagnostic build: where the phase stamps split the stage walk)
+static constexpr int kRoiPairWin = 384;        // windows up to which a stage runs lane = (window, stump group)
 struct RoiLds { lds_i32 *s; lds_u32 *q; double *vnf; unsigned short *qa, *qb; int *cnt; lds_u8 *lev; };
 template <class Pos>
 __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const RoiStep &st, int li, int nx, int gy0, int gy1, int P, const RoiLds &L, Pos pos,
                                                  unsigned long long *__restrict__ hits, unsigned hit_cap ROI_STAMP_ARGS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nst = job.nstages, deep = nst < kRoiDeep ? nst : kRoiDeep;
+    const int nst = job.nstages;
+#ifdef NVCA_STAMPS
+    const int deep = nst < kRoiDeep ? nst : kRoiDeep;
+#endif
     const unsigned long long slot = (unsigned long long)job.slot << 32;
     if (tid < 4) L.cnt[tid] = 0;
     __syncthreads();
@@ -201,10 +205,24 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
     __syncthreads();
     ROI_STAMP(1);
 #endif
-    // ---- B: the counters rotate over three words (read cin, append to cout, clear the third): one barrier per stage
+    // ---- B: stage after stage on the compacted queue.  The counters rotate over three words (read cin, append to cout, clear the
+    // third): one barrier per stage.  Two ways through a stage:
+    //   * many windows (or votes that may not be re-ordered): a window per lane, the stage's stumps in OpenCV's order;
+    //   * at most kRoiPairWin windows and votes that are exact in any order (StageRec flag bit 1): lane = (window i, group g of the
+    //     stage's stumps), G = 1024 / n groups -- every wave of the workgroup is busy whatever n is, a lane walks count / G stumps
+    //     instead of the whole stage, and the partial sums meet in an f64 accumulator in LDS (ds_add_f64; exact, so the total
+    //     is the one OpenCV forms).  Round 3 ran the late stages a wave per window, a stump per lane: with a calibrated cascade
+    //     60-90 windows reach them and leave one by one, each stage of each window a chain of three global round trips (stage
+    //     record, stump records, wave reduction) on one wave -- 67-132 k cycles of a workgroup's 145-230 k.
+    // The accumulators live in the upper part of the first queue (entries 512 ..: a queue of <= 384 windows never reaches them).
     int cin = 0, cur = 0;
-    for (int sidx = 1; sidx < deep; sidx++) {
+    bool acc_ready = false;
+    double *acc = (double *)(L.qa + 512);
+    for (int sidx = 1; sidx < nst; sidx++) {
         __syncthreads();
+#ifdef NVCA_STAMPS
+        if (sidx == deep) ROI_STAMP(2);
+#endif
         const int n = L.cnt[cin];
         if (n == 0) break;
         const int cout = cin == 2 ? 0 : cin + 1;
@@ -214,56 +232,78 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
         // only kernel of the library with any)
         const unsigned short *qi = L.qa + cur * kRoiMaxWin;
         unsigned short *qo = L.qa + (cur ^ 1) * kRoiMaxWin;
-        for (int base = 0; base < n; base += kRoiThreads) {
-            const int i = base + tid;
-            bool pass = false; int wi = 0;
-            if (i < n) {
-                wi = qi[i];
+        const StageRec sr = job.stages[sidx];
+        if (n <= kRoiPairWin && (sr.flags & 2)) {
+            if (!acc_ready) {                          // (whatever earlier, longer queues left there)
+                if (tid < kRoiPairWin) acc[tid] = 0.;
+                acc_ready = true;
+                __syncthreads();
+            }
+            const bool pair = job.pair_policy && (sr.flags & 1);
+            int G = kRoiThreads / n;
+            if (G > sr.count) G = sr.count;
+            const int g = tid / n, i = tid - g * n;
+            if (g < G) {
+                const int wi = qi[i];
                 const int ry = wi / nx, gx = wi - ry * nx;
                 int x, y; pos(gx, gy0 + ry, x, y);
-                pass = roi_run_stages(L.s, y * P + x, P, L.vnf[wi], st.trecs, job.stages, sidx, sidx + 1, job.pair_policy) == sidx + 1;
+                const int off = y * P + x;
+                const double vnf = L.vnf[wi];
+                double p = 0.0;
+                for (int j = g; j < sr.count; j += G) p += roi_vote(L.s, off, P, vnf, st.trecs[sr.first + j], pair);
+                atomicAdd(&acc[i], p);
             }
-            const unsigned long long pm = __ballot(pass);
-            if (pm) {
-                int b2 = 0;
-                if (lane == 0) b2 = atomicAdd(&L.cnt[cout], (int)__popcll(pm));
-                b2 = __shfl(b2, 0);
-                if (pass) qo[b2 + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)wi;
+            __syncthreads();
+            bool pass = false; int wi = 0;
+            if (tid < n) { const double sum = acc[tid]; acc[tid] = 0.; pass = !(sum < (double)sr.thr); wi = qi[tid]; }
+            if (tid < ((n + 63) & ~63)) {              // the waves that hold a window of the queue (wave-uniform)
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    int b2 = 0;
+                    if (lane == 0) b2 = atomicAdd(&L.cnt[cout], (int)__popcll(pm));
+                    b2 = __shfl(b2, 0);
+                    if (pass) qo[b2 + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)wi;
+                }
+            }
+        } else {
+            for (int base = 0; base < n; base += kRoiThreads) {
+                const int i = base + tid;
+                bool pass = false; int wi = 0;
+                if (i < n) {
+                    wi = qi[i];
+                    const int ry = wi / nx, gx = wi - ry * nx;
+                    int x, y; pos(gx, gy0 + ry, x, y);
+                    pass = roi_run_stages(L.s, y * P + x, P, L.vnf[wi], st.trecs, job.stages, sidx, sidx + 1, job.pair_policy) == sidx + 1;
+                }
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    int b2 = 0;
+                    if (lane == 0) b2 = atomicAdd(&L.cnt[cout], (int)__popcll(pm));
+                    b2 = __shfl(b2, 0);
+                    if (pass) qo[b2 + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)wi;
+                }
             }
         }
         cur ^= 1; cin = cout;
     }
     __syncthreads();
-    ROI_STAMP(2);
-    // ---- C
-    const int n = L.cnt[cin];
 #ifdef NVCA_STAMPS
-    if (tid == 0) atomicAdd(&g_roi_phase[sbase + 5], (unsigned long long)n);
+    if (nst <= deep) ROI_STAMP(2);
 #endif
-    const unsigned short *qi = L.qa + cur * kRoiMaxWin;
-    for (int k = wave; k < n; k += kRoiWaves) {
-        const int wi = qi[k], gy = gy0 + wi / nx, gx = wi - (wi / nx) * nx;
-        int x, y; pos(gx, gy, x, y);
-        const int off = y * P + x;
-        const double vnf = L.vnf[wi];
-        bool alive = true;
-        for (int sidx = deep; sidx < nst && alive; sidx++) {
-            const StageRec sr = job.stages[sidx];
-            const bool pair = job.pair_policy && (sr.flags & 1);
-            double stage_sum = 0.0;
-            if (sr.flags & 2) {                       // exact in any order: a stump per lane, then across the wave
-                double p = 0.0;
-                for (int j = lane; j < sr.count; j += 64) p += roi_vote(L.s, off, P, vnf, st.trecs[sr.first + j], pair);
-                for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
-                stage_sum = p;
-            } else                                    // OpenCV's order: every lane walks the stage (wave-uniform, redundant, rare)
-                for (int j = 0; j < sr.count; j++) stage_sum += roi_vote(L.s, off, P, vnf, st.trecs[sr.first + j], pair);
-            alive = !(stage_sum < (double)sr.thr);
-        }
-        if (alive && lane == 0) {
-            const unsigned long long h = atomicAdd(hits, 1ull);
+    // ---- C: whoever is left passed every stage
+    const int nleft = nst > 1 ? L.cnt[cin] : L.cnt[0];
+#ifdef NVCA_STAMPS
+    if (tid == 0) atomicAdd(&g_roi_phase[sbase + 5], (unsigned long long)nleft);
+#endif
+    if (nleft > 0) {
+        if (tid == 0) L.cnt[3] = (int)(unsigned)atomicAdd(hits, (unsigned long long)nleft);
+        __syncthreads();
+        const unsigned long long hb = (unsigned long long)(unsigned)L.cnt[3];
+        const unsigned short *qi = L.qa + cur * kRoiMaxWin;
+        for (int k = tid; k < nleft; k += kRoiThreads) {
+            const int wi = qi[k], gy = gy0 + wi / nx, gx = wi - (wi / nx) * nx;
             const unsigned key = ((unsigned)li << 26) | ((unsigned)(st.key_y0 + gy * st.key_dy) << 13) | (unsigned)(st.key_x0 + gx * st.key_dx);
-            if (h < hit_cap) hits[1 + h] = slot | key;
+            if (hb + k < hit_cap) hits[1 + hb + k] = slot | key;
         }
     }
     __syncthreads();                                  // the queues are reused by the next band

@@ -11,8 +11,10 @@ from nubovca import capi, synth
 
 W, H, N, V = 1920, 1080, 16, 8
 ctx = capi.Context(0)
-face_c = ctx.load_cascade_xml(synth.synthetic_cascade_xml())
-pc = {n: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
+STANDIN = "--standin" in sys.argv          # rounds 1-3's uncalibrated cascades
+face_c = ctx.load_cascade_xml(synth.synthetic_cascade_xml() if STANDIN else synth.calibrated_cascade_xml())
+part_xml = synth.synthetic_part_cascade_xml if STANDIN else synth.calibrated_part_cascade_xml
+pc = {n: ctx.load_cascade_xml(part_xml(n)) for n in ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")}
 base = [(150, 200, 560), (1100, 260, 620)]
 frames = [synth.make_bgr(W, H, 40 + i, "natural", [(x + 8 * (i % 16), y, s) for x, y, s in base]) for i in range(N)]
 keep = [torch.from_numpy(f).cuda() for f in frames]
