@@ -148,7 +148,9 @@ __device__ unsigned long long g_roi_phase[16];
 #define ROI_STAMP_ARGS
 #define ROI_STAMP_PASS
 #endif
+#ifdef NVCA_STAMPS
 static constexpr int kRoiDeep = 4;            // (diagnostic build: where the phase stamps split the stage walk)
+#endif
 static constexpr int kRoiPairWin = 384;        // windows up to which a stage runs lane = (window, stump group)
 struct RoiLds { lds_i32 *s; lds_u32 *q; double *vnf; unsigned short *qa, *qb; int *cnt; lds_u8 *lev; };
 template <class Pos>
