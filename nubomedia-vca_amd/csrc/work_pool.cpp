@@ -69,8 +69,8 @@ struct WorkPool {
 };
 // One pool per PROCESS, shared by every context that asks for helpers (the GStreamer shim holds a context per GPU slot, a bench
 // may hold several): the first caller sizes it, later callers get the same threads -- contexts do not multiply spinning helpers
-// on an oversubscribed host.  A run is exclusive; a caller that finds the pool busy with another context's run does its own
-// work alone instead of waiting.
+// on an oversubscribed host.  A run is exclusive; a caller that finds the pool busy with another context's run waits for it
+// briefly (work_pool_run) and otherwise does its own work alone.
 static std::mutex g_pool_mu;
 static WorkPool *g_pool = nullptr;
 static int g_pool_refs = 0;
@@ -112,8 +112,21 @@ int work_pool_threads(const WorkPool *p) { return p ? (int)p->th.size() : 0; }
 void work_pool_run(WorkPool *p, int n, void (*fn)(void *, int), void *arg)
 {
     if (!p || p->th.empty() || n < 4) { for (int i = 0; i < n; i++) fn(arg, i); return; }
+    // another context's run may be open: it is over within tens of microseconds, and waiting that long for the helpers is cheaper than
+    // doing a round's jobs alone (two contexts of one process on two serving threads -- the shim's NVCA_VIRTUAL_GPUS=2 -- otherwise
+    // took turns at running their jobs serially); a run that stays busy for longer is not waited for
     std::unique_lock<std::mutex> run(p->run_mu, std::try_to_lock);
-    if (!run.owns_lock()) { for (int i = 0; i < n; i++) fn(arg, i); return; }      // another context's run is open
+    if (!run.owns_lock()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0; !run.owns_lock(); spins++) {
+            WorkPool::relax();
+            if ((spins & 31) == 31) {
+                if (run.try_lock()) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+            }
+        }
+        if (!run.owns_lock()) { for (int i = 0; i < n; i++) fn(arg, i); return; }
+    }
     p->fn = fn; p->arg = arg; p->n = n; p->next.store(0); p->finished.store(0);          // (no helper is inside: the previous run waited for that)
     const uint64_t g = p->gen.load() + 1;
     p->gen.store(g);

@@ -23,6 +23,18 @@ python3 $GRAFT_REPO_ROOT/scripts/stamps.py $OUT/stamps.bin > $OUT/stamps_k_band.
 # BASELINE config 3 with its breakdown, the trackers alone, and the N > 1 command line as the driver types it (two ranks rehearsed on this one GPU, gloo)
 timeout -k 10 600 python3 $GRAFT_REPO_ROOT/scripts/bench_roi_chain.py > $OUT/roi_chain.txt 2> $OUT/roi_chain.err
 timeout -k 10 300 python3 $GRAFT_REPO_ROOT/scripts/exp_face_tracker.py > $OUT/face_tracker.txt 2> $OUT/face_tracker.err
+timeout -k 10 300 python3 $GRAFT_REPO_ROOT/scripts/exp_trk_alone.py > $OUT/tracker_alone.txt 2> $OUT/tracker_alone.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trk_stats -- python3 $GRAFT_REPO_ROOT/scripts/exp_trk_alone.py > $OUT/trk_stats.log 2>&1
+python3 - $OUT >> $OUT/tracker_alone.txt <<'PY'
+import csv,glob,sys
+for f in glob.glob(sys.argv[1]+'/trk_stats/**/*kernel_stats.csv',recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'ccl' in r['Name'] or 'trk' in r['Name'] or 'rocclr' in r['Name']:
+            print("%-44s calls %6s avg %8.1f us total %8.2f ms"%(r['Name'][:44],r['Calls'],float(r['AverageNs'])/1e3,float(r['TotalDurationNs'])/1e6))
+PY
+NVCA_LIB=$GRAFT_REPO_ROOT/nubomedia-vca_amd/variants/stamps.so NVCA_STAMPS_OUT=$OUT/stamps_roi timeout -k 10 400 python3 $GRAFT_REPO_ROOT/scripts/exp_roi_stamps.py > $OUT/stamps_roi.log 2>&1; cp $OUT/stamps_roi.roi.txt $OUT/stamps_k_roi.txt 2>/dev/null
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/chain_trace -- python3 $GRAFT_REPO_ROOT/scripts/exp_roi_stamps.py > $OUT/chain_trace.log 2>&1
+python3 $GRAFT_REPO_ROOT/scripts/trace_gaps.py $OUT/chain_trace 0.5 > $OUT/roi_chain_gaps.txt 2>&1
 NVCA_BENCH_REHEARSAL=1 timeout -k 10 600 python3 $B --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_gpus2_rehearsal.json 2> $OUT/bench_gpus2_rehearsal.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +1M -delete; rm -f $OUT/stamps.bin
