@@ -1,6 +1,6 @@
 """Caller host memory reaches the HIP runtime as a raw pointer only inside a range the caller registered (nvca_host_register);
 everything else crosses through page-locked slots of the context's own (csrc/api.cpp caller_h2d / caller_h2d_rows / caller_d2h_rows:
-16 slots of 4 MB, each waited for before it is used again).  More than the ring holds in one context -- odd widths, images
+12 slots of 8 MB, each waited for before it is used again).  More than the ring holds in one context -- odd widths, images
 from one pixel row to several slots -- and memory that WAS registered and is pageable again (the history of the round-3 memory
 access fault); every result against the oracle."""
 import numpy as np
