@@ -11,6 +11,9 @@
 #include <fstream>
 #include <sstream>
 #include <chrono>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <stdexcept>
 #include <new>
 #include <thread>
@@ -743,17 +746,41 @@ static int bounce_used(nvca_ctx *ctx, int slot, hipStream_t st)
 }
 // large pieces are copied by the context's helper threads too (the PCIe link moves ~50 GB/s; one core's memcpy a fifth of that): as
 // many equal parts as there are threads, none below 256 KB
-static void host_copy(nvca_ctx *ctx, void *dst, const void *src, size_t bytes)
+// A large piece on its way INTO a page-locked slot is written once and next read by the DMA engine, never by this core: streaming
+// stores (no read-for-ownership of the destination lines, no pollution of the caches with 6 MB a frame).  memcpy picks them only
+// above a threshold that a thread's share of a frame does not reach.  NVCA_NT_COPY=0: plain memcpy.
+static void copy_streaming(uint8_t *d, const uint8_t *s, size_t n)
+{
+#if defined(__SSE2__)
+    static const bool on = [] { const char *e = getenv("NVCA_NT_COPY"); return !(e && e[0] == '0'); }();
+    if (on && n >= (64u << 10)) {
+        size_t head = (size_t)(-(intptr_t)d) & 15;
+        memcpy(d, s, head); d += head; s += head; n -= head;
+        const size_t blocks = n / 64;
+        for (size_t i = 0; i < blocks; i++, s += 64, d += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)s), b = _mm_loadu_si128((const __m128i *)(s + 16)),
+                          c = _mm_loadu_si128((const __m128i *)(s + 32)), e = _mm_loadu_si128((const __m128i *)(s + 48));
+            _mm_stream_si128((__m128i *)d, a); _mm_stream_si128((__m128i *)(d + 16), b);
+            _mm_stream_si128((__m128i *)(d + 32), c); _mm_stream_si128((__m128i *)(d + 48), e);
+        }
+        _mm_sfence();
+        n -= blocks * 64;
+    }
+#endif
+    memcpy(d, s, n);
+}
+static void host_copy(nvca_ctx *ctx, void *dst, const void *src, size_t bytes, bool into_slot = false)
 {
     static constexpr size_t kMinPart = 256u << 10;
     const int threads = work_pool_threads(ctx->pool) + 1;
     const int parts = (int)std::min<size_t>((size_t)threads, bytes / kMinPart);
-    if (parts < 4 || !ctx->pool) { memcpy(dst, src, bytes); return; }
-    struct Arg { uint8_t *d; const uint8_t *s; size_t n, part; } arg{(uint8_t *)dst, (const uint8_t *)src, bytes, ((bytes + parts - 1) / parts + 63) & ~(size_t)63};
+    if (parts < 4 || !ctx->pool) { if (into_slot) copy_streaming((uint8_t *)dst, (const uint8_t *)src, bytes); else memcpy(dst, src, bytes); return; }
+    struct Arg { uint8_t *d; const uint8_t *s; size_t n, part; bool nt; } arg{(uint8_t *)dst, (const uint8_t *)src, bytes, ((bytes + parts - 1) / parts + 63) & ~(size_t)63, into_slot};
     work_pool_run(ctx->pool, parts, [](void *a, int i) {
         const Arg *g = (const Arg *)a;
         const size_t o = (size_t)i * g->part;
-        if (o < g->n) memcpy(g->d + o, g->s + o, std::min(g->part, g->n - o));
+        if (o >= g->n) return;
+        if (g->nt) copy_streaming(g->d + o, g->s + o, std::min(g->part, g->n - o)); else memcpy(g->d + o, g->s + o, std::min(g->part, g->n - o));
     }, &arg);
 }
 static void ensure_pool(nvca_ctx *ctx)
@@ -776,7 +803,7 @@ int caller_h2d(nvca_ctx *ctx, void *dst, const void *src, size_t bytes, hipStrea
         const size_t len = std::min(BounceRing::kSlot, bytes - o);
         uint8_t *h; int slot, rc;
         if ((rc = bounce_take(ctx, &h, &slot))) return rc;
-        host_copy(ctx, h, (const uint8_t *)src + o, len);
+        host_copy(ctx, h, (const uint8_t *)src + o, len, true);
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)dst + o, h, len, hipMemcpyHostToDevice, st));
         if ((rc = bounce_used(ctx, slot, st))) return rc;
     }
@@ -796,7 +823,7 @@ int caller_h2d_rows(nvca_ctx *ctx, void *dst, size_t dpitch, const void *src, si
         const size_t nr = std::min(per, rows - r0);
         uint8_t *h; int slot, rc;
         if ((rc = bounce_take(ctx, &h, &slot))) return rc;
-        if (spitch == width) host_copy(ctx, h, (const uint8_t *)src + r0 * spitch, nr * width);
+        if (spitch == width) host_copy(ctx, h, (const uint8_t *)src + r0 * spitch, nr * width, true);
         else for (size_t y = 0; y < nr; y++) memcpy(h + y * width, (const uint8_t *)src + (r0 + y) * spitch, width);
         if (dpitch == width) NVCA_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t *)dst + r0 * dpitch, h, nr * width, hipMemcpyHostToDevice, st));
         else NVCA_HIP_CHECK(ctx, hipMemcpy2DAsync((uint8_t *)dst + r0 * dpitch, dpitch, h, width, width, nr, hipMemcpyHostToDevice, st));
