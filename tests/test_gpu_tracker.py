@@ -161,3 +161,37 @@ def test_tracker_component_paths_agree_and_root_list_overflow_falls_back(ctx, fo
             seen += len(exp)
         assert seen > 0
         trk.close()
+
+
+def test_tracker_batches_of_changing_shape_share_one_workspace(ctx):
+    """The live-tile list of the component kernels (marks stamped with the launch's tick, a count per slot) lives in the context's
+    tracker workspace and is laid out per (frame size, batch): calls that alternate between batch sizes, and one call that mixes two
+    frame sizes (two launch sets), must not read each other's marks -- every stream against its own oracle tracker, tick by tick."""
+    import orc
+    from nubovca import capi
+    geos = [(640, 480), (640, 480), (640, 480), (352, 288), (352, 288)]
+    n = 7
+    seqs = [moving_scene(W, H, n, 5, 900 + s, noise=(3 if s % 2 else 0)) for s, (W, H) in enumerate(geos)]
+    trks = [capi.Tracker(ctx) for _ in geos]
+    otrs = [orc.Tracker() for _ in geos]
+    # which streams take part in tick i: all five (two launch sets), then three of one size, then one alone, then the two small ones ...
+    parts = [[0, 1, 2, 3, 4], [0, 1, 2], [3], [3, 4], [0, 1, 2, 3, 4], [1], [0, 1, 2, 3, 4]]
+    seen = [0] * len(geos)
+    found = 0
+    for i in range(n):
+        who = parts[i]
+        frames, ts = [], []
+        for s in who:
+            W, H = geos[s]
+            fr = seqs[s][seen[s]]
+            frames.append(capi.make_frame(fr.ctypes.data, W, H, W * 4, capi.MEM_HOST))
+            ts.append(5000.0 + 33.3 * seen[s])
+        res = capi.tracker_batch_process(ctx, [trks[s] for s in who], frames, ts)
+        for k, s in enumerate(who):
+            exp = otrs[s].process(seqs[s][seen[s]], ts[k], cap=1 << 16)
+            assert np.array_equal(res[k], exp), (i, s)
+            found += len(exp)
+            seen[s] += 1
+    assert found > 0
+    for t in trks:
+        t.close()
