@@ -241,7 +241,7 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
     f720, ms720, f720s, ms720s = multi(1280, 720, 32, False)
     ftrk, mstrk, ftrks, mstrks = multi(1920, 1080, 8, True)
     # BASELINE configs[2]: the face -> eye / nose / mouth / ear chain on V concurrent 1080p streams, batched entry points
-    def roi_chain(base, V=8, ticks=4, reps=6, contexts=1, calibrated=True):
+    def roi_chain(base, V=8, ticks=4, reps=6, contexts=1, calibrated=True, inflight=False):
         """V video streams x (face detector + eye + nose + mouth + ear detectors, own face pass each) per tick.  contexts = 2: the streams
         are dealt to two contexts of this GPU, a serving thread each (what the GStreamer shim does with NVCA_VIRTUAL_GPUS=2: a
         context per slot) -- one context's host work between its three waits runs beside the other's kernels."""
@@ -272,8 +272,24 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
             cc.face_batch_collect(tk)
             found[c] += sum(len(a) + len(b) for a, b in res)
 
+        def submit(c, i):
+            cc, fcs, parts = S[c]
+            fb = [frs[i % ticks][v] for v in share[c]]
+            return capi.part_batch_submit(cc, parts, [f for f in fb for _ in range(4)]), cc.face_batch_submit(fcs, fb)
+
         def run(i0, i1):
-            if contexts == 1:
+            if contexts == 1 and inflight:
+                # two part batches in flight: tick i + 1's gates, images and face passes are queued before tick i is collected
+                cc = S[0][0]
+                pt, ft = submit(0, i0)
+                for i in range(i0, i1):
+                    nxt = submit(0, i + 1) if i + 1 < i1 else None
+                    res = capi.part_batch_collect(cc, pt)
+                    cc.face_batch_collect(ft)
+                    found[0] += sum(len(a) + len(b) for a, b in res)
+                    if nxt:
+                        pt, ft = nxt
+            elif contexts == 1:
                 for i in range(i0, i1):
                     tick(0, i)
             else:
@@ -324,12 +340,15 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
     on1080 = (W, H) == (1920, 1080)
     froi, msroi, nparts, roiroof = roi_chain(big) if on1080 else (None, None, None, None)
     froi2, msroi2, nparts2, roiroof2 = roi_chain(big, contexts=2) if on1080 else (None, None, None, None)
+    froi3, msroi3, nparts3, roiroof3 = roi_chain(big, inflight=True) if on1080 else (None, None, None, None)
     fold, msold, npold, rold = roi_chain(big, calibrated=False) if on1080 else (None, None, None, None)
     fsp, mssp, npsp, rsp = roi_chain([(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)], calibrated=False) if on1080 else (None, None, None, None)
     tab["workloads"] = {"roi_chain": {"frames_per_s": froi, "ms_per_tick": msroi, "streams": 8, "parts_per_frame": nparts, "roofline": roiroof,
                                       "note": "BASELINE configs[2]: 8 x 1080p streams x (face detector + eye + nose + mouth + ear, own face pass each), nvca_face_batch_submit/collect around nvca_part_batch_process, one context, one serving thread; part cascades calibrated on face regions (every early stage lets ~2/3 through); scripts/bench_roi_chain.py gives the breakdown"},
                         "roi_chain_2ctx": {"frames_per_s": froi2, "ms_per_tick": msroi2, "streams": 8, "parts_per_frame": nparts2, "roofline": roiroof2,
                                            "note": "the same 8 streams dealt to two contexts of this GPU with a serving thread each (the GStreamer shim's NVCA_VIRTUAL_GPUS=2): one context's host work between its waits runs beside the other's kernels"},
+                        "roi_chain_two_in_flight": {"frames_per_s": froi3, "ms_per_tick": msroi3, "streams": 8, "parts_per_frame": nparts3, "roofline": roiroof3,
+                                                    "note": "the same 8 streams, one context, one serving thread, nvca_part_batch_submit / _collect: tick k + 1's gates, working images and face passes are queued before tick k's searches are collected (results arrive one tick later)"},
                         "roi_chain_standin_parts": {"frames_per_s": fold, "ms_per_tick": msold, "streams": 8, "parts_per_frame": npold, "roofline": rold,
                                                     "note": "as roi_chain with rounds 2-3's uncalibrated part cascades (their early stages let ~150 windows per face region through to the late stages)"},
                         "roi_chain_sparse": {"frames_per_s": fsp, "ms_per_tick": mssp, "streams": 8, "parts_per_frame": npsp, "roofline": rsp,

@@ -315,6 +315,19 @@ int  nvca_part_stream_process(nvca_part_stream *s, const nvca_frame *frame_bgr, 
 int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames,
                              nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
 
+/* The same call in two halves, for a serving loop that keeps the GPU busy between the waits of a call (the counterpart of
+ * nvca_face_batch_submit / _collect; the reference has no such boundary: its elements run one frame at a time on their streaming
+ * threads, kms*detect.cpp transform_frame_ip).  submit: the streams' frame gates, the working images and the face passes are
+ * queued -- nothing is waited for -- and *ticket names the call; the frames must stay valid until the ticket is collected.
+ * collect: the face passes' results, the part searches, the merging heuristics; outputs as nvca_part_batch_process.  Tickets are
+ * collected in submit order (the streams' state machines advance in that order); at most two are outstanding, so the usual loop
+ * is submit(k + 1), collect(k).  A stream may appear in both outstanding calls (not in a synchronous nvca_part_batch_process /
+ * nvca_part_stream_process while a ticket of its is outstanding: refused).  A collect that fails rolls its streams back as a
+ * failed nvca_part_batch_process does and abandons a newer outstanding ticket with it (rolled back first); a ticket that is never
+ * collected is rolled back when the context is destroyed. */
+int  nvca_part_batch_submit(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, int *ticket);
+int  nvca_part_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
+
 /* ---- NuboTracker stream -------------------------------------------------
  * Replaces gst_nubo_tracker_img_conf + gst_nubo_tracker_process
  * (TRK/gstnubotracker.cpp:202-237, 339-421): BGRA -> gray, absdiff, threshold,

@@ -953,13 +953,14 @@ nvca_ctx::~nvca_ctx()
     nvca::free_scale_tables(this);
     if (ws) ws->release_all();
     trk.release_all();
-    part.release_all();
+    for (void *&c : part_calls) if (c && part_call_free) { part_call_free(c); c = nullptr; }      // submitted, never collected: rolled back, drained
+    for (nvca::PartWorkspace &w : part_sets) w.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     bounce.release();
     nvca::work_pool_destroy(pool); pool = nullptr;
     overlay_img.release();
     for (auto &kv : roi_stage_recs) { kv.second->release(); delete kv.second; }
-    roi_tables.release(); roi_hits.release(); roi_h_tables.release(); roi_h_hits.release();
+    for (RoiBuffers &b : roi_bufs) { b.tables.release(); b.hits.release(); b.h_tables.release(); b.h_hits.release(); }
     for (auto e : timer.pool) (void)hipEventDestroy(e);
     for (auto &e : timer.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (nvca::FaceTicket *&t : face_tickets) { nvca::free_face_ticket(t); t = nullptr; }
@@ -2229,27 +2230,27 @@ static int roi_launch(nvca_ctx *ctx, RoiBatch &rb, bool full_cap)
     rb.cap = (unsigned)std::min<long long>(want, full_cap ? (1ll << 26) : (1ll << 18));
     const size_t first = std::min<size_t>(rb.cap, std::max<size_t>(8192, ctx->roi_first_hint));
     rb.first = first;
-    if (ctx->roi_tables.ensure(total) || ctx->roi_h_tables.ensure(total) || ctx->roi_hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->roi_h_hits.ensure(((size_t)rb.cap + 1) * 8)) {
+    if (ctx->rbuf().tables.ensure(total) || ctx->rbuf().h_tables.ensure(total) || ctx->rbuf().hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->rbuf().h_hits.ensure(((size_t)rb.cap + 1) * 8)) {
         ctx->set_error("allocation failed (small-image detector)"); return NVCA_ERR_NOMEM;
     }
-    unsigned char *h = ctx->roi_h_tables.as<unsigned char>();
+    unsigned char *h = ctx->rbuf().h_tables.as<unsigned char>();
     memcpy(h, rb.jobs.data(), jb); memcpy(h + o_steps, rb.steps.data(), sb);
     if (!rb.tabs.empty()) memcpy(h + o_tabs, rb.tabs.data(), rb.tabs.size());
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->roi_tables.p, h, total - 64, hipMemcpyHostToDevice, ctx->cs()));
-    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ctx->roi_hits.p, 0, sizeof(unsigned long long), ctx->cs()));
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->rbuf().tables.p, h, total - 64, hipMemcpyHostToDevice, ctx->cs()));
+    NVCA_HIP_CHECK(ctx, hipMemsetAsync(ctx->rbuf().hits.p, 0, sizeof(unsigned long long), ctx->cs()));
     const int lds = rb.plane_words * 8 + kRoiMaxWin * (8 + 2 + 2) + 16 + ((rb.lev_bytes + 15) & ~15) + 64;      // k_roi's carve-up
     if (const int e = roi_grant_lds(lds)) { ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e)); return NVCA_ERR_HIP; }
-    const unsigned char *d = ctx->roi_tables.as<unsigned char>();
+    const unsigned char *d = ctx->rbuf().tables.as<unsigned char>();
     { TimedLaunch t(ctx, NVCA_K_ROI);
-      launch_roi(ctx->cs(), (const RoiJobDev *)d, (int)rb.steps.size(), (const RoiStep *)(d + o_steps), d + o_tabs, ctx->roi_hits.as<unsigned long long>(), rb.cap, rb.plane_words, lds); }
+      launch_roi(ctx->cs(), (const RoiJobDev *)d, (int)rb.steps.size(), (const RoiStep *)(d + o_steps), d + o_tabs, ctx->rbuf().hits.as<unsigned long long>(), rb.cap, rb.plane_words, lds); }
     NVCA_LAUNCH_CHECK(ctx);
-    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->roi_h_hits.p, ctx->roi_hits.p, (first + 1) * 8, hipMemcpyDeviceToHost, ctx->cs()));
+    NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->rbuf().h_hits.p, ctx->rbuf().hits.p, (first + 1) * 8, hipMemcpyDeviceToHost, ctx->cs()));
     return NVCA_OK;
 }
 // after the lane has drained: hand every job its candidates; NVCA_ERR_OVERFLOW (with hit_cap_wanted set) when the list was too short
 static int roi_collect(nvca_ctx *ctx, RoiBatch &rb)
 {
-    unsigned long long *hh = ctx->roi_h_hits.as<unsigned long long>();
+    unsigned long long *hh = ctx->rbuf().h_hits.as<unsigned long long>();
     const unsigned long long total = hh[0];
     const int nj = (int)rb.jobs.size();
     if (total > rb.cap) {
@@ -2263,7 +2264,7 @@ static int roi_collect(nvca_ctx *ctx, RoiBatch &rb)
     ctx->roi_first_hint = std::max<size_t>((size_t)(total + total / 4), ctx->roi_first_hint - ctx->roi_first_hint / 16);
     const size_t first = rb.first;
     if (total > first) {
-        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ctx->roi_hits.as<unsigned long long>() + 1 + first, (total - first) * 8, hipMemcpyDeviceToHost, ctx->cs()));
+        NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ctx->rbuf().hits.as<unsigned long long>() + 1 + first, (total - first) * 8, hipMemcpyDeviceToHost, ctx->cs()));
         NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
     }
     // (the list is in the order the workgroups appended: every job sorts its own keys into the serial order when it advances)
@@ -2367,13 +2368,13 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
 // ---- working images of a batched part call ---------------------------------------------------------------------------
 int part_arena(nvca_ctx *ctx, size_t bytes, uint8_t **base)
 {
-    if (ctx->part.arena.ensure(bytes + 256)) { ctx->set_error("allocation failed (part detectors' images)"); return NVCA_ERR_NOMEM; }
-    *base = ctx->part.arena.as<uint8_t>();
+    if (ctx->pw().arena.ensure(bytes + 256)) { ctx->set_error("allocation failed (part detectors' images)"); return NVCA_ERR_NOMEM; }
+    *base = ctx->pw().arena.as<uint8_t>();
     return NVCA_OK;
 }
 int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep)
 {
-    PartWorkspace &pw = ctx->part;
+    PartWorkspace &pw = ctx->pw();
     const size_t need_l = (size_t)(n_keep + n_scratch + 1) * 256, need_h = (size_t)(std::max(n_keep, n_scratch) + 1) * 256 * sizeof(unsigned);
     if (pw.luts.ensure(need_l)) { ctx->set_error("allocation failed (part detectors' LUTs)"); return NVCA_ERR_NOMEM; }
     const void *old = pw.hist.p;
@@ -2385,7 +2386,7 @@ int part_luts(nvca_ctx *ctx, int n_keep, int n_scratch, uint8_t **keep)
 // a small table for the next launch: page-locked staging ring -> device ring, copied on the current lane
 int part_table(nvca_ctx *ctx, const void *host, size_t bytes, void **dev)
 {
-    PartWorkspace &pw = ctx->part;
+    PartWorkspace &pw = ctx->pw();
     static constexpr size_t kRing = 256 * 1024;
     if (pw.tables.ensure(kRing) || pw.h_tables.ensure(kRing)) { ctx->set_error("allocation failed (part detectors' tables)"); return NVCA_ERR_NOMEM; }
     const size_t room = round_up(bytes, 64);
@@ -2407,7 +2408,7 @@ int part_gray_eq(nvca_ctx *ctx, const void *const *bgr, int n, int w, int h, int
     g.gpitch = w; g.gray_slot = slot;
     bool aligned = stride % 4 == 0 && w % 4 == 0 && slot % 4 == 0 && ((uintptr_t)gray & 3) == 0;
     for (int k = 0; k < n; k++) aligned = aligned && ((uintptr_t)bgr[k] & 3) == 0;
-    unsigned *hist = ctx->part.hist.as<unsigned>();
+    unsigned *hist = ctx->pw().hist.as<unsigned>();
     { TimedLaunch t(ctx, NVCA_K_GRAY);
       launch_gray(ctx->cs(), (const uint8_t *const *)d_ptrs, g, 0, nullptr, nullptr, nullptr, nullptr, w, gray, hist, n, aligned); }
     { TimedLaunch t(ctx, NVCA_K_LUT); launch_lut(ctx->cs(), hist, w * h, luts, n, 1); }
@@ -2428,9 +2429,9 @@ int part_image_batch(nvca_ctx *ctx, const PartImageBatch &b, const uint8_t *luts
     if (with_lut) memcpy(tab.data() + (size_t)n * sizeof(void *), b.lut_idx.data(), (size_t)n * sizeof(int));
     void *d_tab = nullptr;
     if ((rc = part_table(ctx, tab.data(), tab.size(), &d_tab))) return rc;
-    unsigned *hist = b.post_eq ? ctx->part.hist.as<unsigned>() : nullptr;
-    uint8_t *scratch = ctx->part.luts.as<uint8_t>() + ctx->part.luts.bytes - (size_t)(n + 1) * 256;       // the scratch LUTs sit at the end
-    if (b.post_eq && (size_t)(n + 1) * 256 > ctx->part.luts.bytes) { ctx->set_error("internal: LUT storage"); return NVCA_ERR_ARG; }
+    unsigned *hist = b.post_eq ? ctx->pw().hist.as<unsigned>() : nullptr;
+    uint8_t *scratch = ctx->pw().luts.as<uint8_t>() + ctx->pw().luts.bytes - (size_t)(n + 1) * 256;       // the scratch LUTs sit at the end
+    if (b.post_eq && (size_t)(n + 1) * 256 > ctx->pw().luts.bytes) { ctx->set_error("internal: LUT storage"); return NVCA_ERR_ARG; }
     { TimedLaunch t(ctx, NVCA_K_RESIZE1);
       launch_work_resize(ctx->cs(), b.bgr, (const uint8_t *const *)d_tab, with_lut ? (const int *)((uint8_t *)d_tab + (size_t)n * sizeof(void *)) : nullptr, luts,
                          b.sh, b.sstride, gp->tab.mode, gp->d_xofs.as<int>(), gp->d_ialpha.as<short>(), gp->d_yofs.as<int>(), gp->d_ibeta.as<short>(),
@@ -2450,7 +2451,7 @@ int part_flip_batch(nvca_ctx *ctx, const uint8_t *src, uint8_t *dst, int w, int 
 }
 int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
 {
-    PartWorkspace &pw = ctx->part;
+    PartWorkspace &pw = ctx->pw();
     if (!pw.images_done) NVCA_HIP_CHECK(ctx, hipEventCreateWithFlags(&pw.images_done, hipEventDisableTiming));
     NVCA_HIP_CHECK(ctx, hipEventRecord(pw.images_done, ctx->cs()));
     for (int i = 0; i < n; i++)
@@ -2463,23 +2464,27 @@ int part_images_done(nvca_ctx *ctx, const int *lanes, int n)
 double g_jobs_fine_s[6] = {0, 0, 0, 0, 0, 0};        // NVCA_PART_STATS: roi_add_job, roi_launch, roi_collect, helper-thread advance, serial advance, small-path jobs (count)
 double g_jobs_enqueue_s = 0, g_jobs_wait_s = 0, g_jobs_advance_s = 0;      // NVCA_PART_STATS (diagnostic, one context at a time): where run_detect_jobs spends the host's time
 static inline double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
+// One round of a job set in two halves, so that a caller may leave a round queued and come back for it (parts.cpp: a submitted part-detector
+// batch keeps its face passes in flight while the batch before it is collected).  begin: every unfinished job queues its next launch
+// set (small images: all in ONE k_roi launch); end: the lanes are waited for, the candidates handed out, every job advanced.
+struct JobRound { RoiBatch rb; bool used[kLanes] = {false}; int rc = NVCA_OK; double t1 = 0; int roi_regrown = 0; };
+static int jobs_round_begin(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, int lane0, JobRound &R, bool *pending_out)
 {
-    const int lane0 = ctx->cur_lane;
     const bool g_job_stats = ctx->sw.part_stats > 0;
-    struct Restore { nvca_ctx *c; int l, cap, wanted; ~Restore() { c->cur_lane = l; c->hit_cap = cap; c->hit_cap_wanted = wanted; } } restore{ctx, lane0, ctx->hit_cap, ctx->hit_cap_wanted};
-    ctx->hit_cap_wanted = 0;                 // (what the batched face path may have noted for its next batch is put back at the end)
-    int roi_regrown = 0;
-    for (;;) {
+    const int roi_regrown = R.roi_regrown;
+    {
         if (ctx->hit_cap_wanted > ctx->hit_cap) ctx->hit_cap = ctx->hit_cap_wanted;      // a set overflowed in the last round: it runs again with room (this call only)
         int pending = 0;
         for (int i = 0; i < n; i++) if (jobs[i]->phase != 3) pending++;
-        if (!pending) return NVCA_OK;
-        int rc = NVCA_OK;
-        bool used[kLanes] = {false};
+        if (!pending) { *pending_out = false; return NVCA_OK; }
+        *pending_out = true;
+        int &rc = R.rc; rc = NVCA_OK;
+        bool (&used)[kLanes] = R.used;
+        for (bool &u : used) u = false;
         const double t0 = g_job_stats ? mono_s() : 0;
         // small images first: every such job of the round goes into ONE k_roi launch (no plan, no per-job launches)
-        RoiBatch rb;
+        R.rb = RoiBatch();
+        RoiBatch &rb = R.rb;
         for (int i = 0; i < n && !rc; i++) {
             DetectJob &j = *jobs[i];
             if (j.phase == 3) continue;
@@ -2506,8 +2511,22 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
         const double tl = g_job_stats ? mono_s() : 0;
         if (!rc && !rb.jobs.empty()) { ctx->cur_lane = rb.lane; used[rb.lane] = true; rc = roi_launch(ctx, rb, roi_regrown > 0); }
         const double t1 = g_job_stats ? mono_s() : 0;
+        R.t1 = t1;
         if (g_job_stats) g_jobs_fine_s[1] += t1 - tl;
         if (g_job_stats) g_jobs_enqueue_s += t1 - t0;
+    }
+    ctx->cur_lane = lane0;
+    return NVCA_OK;          // (a failed enqueue is carried in R.rc: the round is still waited for and closed by jobs_round_end)
+}
+static int jobs_round_end(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, int lane0, JobRound &R)
+{
+    const bool g_job_stats = ctx->sw.part_stats > 0;
+    int rc = R.rc;
+    bool (&used)[kLanes] = R.used;
+    RoiBatch &rb = R.rb;
+    int &roi_regrown = R.roi_regrown;
+    const double t1 = R.t1;
+    {
         for (int l = 0; l < kLanes; l++) {
             if (!used[l]) continue;
             const hipError_t he = hipStreamSynchronize(ctx->lane_streams[l]);
@@ -2580,7 +2599,42 @@ int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lan
             for (int i = 0; i < n; i++) { if (jobs[i]->gp) { jobs[i]->gp->inflight--; jobs[i]->gp = nullptr; } jobs[i]->phase = 3; }
             return rc;
         }
+        return NVCA_OK;
     }
+}
+JobRound *job_round_new() { return new (std::nothrow) JobRound(); }
+void job_round_free(JobRound *r) { delete r; }
+// the first round of a job set, left queued (R from job_round_new).  Jobs that cannot take the small-image path make the caller
+// wait for the round as before: *queued = false and nothing is launched.
+int detect_jobs_begin(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, JobRound *R, bool *queued)
+{
+    *queued = false;
+    for (int i = 0; i < n; i++) if (jobs[i]->phase != 0 || !roi_eligible(ctx, *jobs[i], n)) return NVCA_OK;
+    const int lane0 = ctx->cur_lane;
+    bool pending = false;
+    const int rc = jobs_round_begin(ctx, jobs, n, lanes, lane0, *R, &pending);
+    ctx->cur_lane = lane0;
+    *queued = pending;
+    return rc;
+}
+// ... and the rest of the set: the queued round is closed (queued == true), then round after round until every job is done
+int detect_jobs_finish(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, JobRound *R, bool queued)
+{
+    const int lane0 = ctx->cur_lane;
+    struct Restore { nvca_ctx *c; int l, cap, wanted; ~Restore() { c->cur_lane = l; c->hit_cap = cap; c->hit_cap_wanted = wanted; } } restore{ctx, lane0, ctx->hit_cap, ctx->hit_cap_wanted};
+    ctx->hit_cap_wanted = 0;
+    if (queued) { const int rc = jobs_round_end(ctx, jobs, n, lanes, lane0, *R); if (rc) return rc; }
+    for (;;) {
+        bool pending = false;
+        int rc = jobs_round_begin(ctx, jobs, n, lanes, lane0, *R, &pending);
+        if (!pending) return rc;
+        if ((rc = jobs_round_end(ctx, jobs, n, lanes, lane0, *R))) return rc;
+    }
+}
+int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes)
+{
+    JobRound R;
+    return detect_jobs_finish(ctx, jobs, n, lanes, &R, false);
 }
 
 } // namespace nvca

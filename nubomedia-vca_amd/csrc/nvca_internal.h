@@ -320,14 +320,23 @@ struct nvca_ctx {
     std::map<std::pair<uint64_t, uint64_t>, nvca::ScaleTable *> scale_tables;   // (cascade uid, factor bits)
     std::unique_ptr<nvca::Workspace> ws;
     nvca::TrkWorkspace trk;           // tracker buffers live and die with the context
-    nvca::PartWorkspace part;
+    // the working images / tables of a batched part-detector call; two sets: a submitted call (nvca_part_batch_submit) may be in
+    // flight while the one before it is collected -- a call uses the set of its ticket's parity (parts.cpp sets part_set)
+    nvca::PartWorkspace part_sets[2]; int part_set = 0;
+    nvca::PartWorkspace &pw() { return part_sets[part_set]; }
+    void *part_calls[2] = {nullptr, nullptr};  // submitted, not yet collected part-detector calls (parts.cpp: PartCall), by ticket parity
+    void (*part_call_free)(void *) = nullptr;
+    int part_seq = 0;                         // the next ticket
     nvca::Switches sw;                // this context's switches: the process defaults (environment), nvca_ctx_set_option overrides
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)
     void *identity_lut = nullptr;     // 256 B on device
     nvca::DevBuf overlay_img;         // the caller's overlay image on the device (nvca_overlay_blend on device frames)
     // small-image detector (kernels_roi.hip): per-cascade stage records on the device, the tables / candidate list of a launch
     std::map<uint64_t, nvca::DevBuf *> roi_stage_recs;
-    nvca::DevBuf roi_tables, roi_hits; nvca::PinnedBuf roi_h_tables, roi_h_hits;
+    // (three sets: [0] the synchronous callers', [1] / [2] the part-detector calls in flight by ticket parity -- a round of theirs stays
+    // queued between submit and collect)
+    struct RoiBuffers { nvca::DevBuf tables, hits; nvca::PinnedBuf h_tables, h_hits; } roi_bufs[3]; int roi_set = 0;
+    RoiBuffers &rbuf() { return roi_bufs[roi_set]; }
     size_t roi_first_hint = 0;              // candidates of the recent small-image rounds (+ a quarter): what the launch copies back with itself
     nvca::WorkPool *pool = nullptr; bool pool_tried = false;
     std::mutex err_mu;                // set_error may be called from the helper threads
@@ -600,6 +609,12 @@ struct DetectJob;
 int make_detect_job(nvca_ctx *ctx, DetectJob &j, const nvca_cascade *casc, const void *gray, int w, int h, int stride, int mem,
                     double sf, int min_neighbors, int flags, int minw, int minh, int maxw, int maxh, bool raw_only);
 int run_detect_jobs(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes);      // lanes: per job, or null (current lane)
+// ... in two halves: the first round queued and left in flight, then the rest (api.cpp)
+struct JobRound;
+JobRound *job_round_new();
+void job_round_free(JobRound *r);
+int detect_jobs_begin(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, JobRound *R, bool *queued);
+int detect_jobs_finish(nvca_ctx *ctx, DetectJob *const *jobs, int n, const int *lanes, JobRound *R, bool queued);
 DetectJob *detect_job_new();
 void detect_job_free(DetectJob *j);
 const std::vector<nvca_rect> &detect_job_out(const DetectJob *j, int k);

@@ -198,18 +198,59 @@ try {
 }
 NVCA_API_CATCH((s ? s->ctx : nullptr))
 
-// One transform_frame_ip of every stream of the batch.  The streams' device work is queued together and waited for three
-// times per call, however many streams there are: (1) the working images of all frames (a launch set per image size) and the
-// face passes (an N-image job per kind of pass), (2) every part search in every face's region (FIND_BIGGEST searches that
-// narrow their scan take one more round), (3) nothing -- the merging heuristics that follow are host code on the collected boxes.
-int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, nvca_rect *out_a, int cap_a,
-                            int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
-try {
-    NVCA_LOCK_OR_FAIL(ctx);
-    // diagnostic (NVCA_PART_STATS): the whole call, entry to the last destructor, next to the phase timers below
-    static double total_acc = 0, phase3_acc = 0;
-    struct Whole { bool on; double t0; ~Whole() { if (on) total_acc += mono_s() - t0; } } whole{ctx->sw.part_stats > 0 && n >= ctx->sw.part_stats, ctx->sw.part_stats > 0 ? mono_s() : 0};
-    if (n < 0 || (n > 0 && (!streams || !frames || !n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
+} // extern "C"
+
+// ---- a batched call in two halves -------------------------------------------------------------------------------------------------
+// front: the gates of every stream, the working images and the face passes QUEUED (nothing is waited for); back: the face passes'
+// results, the part searches in every face's region, the merging heuristics.  nvca_part_batch_process runs them back to back;
+// nvca_part_batch_submit / _collect let the caller queue the next frames' front half before it collects this frames' back half, so
+// that the image chains and face passes of tick k + 1 fill the GPU while tick k's searches are advanced on the host (two calls may be
+// in flight: each uses the working-image set, candidate buffers and lanes of its ticket's parity).
+namespace {
+struct StreamSnap { nvca_part_stream *s; RectV faces, la, lb; int num_frame, to_process, no_a, no_b; bool popped; RectV front; };
+static double g_total_acc = 0, g_phase3_acc = 0;          // NVCA_PART_STATS (diagnostic, one context at a time)
+static constexpr int kCallLanes = 3;                      // lanes of one call: images on the first, face passes and part searches side by side on all three
+struct PartCall {
+    nvca_ctx *ctx = nullptr; int n = 0, parity = 0, seq = 0;
+    std::vector<nvca_part_stream *> streams; std::vector<nvca_frame> frames;
+    std::vector<FrameGroup> groups;
+    std::vector<ImageBatch> batches;
+    std::deque<FacePass> passes;
+    std::vector<PartWork> work;
+    std::vector<DetectJob *> jobs;
+    std::vector<int> job_lane;
+    int n_eye = 0;
+    JobRound *round = nullptr; bool queued = false;       // the face passes' first round, left in flight by the front half
+    double t0 = 0, t1 = 0;
+    // The gates of phase 1a (and find_ears_begin in phase 2) advance per-stream state; plans, buffers and launches come after
+    // them and may still fail (too many scales, allocation, a refused launch).  Whatever the error, the call leaves every
+    // stream as it found it -- the GStreamer shim re-runs the streams one by one after a refused batch, and a gate that had
+    // already advanced would then advance twice and drop a queued face event.  Nothing of the call may stay in flight either:
+    // the caller's frames (H2D copies) and the arena are only safe to reuse once the lanes have drained.
+    std::vector<StreamSnap> snaps; bool armed = true;
+    ~PartCall()
+    {
+        if (armed && ctx) {
+            (void)hipDeviceSynchronize();
+            for (StreamSnap &g : snaps) {
+                nvca_part_stream *s = g.s;
+                s->faces.swap(g.faces); s->la.swap(g.la); s->lb.swap(g.lb);
+                s->num_frame = g.num_frame; s->num_frames_to_process = g.to_process; s->no_det_a = g.no_a; s->no_det_b = g.no_b;
+                if (g.popped) s->queue.push_front(std::move(g.front));
+            }
+        }
+        job_round_free(round);
+    }
+};
+struct CallSets {            // the context's per-call selections, put back when the half is over
+    nvca_ctx *c; int part_set, roi_set;
+    CallSets(nvca_ctx *x, int parity) : c(x), part_set(x->part_set), roi_set(x->roi_set) { c->part_set = parity; c->roi_set = 1 + parity; }
+    ~CallSets() { c->part_set = part_set; c->roi_set = roi_set; c->cur_lane = 0; }
+};
+
+int part_front(nvca_ctx *ctx, PartCall &c, int n, nvca_part_stream *const *streams, const nvca_frame *frames)
+{
+    if (n < 0 || (n > 0 && (!streams || !frames))) return NVCA_ERR_ARG;
     for (int i = 0; i < n; i++) {
         const nvca_part_stream *s = streams[i]; const nvca_frame *f = &frames[i];
         if (!s || s->ctx != ctx || !f->data || f->width <= 0 || f->height <= 0 || f->stride < f->width * 3 || s->p.width_to_process <= 0 ||
@@ -223,13 +264,18 @@ try {
         }
     }
     (void)hipSetDevice(ctx->device);
-    std::vector<FrameGroup> groups;
-    std::vector<ImageBatch> batches;
-    std::deque<FacePass> passes;
-    std::vector<PartWork> work(n);
-    std::vector<DetectJob *> jobs;
-    std::vector<int> job_lane;
-    int n_eye = 0;
+    c.ctx = ctx; c.n = n;
+    c.streams.assign(streams, streams + n); c.frames.assign(frames, frames + n);
+    c.work.resize(n);
+    std::vector<FrameGroup> &groups = c.groups;
+    std::vector<ImageBatch> &batches = c.batches;
+    std::deque<FacePass> &passes = c.passes;
+    std::vector<PartWork> &work = c.work;
+    std::vector<DetectJob *> &jobs = c.jobs;
+    std::vector<int> &job_lane = c.job_lane;
+    int &n_eye = c.n_eye;
+    const int lane_base = c.parity ? 1 + kCallLanes : 1;           // lanes 1 .. 3 / 4 .. 6; calls with several streams stay off lane 0, where a face detector's batch may be in flight
+    CallSets sets(ctx, c.parity);
     // image k of the batch of (frame geometry, size, chain): asked for by frame group gi
     auto request = [&](int gi, int dw, int dh, bool eye, bool post_eq) {
         const FrameGroup &fg = groups[gi];
@@ -250,45 +296,20 @@ try {
         if (it == b.members.end()) b.members.push_back(gi);
         return r;
     };
-    // the images are made on one lane; the face passes and the part searches run on the lanes side by side behind them.  Calls with
-    // several streams stay off lane 0, where a face detector's batch may be in flight (nvca_face_batch_submit)
-    struct LaneGuard { nvca_ctx *c; ~LaneGuard() { c->cur_lane = 0; } } lane_guard{ctx};
-    // The gates of phase 1a (and find_ears_begin in phase 2) advance per-stream state; plans, buffers and launches come after
-    // them and may still fail (too many scales, allocation, a refused launch).  Whatever the error, the call leaves every
-    // stream as it found it -- the GStreamer shim re-runs the streams one by one after a refused batch, and a gate that had
-    // already advanced would then advance twice and drop a queued face event.  Nothing of the call may stay in flight either:
-    // the caller's frames (H2D copies) and the arena are only safe to reuse once the lanes have drained.
-    struct StreamSnap { nvca_part_stream *s; RectV faces, la, lb; int num_frame, to_process, no_a, no_b; bool popped; RectV front; };
-    struct Rollback {
-        nvca_ctx *c; std::vector<StreamSnap> v; bool armed = true;
-        ~Rollback()
-        {
-            if (!armed) return;
-            (void)hipDeviceSynchronize();
-            for (StreamSnap &g : v) {
-                nvca_part_stream *s = g.s;
-                s->faces.swap(g.faces); s->la.swap(g.la); s->lb.swap(g.lb);
-                s->num_frame = g.num_frame; s->num_frames_to_process = g.to_process; s->no_det_a = g.no_a; s->no_det_b = g.no_b;
-                if (g.popped) s->queue.push_front(std::move(g.front));
-            }
-        }
-    } rollback{ctx, {}};
-    rollback.v.reserve(n);
+    c.snaps.reserve(n);
     for (int i = 0; i < n; i++) {
         nvca_part_stream *s = streams[i];
-        rollback.v.push_back(StreamSnap{s, s->faces, s->la, s->lb, s->num_frame, s->num_frames_to_process, s->no_det_a, s->no_det_b, false, RectV()});
+        c.snaps.push_back(StreamSnap{s, s->faces, s->la, s->lb, s->num_frame, s->num_frames_to_process, s->no_det_a, s->no_det_b, false, RectV()});
     }
     int rc = NVCA_OK;
     const int D = NVCA_MEM_DEVICE;
 #define CK(e) do { if ((rc = (e))) return rc; } while (0)
-    const bool stats = ctx->sw.part_stats > 0;    // diagnostic: the host's time per phase of calls with n (default 8) or more streams, every 8 such calls
-    static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
-    const int stats_min = stats ? ctx->sw.part_stats : 8;
-    const double ts0 = stats ? mono_s() : 0;
+    const bool stats = ctx->sw.part_stats > 0;
+    c.t0 = stats ? mono_s() : 0;
     // ---- phase 1a: gating of every stream, in stream order; what the streams that run need is only noted down here
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
-        nvca_part_stream *s = w.s = streams[i]; const nvca_frame *f = w.f = &frames[i];
+        nvca_part_stream *s = w.s = streams[i]; const nvca_frame *f = w.f = &c.frames[i];
         const int kind = s->p.kind, W = w.W = f->width, H = w.H = f->height;
         // conf_images: float arithmetic (EYE/kmseyedetect.cpp:331-339 and siblings)
         const float o2f = (kind != NVCA_PART_EAR && s->p.detect_event) ? ((float)W) / ((float)W) : ((float)W) / ((float)160);
@@ -301,7 +322,7 @@ try {
                 received = false;
                 if (!s->queue.empty()) {
                     s->faces = s->queue.front(); s->queue.pop_front();
-                    rollback.v[i].popped = true; rollback.v[i].front = s->faces;
+                    c.snaps[i].popped = true; c.snaps[i].front = s->faces;
                     received = true;
                     s->num_frames_to_process = 10 / (5 - s->p.process_x_every_4);
                 }
@@ -309,6 +330,7 @@ try {
             if (!received && s->num_frames_to_process <= 0) w.early_return = true;
         }
         if (w.early_return) continue;
+        if (4 == s->num_frame) s->num_frame = 0;                                // GOP (the reference resets at the end of the frame before: nothing reads the counter in between)
         s->num_frame++;
         const int px = s->p.process_x_every_4;
         w.run = (2 == px && (1 == s->num_frame % 2)) || ((2 != px) && (s->num_frame <= px));
@@ -327,7 +349,7 @@ try {
             FrameGroup &fg = groups.back();
             fg.data = f->data; fg.w = W; fg.h = H; fg.stride = f->stride; fg.mem = f->mem;
         }
-        w.lane = n > 1 ? 1 + w.group % (kPartLanes - 1) : 0;     // the part searches of one frame's streams share a lane
+        w.lane = n > 1 ? lane_base + w.group % kCallLanes : 0;     // the part searches of one frame's streams share a lane
         // the images this stream works on: requested here, computed below for all streams at once
         if (kind == NVCA_PART_EYE) {
             FrameGroup &fg = groups[w.group];
@@ -352,7 +374,7 @@ try {
     }
     // ---- phase 1b: every image the call needs, in a handful of launches
     {
-        ctx->cur_lane = n > 1 ? 1 : 0;
+        ctx->cur_lane = n > 1 ? lane_base : 0;
         // arena: uploads of host frames | full-size gray images of the eye detectors' frames | the working images, batch by batch
         size_t need = 0;
         auto carve = [&](size_t bytes) { const size_t at = need; need += (bytes + 255) & ~(size_t)255; return at; };
@@ -402,7 +424,7 @@ try {
             if (b.flips) CK(part_flip_batch(ctx, b.base, b.base + b.slot * b.members.size(), b.dw, b.dh, (int)b.members.size(), b.slot));     // EAR :800
         }
         // the face passes: members in image order, so that a pass over all images of a batch reads them in place
-        int next_lane = 2;
+        int next_lane = lane_base + 1;
         std::vector<int> used_lanes;
         for (FacePass &fp : passes) {
             std::sort(fp.members.begin(), fp.members.end());
@@ -421,7 +443,7 @@ try {
                 if (fp.type == 2)          // ... and the mirrored images (EAR :796-803): results k + count
                     for (size_t m = m0; m < m1; m++) if (detect_job_add_image(job, b.base + b.slot * (b.members.size() + fp.members[m])) < 0) return NVCA_ERR_ARG;
                 const int lane = n > 1 ? next_lane : 0;
-                next_lane = next_lane + 1 < kPartLanes ? next_lane + 1 : 2;
+                next_lane = next_lane + 1 < lane_base + kCallLanes ? next_lane + 1 : lane_base + 1;
                 jobs.push_back(job); job_lane.push_back(lane); used_lanes.push_back(lane);
             }
         }
@@ -430,16 +452,48 @@ try {
         used_lanes.erase(std::unique(used_lanes.begin(), used_lanes.end()), used_lanes.end());
         CK(part_images_done(ctx, used_lanes.data(), (int)used_lanes.size()));
     }
-    const double ts1 = stats ? mono_s() : 0;
+    c.t1 = stats ? mono_s() : 0;
+    // the face passes' launch sets are queued here and collected by the back half (small-image jobs: one k_roi launch for all of them)
+    if (!jobs.empty()) {
+        c.round = job_round_new();
+        if (!c.round) return NVCA_ERR_NOMEM;
+        CK(detect_jobs_begin(ctx, jobs.data(), (int)jobs.size(), job_lane.data(), c.round, &c.queued));
+    }
+#undef CK
+    return NVCA_OK;
+}
+
+int part_back(nvca_ctx *ctx, PartCall &c, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
+{
+    const int n = c.n;
+    if ((n > 0 && (!n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    std::vector<FrameGroup> &groups = c.groups;
+    std::vector<ImageBatch> &batches = c.batches;
+    std::deque<FacePass> &passes = c.passes;
+    std::vector<PartWork> &work = c.work;
+    std::vector<DetectJob *> &jobs = c.jobs;
+    std::vector<int> &job_lane = c.job_lane;
+    const int lane_base = c.parity ? 1 + kCallLanes : 1;
+    CallSets sets(ctx, c.parity);
+    int rc = NVCA_OK;
+#define CK(e) do { if ((rc = (e))) return rc; } while (0)
+    const bool stats = ctx->sw.part_stats > 0;    // diagnostic: the host's time per phase of calls with n (default 8) or more streams, every 8 such calls
+    static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
+    const int stats_min = stats ? ctx->sw.part_stats : 8;
+    const bool whole_on = stats && n >= ctx->sw.part_stats;
+    const double ts0 = c.t0, ts1 = c.t1, tb0 = stats ? mono_s() : 0;
+    struct Whole { bool on; double t0, front; ~Whole() { if (on) g_total_acc += mono_s() - t0 + front; } } whole{whole_on, tb0, ts1 - ts0};
     // Every face pass waits for the images (part_images_done), so draining the passes' lanes drains the image lane's work
     // too.  A call without any face pass (detect-event streams: the faces were pushed) has nobody waiting for it: the H2D
     // copies of the caller's frames and the image kernels are drained here, before the call can return -- the caller may
     // recycle its buffers, and the next call carves the same arena on another lane.
     if (jobs.empty() && !groups.empty()) {
-        const hipError_t he = hipStreamSynchronize(ctx->lane_streams[n > 1 ? 1 : 0]);
+        const hipError_t he = hipStreamSynchronize(ctx->lane_streams[n > 1 ? lane_base : 0]);
         if (he != hipSuccess) { ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(he)); return NVCA_ERR_HIP; }
     }
-    CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 1: every face pass
+    if (!jobs.empty()) CK(detect_jobs_finish(ctx, jobs.data(), (int)jobs.size(), job_lane.data(), c.round, c.queued));          // wait 1: every face pass
+    c.queued = false;
     // a stream's faces: result k of its pass's job
     auto pass_result = [&](const PartWork &w, bool mirrored) -> const std::vector<nvca_rect> & {
         const FacePass &fp = passes[w.pass];
@@ -500,23 +554,23 @@ try {
     CK(run_detect_jobs(ctx, jobs.data(), (int)jobs.size(), job_lane.data()));          // wait 2 (+ one more for searches that narrowed)
     if (stats) {
         const double ts4 = mono_s();
-        if (n >= stats_min) { acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
+        if (n >= stats_min) { acc[0] += ts1 - ts0; acc[1] += ts2 - tb0; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; }
         else { g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; for (double &v : g_jobs_fine_s) v = 0; }
         if (n >= stats_min && ++calls % 8 == 0) {
             fprintf(stderr, "nubovca part batch (ms per call): image chains %.3f, face passes %.3f, roi set-up %.3f, roi searches %.3f | in the job rounds: enqueue %.3f, wait %.3f, advance %.3f | merging (previous calls) %.3f, whole call (previous 8) %.3f\n",
                     acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, g_jobs_enqueue_s / 8 * 1e3, g_jobs_wait_s / 8 * 1e3, g_jobs_advance_s / 8 * 1e3,
-                    phase3_acc / 8 * 1e3, total_acc / 8 * 1e3);
+                    g_phase3_acc / 8 * 1e3, g_total_acc / 8 * 1e3);
             fprintf(stderr, "nubovca part batch, job rounds in detail (ms per call): adding jobs %.3f (%.0f jobs), launch %.3f, collect %.3f, advance on the helpers %.3f, advance serial %.3f\n",
                     g_jobs_fine_s[0] / 8 * 1e3, g_jobs_fine_s[5] / 8, g_jobs_fine_s[1] / 8 * 1e3, g_jobs_fine_s[2] / 8 * 1e3, g_jobs_fine_s[3] / 8 * 1e3, g_jobs_fine_s[4] / 8 * 1e3);
             for (double &v : g_jobs_fine_s) v = 0;
-            acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; phase3_acc = 0; total_acc = 0;
+            acc[0] = acc[1] = acc[2] = acc[3] = 0; g_jobs_enqueue_s = g_jobs_wait_s = g_jobs_advance_s = 0; g_phase3_acc = 0; g_total_acc = 0;
         }
     }
 #undef CK
-    rollback.armed = false;                // nothing below can fail short of an exception -- which the containers' strong guarantee
+    c.armed = false;                // nothing below can fail short of an exception -- which the containers' strong guarantee
                                            // and the ABI barrier turn into an error code; the device work is complete
     // ---- phase 3: merging heuristics, hysteresis, emission -- in stream order
-    struct P3 { bool on; double t0; ~P3() { if (on) phase3_acc += mono_s() - t0; } } p3{whole.on, whole.on ? mono_s() : 0};
+    struct P3 { bool on; double t0; ~P3() { if (on) g_phase3_acc += mono_s() - t0; } } p3{whole_on, whole_on ? mono_s() : 0};
     for (int i = 0; i < n; i++) {
         PartWork &w = work[i];
         nvca_part_stream *s = w.s;
@@ -562,12 +616,86 @@ try {
                 }
             }
             if (kind == NVCA_PART_NOSE || kind == NVCA_PART_MOUTH) s->la = res_a;   // rebuilt on every call that gets here
-            if (4 == s->num_frame) s->num_frame = 0;                                // GOP
         }
         n_a[i] = (int)s->la.size(); n_b[i] = (int)s->lb.size();
         for (int k = 0; k < std::min(n_a[i], cap_a); k++) out_a[(size_t)i * cap_a + k] = s->la[k];
         for (int k = 0; k < std::min(n_b[i], cap_b); k++) out_b[(size_t)i * cap_b + k] = s->lb[k];
     }
+    return NVCA_OK;
+}
+
+void part_call_free(void *p) { delete (PartCall *)p; }
+// the slot of the next call, or -1 when two are in flight
+int part_call_slot(nvca_ctx *ctx)
+{
+    const int parity = ctx->part_seq & 1;
+    return ctx->part_calls[parity] ? -1 : parity;
+}
+} // namespace
+
+extern "C" {
+
+// One transform_frame_ip of every stream of the batch.  The streams' device work is queued together and waited for three
+// times per call, however many streams there are: (1) the working images of all frames (a launch set per image size) and the
+// face passes (an N-image job per kind of pass), (2) every part search in every face's region (FIND_BIGGEST searches that
+// narrow their scan take one more round), (3) nothing -- the merging heuristics that follow are host code on the collected boxes.
+int nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, nvca_rect *out_a, int cap_a,
+                            int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
+try {
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && (!streams || !frames || !n_a || !n_b)) || cap_a < 0 || cap_b < 0 || (cap_a > 0 && !out_a) || (cap_b > 0 && !out_b)) return NVCA_ERR_ARG;
+    const int slot = part_call_slot(ctx);
+    if (slot < 0) { ctx->set_error("two part batches are in flight: collect one first"); return NVCA_ERR_ARG; }
+    // a stream of an outstanding ticket would have its back halves run out of order (this call's before the ticket's): refused
+    for (void *o : ctx->part_calls)
+        if (o)
+            for (nvca_part_stream *s : ((PartCall *)o)->streams)
+                for (int i = 0; i < n; i++)
+                    if (streams[i] == s) { ctx->set_error("part stream has a submitted batch outstanding: collect it first"); return NVCA_ERR_ARG; }
+    PartCall call; call.parity = slot;
+    int rc = part_front(ctx, call, n, streams, frames);
+    if (!rc) rc = part_back(ctx, call, out_a, cap_a, n_a, out_b, cap_b, n_b);
+    return rc;
+}
+NVCA_API_CATCH(ctx)
+
+// The same call in two halves (see part_front / part_back).  submit: gates, working images and face passes are queued, *ticket names
+// the call; the frames must stay valid until the ticket is collected.  collect: the oldest outstanding ticket only (the streams' state
+// machines advance in submit order).  At most two tickets are outstanding.  A failed collect rolls its streams back as a failed
+// nvca_part_batch_process does -- and abandons a newer outstanding ticket with it (that ticket's streams are rolled back first).
+int nvca_part_batch_submit(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, int *ticket)
+try {
+    NVCA_LOCK_OR_FAIL(ctx);
+    if (!ticket) return NVCA_ERR_ARG;
+    const int slot = part_call_slot(ctx);
+    if (slot < 0) { ctx->set_error("two part batches are in flight: collect one first"); return NVCA_ERR_ARG; }
+    // a stream may not sit in two outstanding calls whose order the library cannot see: it may (tick k, tick k + 1), in submit order
+    std::unique_ptr<PartCall> call(new PartCall());
+    call->parity = slot; call->seq = ctx->part_seq;
+    const int rc = part_front(ctx, *call, n, streams, frames);
+    if (rc) return rc;                                   // (~PartCall rolls the gates back)
+    ctx->part_call_free = part_call_free;
+    ctx->part_calls[slot] = call.release();
+    *ticket = ctx->part_seq++;
+    return NVCA_OK;
+}
+NVCA_API_CATCH(ctx)
+int nvca_part_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b)
+try {
+    NVCA_LOCK_OR_FAIL(ctx);
+    const int slot = ticket & 1, other = slot ^ 1;
+    PartCall *call = ticket >= 0 ? (PartCall *)ctx->part_calls[slot] : nullptr;
+    if (!call || call->seq != ticket) { ctx->set_error("unknown part-batch ticket"); return NVCA_ERR_ARG; }
+    PartCall *newer = (PartCall *)ctx->part_calls[other];
+    if (newer && newer->seq < ticket) { ctx->set_error("part-batch tickets are collected in submit order"); return NVCA_ERR_ARG; }
+    const int rc = part_back(ctx, *call, out_a, cap_a, n_a, out_b, cap_b, n_b);
+    if (rc && rc != NVCA_ERR_ARG) {                      // (bad output arguments: the ticket stays collectable)
+        if (newer) { ctx->part_calls[other] = nullptr; delete newer; }       // its gates were taken on top of this call's: back first
+        ctx->part_calls[slot] = nullptr; delete call;
+        return rc;
+    }
+    if (rc) return rc;
+    ctx->part_calls[slot] = nullptr; delete call;
     return NVCA_OK;
 }
 NVCA_API_CATCH(ctx)

@@ -82,6 +82,7 @@ SYMBOLS = [
     "nvca_host_register", "nvca_host_unregister", "nvca_face_batch_submit", "nvca_face_batch_collect",
     "nvca_integral_tilted", "nvca_cascade_kind", "nvca_part_batch_process", "nvca_device_count", "nvca_draw_shapes",
     "nvca_cascade_validate_mem", "nvca_abi_selftest", "nvca_ctx_set_option", "nvca_ctx_get_option", "nvca_overlay_blend",
+    "nvca_part_batch_submit", "nvca_part_batch_collect",
 ]
 
 _lib = None
@@ -189,6 +190,8 @@ def load():
     L.nvca_part_stream_faces.argtypes = [vp, C.POINTER(Rect), C.c_int, ip]
     L.nvca_part_batch_process.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     L.nvca_part_stream_process.argtypes = [vp, C.POINTER(Frame), C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
+    L.nvca_part_batch_submit.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(Frame), ip]
+    L.nvca_part_batch_collect.argtypes = [vp, C.c_int, C.POINTER(Rect), C.c_int, ip, C.POINTER(Rect), C.c_int, ip]
     _lib = L
     return L
 
@@ -618,6 +621,70 @@ def part_batch_process(ctx, streams, frames, cap=64):
     A = np.frombuffer(a, dtype=np.int32).reshape(n, cap, 4)
     B = np.frombuffer(b, dtype=np.int32).reshape(n, cap, 4)
     return [(A[i, :min(na[i], cap)].copy(), B[i, :min(nb[i], cap)].copy()) for i in range(n)]
+
+
+class PartTicket:
+    """a submitted nvca_part_batch_submit call: keeps what the library still reads (the frame records and whatever backs them) alive"""
+
+    def __init__(self, ticket, n, keep):
+        self.ticket, self.n, self._keep = ticket, n, keep
+
+
+def part_batch_submit(ctx, streams, frames):
+    """nvca_part_batch_submit: gates, working images and face passes of one frame per stream are queued; -> PartTicket"""
+    n = len(streams)
+    sh = (C.c_void_p * n)(*[s.h for s in streams])
+    fr = (Frame * n)(*[f if isinstance(f, Frame) else make_frame(np.ascontiguousarray(f, np.uint8)) for f in frames])
+    t = C.c_int(-1)
+    ctx.check(ctx.L.nvca_part_batch_submit(ctx.h, n, sh, fr, C.byref(t)))
+    return PartTicket(t.value, n, (sh, fr, frames))
+
+
+def part_batch_collect(ctx, tk, cap=64):
+    """nvca_part_batch_collect: the ticket's results, [(list A, list B)] per stream (tickets in submit order)"""
+    n = tk.n
+    a, b = (Rect * (n * cap))(), (Rect * (n * cap))()
+    na, nb = (C.c_int * n)(), (C.c_int * n)()
+    ctx.check(ctx.L.nvca_part_batch_collect(ctx.h, tk.ticket, a, cap, na, b, cap, nb))
+    tk._keep = None
+    A = np.frombuffer(a, dtype=np.int32).reshape(n, cap, 4)
+    B = np.frombuffer(b, dtype=np.int32).reshape(n, cap, 4)
+    return [(A[i, :min(na[i], cap)].copy(), B[i, :min(nb[i], cap)].copy()) for i in range(n)]
+
+
+class PreparedPartBatch:
+    """argument and result arrays of a part-detector batch that is handed in again and again (the same streams on the same frame
+    buffers, e.g. one frame set of a serving loop): the ctypes marshalling is done once; process() / submit() + collect() are then
+    just the C calls, the results stay in the arrays (counts_a / counts_b, boxes_a / boxes_b)"""
+
+    def __init__(self, ctx, streams, frames, cap=64):
+        self.ctx, self.n, self.cap = ctx, len(streams), cap
+        n = self.n
+        self.keep = (list(streams), list(frames))
+        self.sh = (C.c_void_p * n)(*[s.h for s in streams])
+        self.fr = (Frame * n)(*[f if isinstance(f, Frame) else make_frame(np.ascontiguousarray(f, np.uint8)) for f in frames])
+        self.a, self.b = (Rect * (n * cap))(), (Rect * (n * cap))()
+        self.na, self.nb = (C.c_int * n)(), (C.c_int * n)()
+        self.boxes_a = np.frombuffer(self.a, dtype=np.int32).reshape(n, cap, 4)
+        self.boxes_b = np.frombuffer(self.b, dtype=np.int32).reshape(n, cap, 4)
+        self.counts_a = np.frombuffer(self.na, dtype=np.int32)
+        self.counts_b = np.frombuffer(self.nb, dtype=np.int32)
+        self.ticket = C.c_int(-1)
+
+    def process(self):
+        self.ctx.check(self.ctx.L.nvca_part_batch_process(self.ctx.h, self.n, self.sh, self.fr, self.a, self.cap, self.na, self.b, self.cap, self.nb))
+
+    def submit(self):
+        self.ctx.check(self.ctx.L.nvca_part_batch_submit(self.ctx.h, self.n, self.sh, self.fr, C.byref(self.ticket)))
+
+    def collect(self):
+        self.ctx.check(self.ctx.L.nvca_part_batch_collect(self.ctx.h, self.ticket.value, self.a, self.cap, self.na, self.b, self.cap, self.nb))
+
+    def found(self):
+        return int(np.minimum(self.counts_a, self.cap).sum() + np.minimum(self.counts_b, self.cap).sum())
+
+    def results(self):
+        return [(self.boxes_a[i, :min(self.na[i], self.cap)].copy(), self.boxes_b[i, :min(self.nb[i], self.cap)].copy()) for i in range(self.n)]
 
 
 class PartStream:

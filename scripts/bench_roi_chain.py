@@ -167,6 +167,49 @@ print(json.dumps({"roi_chain_batched": {"video_streams": V, "frames_per_s": V * 
                    "note": "launch-bound small-image work: %d kernel launches per tick" % int(sum(v[1] for v in kt.values()) / K2)}}}))
 
 
+# ---- the same workload with TWO part batches in flight (nvca_part_batch_submit / _collect): tick k + 1's gates, working images and face
+# passes are queued before tick k's searches are collected -- what a serving loop does; results are tick k's when collect(k) returns
+def run_inflight():
+    """frame sets repeat every N ticks: a prepared batch per set (the ctypes marshalling of 32 streams and frames is a third of a
+    millisecond a tick in Python, which is the harness, not the library)"""
+    found = 0
+    pbs, fbs = [], []
+    for i in range(N):
+        fb = [fr[(i + 3 * v) % N] for v in range(V)]
+        pbs.append(capi.PreparedPartBatch(ctx, flat, [fb[v] for v in range(V) for _ in range(4)]))
+        fbs.append(fb)
+    for i in range(4):
+        tick_pipelined(i)
+    ctx.synchronize()
+    K3 = 4 * K2
+    for mode in ("one call per tick", "two in flight"):
+        found = 0
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        if mode == "two in flight":
+            pbs[0].submit(); ft = ctx.face_batch_submit(faces_v, fbs[0])
+            for i in range(K3):
+                nxt = None
+                if i + 1 < K3:
+                    pbs[(i + 1) % N].submit(); nxt = ctx.face_batch_submit(faces_v, fbs[(i + 1) % N])
+                pbs[i % N].collect()
+                ctx.face_batch_collect(ft)
+                found += pbs[i % N].found()
+                ft = nxt
+        else:
+            for i in range(K3):
+                ft = ctx.face_batch_submit(faces_v, fbs[i % N])
+                pbs[i % N].process()
+                ctx.face_batch_collect(ft)
+                found += pbs[i % N].found()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"roi_chain_batched_prepared, " + mode: {"video_streams": V, "frames_per_s": V * K3 / dt, "ms_per_tick": dt / K3 * 1e3, "parts_per_frame": found / (V * K3)}}))
+
+
+run_inflight()
+
+
 # ---- the same V video streams spread over C contexts on the one GPU, one host thread per context (what the GStreamer shim's
 # per-GPU frontend does with NVCA_VIRTUAL_GPUS): the launch-bound chains of different contexts are queued in parallel
 import threading

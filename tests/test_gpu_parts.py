@@ -132,6 +132,59 @@ def test_roi_chain_1080p_batched(env):
     assert tot > 0
 
 
+def test_roi_chain_submit_collect_two_ticks_in_flight(env):
+    """nvca_part_batch_submit / _collect as a serving loop: tick k + 1's gates, working images and face passes are queued before tick k is
+    collected (two calls in flight on the two buffer / lane sets), host and device frames, detect-event streams next to streams with
+    their own face pass, ticks on which nothing runs (process-x-every-4-frames).  Every stream's lists as if it had run alone."""
+    import torch
+    from nubovca import capi, synth
+    ctx = env[0]
+    V, T = 3, 7
+    kinds = ("eye", "nose", "mouth", "ear")
+    pairs = [[_streams(env, k, process_x_every_4_frames=(2 if v == 1 else 4)) for k in kinds] for v in range(V)]
+    scenes = [[synth.make_bgr(1920, 1080, 300 + 10 * v + t, "natural", [(300 + 100 * v + 12 * t, 150 + 20 * v, 500 + 30 * v)] if (v + t) % 4 else [])
+               for v in range(V)] for t in range(T)]
+    streams = [pairs[v][j][0] for v in range(V) for j in range(4)]
+    keep = {}
+
+    def frames_of(t, tag=0):
+        out = []
+        for v in range(V):
+            if v == 0:                                     # host memory
+                out += [scenes[t][v]] * 4
+            else:
+                d = torch.from_numpy(scenes[t][v]).cuda()
+                keep[(t, v, tag)] = d                      # (alive until the test ends: a submitted call reads its frames until it is collected)
+                out += [capi.make_frame(d.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE)] * 4
+        torch.cuda.synchronize()
+        return out
+    tot = 0
+    tk = capi.part_batch_submit(ctx, streams, frames_of(0))
+    for t in range(T):
+        nxt = capi.part_batch_submit(ctx, streams, frames_of(t + 1)) if t + 1 < T else None
+        if nxt is not None and t == 2:                     # a third call while two are in flight is refused, and changes nothing
+            with pytest.raises(capi.NvcaError):
+                capi.part_batch_submit(ctx, streams, frames_of(t + 1, tag=1))
+            with pytest.raises(capi.NvcaError):            # ... and so is collecting out of order
+                capi.part_batch_collect(ctx, nxt)
+            with pytest.raises(capi.NvcaError):            # ... and a synchronous call on a stream that has a ticket outstanding
+                capi.part_batch_process(ctx, streams[:1], [scenes[0][0]])
+        res = capi.part_batch_collect(ctx, tk)
+        for v in range(V):
+            for j in range(4):
+                ea, eb = pairs[v][j][1].process(scenes[t][v])
+                ga, gb = res[v * 4 + j]
+                assert np.array_equal(ga, ea) and np.array_equal(gb, eb), (t, v, kinds[j], ga, ea, gb, eb)
+                tot += len(ea) + len(eb)
+        tk = nxt
+    assert tot > 0
+    # the synchronous call still works next to it, and an abandoned ticket is rolled back with its context (nothing to assert but no crash)
+    res = capi.part_batch_process(ctx, streams[:4], [scenes[0][0]] * 4)
+    for j in range(4):
+        ea, eb = pairs[0][j][1].process(scenes[0][0])
+        assert np.array_equal(res[j][0], ea) and np.array_equal(res[j][1], eb)
+
+
 @pytest.mark.parametrize("opts", [{"host_threads": 0}, {"roi": 0}, {"roi": 0, "host_threads": 0}])
 def test_roi_chain_batched_on_the_other_paths(env, opts):
     """the batched chain with the per-job host work on the calling thread only (no helper threads), and with the face-region
