@@ -2036,7 +2036,12 @@ struct RoiBatch {
     std::vector<RoiJobDev> jobs; std::vector<RoiStep> steps; std::vector<unsigned char> tabs; std::vector<DetectJob *> owners; std::vector<int> owner_img;
     std::vector<ScaleTable *> held;                 // stump tables of the launch: kept from eviction until it has been collected
     int plane_words = 0, lev_bytes = 0, lane = 0; unsigned cap = 0; size_t first = 0;
-    ~RoiBatch() { for (ScaleTable *t : held) if (t->refs > 0) t->refs--; }
+    void release() { for (ScaleTable *t : held) if (t->refs > 0) t->refs--; held.clear(); }
+    ~RoiBatch() { release(); }
+    RoiBatch() = default;
+    RoiBatch(const RoiBatch &) = delete; RoiBatch &operator=(const RoiBatch &) = delete;
+    // (a round object is reused from round to round: what the previous round held is released first)
+    void reset() { release(); jobs.clear(); steps.clear(); tabs.clear(); owners.clear(); owner_img.clear(); plane_words = 0; lev_bytes = 0; lane = 0; cap = 0; first = 0; }
 };
 static bool roi_eligible(const nvca_ctx *ctx, const DetectJob &j, int njobs_in_round)
 {
@@ -2483,7 +2488,7 @@ static int jobs_round_begin(nvca_ctx *ctx, DetectJob *const *jobs, int n, const 
         for (bool &u : used) u = false;
         const double t0 = g_job_stats ? mono_s() : 0;
         // small images first: every such job of the round goes into ONE k_roi launch (no plan, no per-job launches)
-        R.rb = RoiBatch();
+        R.rb.reset();
         RoiBatch &rb = R.rb;
         for (int i = 0; i < n && !rc; i++) {
             DetectJob &j = *jobs[i];
