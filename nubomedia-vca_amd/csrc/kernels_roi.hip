@@ -15,7 +15,8 @@
 //   * candidates go to one list for the whole launch as (job << 32) | step << 26 | iy << 13 | ix; the host orders them
 //     (= OpenCV's serial order), groups them and, for FIND_BIGGEST, replays the serial search on them (api.cpp).
 // Same arithmetic as the large-image kernels: i32 rectangle sums, f32 products, f64 variance / thresholds / stage sums in
-// OpenCV's order (one lane walks a window's stumps in order), contraction off.  Stump cascades with upright features only.
+// OpenCV's order (one lane walks a window's stumps in order; a stage whose partial sums are exact in any order may be split over
+// lanes and summed in LDS), contraction off.  Stump cascades with upright features only.
 #include "nvca_internal.h"
 
 namespace nvca {
@@ -131,9 +132,10 @@ __device__ __forceinline__ double roi_vote(const lds_i32 *s, int off, int P, dou
 // The windows of ONE ladder step / pyramid level, by the whole workgroup (16 waves), in three phases:
 //   A  dense: variance normaliser + stage 0 for every window (a wave per grid row, 64 windows at a time, the adaptive x step's
 //      reject-run parity carried from chunk to chunk); the windows the serial walk visits and stage 0 passes are queued
-//   B  stages 1 .. kRoiDeep-1: window per lane on the compacted queue, re-queued after every stage
-//   C  the long late stages on the few windows left: a wave per window, a stump per lane (votes summed across the wave where
-//      the stage's sums are exact in any order -- StageRec flag bit 1 -- and in OpenCV's order otherwise)
+//   B  every further stage on the compacted queue, re-queued after every stage: a window per lane while many are left (or where a
+//      stage's votes may not be re-ordered), lane = (window, group of the stage's stumps) with f64 accumulators in LDS once at most
+//      kRoiPairWin are (votes exact in any order -- StageRec flag bit 1): all 16 waves stay busy on a handful of windows
+//   C  whoever is left after the last stage goes to the launch's candidate list
 // The queues and the per-window normalisers hold kRoiMaxWin windows: a larger grid goes through in bands of whole rows.
 static constexpr int kRoiThreads = 1024, kRoiWaves = kRoiThreads / 64;
 #ifdef NVCA_STAMPS
