@@ -256,9 +256,11 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
         cx = [ctx] + [capi.Context(dev.index or 0) for _ in range(contexts - 1)]
         share = [list(range(c, V, contexts)) for c in range(contexts)]           # video streams of context c
         S = []
+        loaded = []
         for c, cc in enumerate(cx):
             fcas = casc if c == 0 else cc.load_cascade_xml(xml_face)
             pcs = {nm: cc.load_cascade_xml(part_xml(nm)) for nm in names}
+            loaded.append(list(pcs.values()) + ([fcas] if c else []))
             fcs = [capi.FaceStream(cc, fcas, width_to_process=1920, multi_scale_factor=props["multi_scale_factor"]) for _ in share[c]]
             parts = [capi.PartStream(cc, k, fcas, pcs[a], pcs[b] if b else None) for _ in share[c] for k, a, b in kinds]
             S.append((cc, fcs, parts))
@@ -323,6 +325,9 @@ def secondary_table(ctx, casc, props, frames_np, W, H, F, dev, args, xml_face):
                 st.close()
             for pt in parts:
                 pt.close()
+        for pcs_c in loaded:                     # the workload's cascades go with it (their stump tables would otherwise fill the context's cache for the next workload)
+            for cs in pcs_c:
+                cs.free()
         for cc in cx[1:]:
             cc.close()
         # algorithmic bytes per video frame (SURVEY.md 8d's formula per working image): the face detector's 60.21 MB plus, per part

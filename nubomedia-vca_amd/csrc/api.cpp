@@ -1284,9 +1284,12 @@ try {
         }
         { auto sr = c->ctx->roi_stage_recs.find((uint64_t)c->c.uid);
           if (sr != c->ctx->roi_stage_recs.end()) { (void)hipDeviceSynchronize(); sr->second->release(); delete sr->second; c->ctx->roi_stage_recs.erase(sr); } }
-        for (auto it = c->ctx->scale_tables.begin(); it != c->ctx->scale_tables.end();) {      // and its stump tables
-            if (it->first.first == (uint64_t)c->c.uid && it->second->refs == 0) { (void)hipDeviceSynchronize(); delete it->second; it = c->ctx->scale_tables.erase(it); }
-            else ++it;
+        bool drained = false;
+        for (auto it = c->ctx->scale_tables.begin(); it != c->ctx->scale_tables.end();) {      // and its stump tables (one drain of the device for all of them)
+            if (it->first.first == (uint64_t)c->c.uid && it->second->refs == 0) {
+                if (!drained) { (void)hipDeviceSynchronize(); drained = true; }
+                delete it->second; it = c->ctx->scale_tables.erase(it);
+            } else ++it;
         }
     }
     delete c;

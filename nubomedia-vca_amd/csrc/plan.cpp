@@ -560,11 +560,18 @@ ScaleTable *get_scale_table(nvca_ctx *ctx, const Cascade &c, double factor)
     const auto key = std::make_pair((uint64_t)c.uid, fb);
     auto it = ctx->scale_tables.find(key);
     if (it != ctx->scale_tables.end()) { it->second->last_use = ++ctx->next_uid; return it->second; }
-    if (ctx->scale_tables.size() >= 768) {          // bounded: drop the least recently used table nobody references
-        auto victim = ctx->scale_tables.end();
-        for (auto jt = ctx->scale_tables.begin(); jt != ctx->scale_tables.end(); ++jt)
-            if (jt->second->refs == 0 && (victim == ctx->scale_tables.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
-        if (victim != ctx->scale_tables.end()) { (void)hipDeviceSynchronize(); delete victim->second; ctx->scale_tables.erase(victim); }      // any lane may still hold kernels that read it
+    if (ctx->scale_tables.size() >= 768) {
+        // bounded: the least recently used tables nobody references go -- a sixteenth of the cache at a time, behind ONE drain of the
+        // device (any lane may still hold kernels that read them).  One table per miss meant a device-wide wait per miss once the cache
+        // was full: a process that had worked through a few dozen cascades (bench.py's secondary table) met it on every new factor.
+        std::vector<std::pair<uint64_t, std::pair<uint64_t, uint64_t>>> idle;       // (last use, key)
+        for (auto &kv : ctx->scale_tables) if (kv.second->refs == 0) idle.push_back({kv.second->last_use, kv.first});
+        const size_t drop = std::min<size_t>(idle.size(), 48);
+        if (drop) {
+            std::partial_sort(idle.begin(), idle.begin() + drop, idle.end());
+            (void)hipDeviceSynchronize();
+            for (size_t i = 0; i < drop; i++) { auto it = ctx->scale_tables.find(idle[i].second); delete it->second; ctx->scale_tables.erase(it); }
+        }
     }
     std::unique_ptr<ScaleTable> t(new ScaleTable());
     build_scale_table(c, factor, *t);

@@ -754,3 +754,20 @@ def test_kernel_timing_every_batch_and_sampled(ctx, casc, orc_cascade):
         assert kt["gray_resize_hist"][1] == want, (mode, kt)
         assert kt["gray_resize_hist"][0] > 0.0
     assert all(v[1] == 0 for v in ctx.kernel_timing().values())      # off: nothing accumulates
+
+
+def test_stump_table_cache_turns_over(ctx, casc_small, orc_small):
+    """Stump tables are cached per (cascade, factor), 768 of them a context; beyond that the least recently used ones that nobody
+    references are dropped in groups.  Fifty scale factors on one image walk ~1 500 distinct factors: the cache turns over twice
+    while calls keep being answered, and a factor that comes round again is rebuilt -- every answer against the oracle's."""
+    import orc
+    from nubovca import synth
+    g = orc.equalize_hist(synth.make_gray(160, 120, 17, "natural", [(20, 15, 80)]))
+    sfs = [1.02 + 0.0013 * k for k in range(50)]
+    hits = 0
+    for sf in sfs + sfs[:3]:
+        raw = ctx.detect_raw(casc_small, g, sf, 0, (0, 0))
+        eraw = orc.detect_raw(orc_small, g, sf, 0, (0, 0))
+        assert np.array_equal(raw, eraw), (sf, len(raw), len(eraw))
+        hits += len(eraw)
+    assert hits > 0
