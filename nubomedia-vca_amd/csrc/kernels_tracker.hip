@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_ccl_fold(int *__restrict__ labels, Comp
     }
 }
 __global__ __launch_bounds__(256) void k_ccl_emit(const TrkSlot *__restrict__ slots, const int *__restrict__ labels, const CompAcc *__restrict__ acc, const int *__restrict__ roots, int roots_cap,
-                                                  int n, int *__restrict__ out, int cap)
+                                                  int n, int *__restrict__ out, int cap, int batch)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0 && roots[2]) atomicOr(&out[1], 2);      // a label walk met a word it must never meet: the host reports an internal error
     if (roots[1]) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&out[1], 1); return; }      // list overflow: the host falls back
@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void k_ccl_emit(const TrkSlot *__restrict__ sl
     if (cnt > roots_cap) cnt = roots_cap;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt; e += gridDim.x * 256) {
         const int ent = roots[kRootsHdr + e], slot = ent / n, i = ent - slot * n;
+        if (ent < 0 || slot >= batch) { atomicOr(&out[1], 2); continue; }       // (an entry nobody wrote: never an index -- the host reports an internal error)
         if (labels[(size_t)slot * n + i] != i) continue;
         const CompAcc c = acc[(size_t)slot * n + i];
         if (c.seed == 0x7fffffff) continue;
@@ -618,7 +619,7 @@ void launch_tracker(hipStream_t st, const void *d_slots, int batch, int w, int h
         NVCA_LAUNCH(k_ccl_tile<true>, dim3(tile_blocks), dim3(256), 0, st, slots, labels, (CompAcc *)acc, roots, roots_cap, w, h, (const uint8_t *)flags, (int)gt.x, batch, tiles, tick);
         NVCA_LAUNCH(k_ccl_border, dim3(tile_blocks), dim3(256), 0, st, slots, labels, w, h, batch, tiles, tick, roots + 2);
         NVCA_LAUNCH(k_ccl_fold, dim3(128), dim3(256), 0, st, labels, (CompAcc *)acc, (const int *)roots, roots_cap, w * h, roots + 2, batch);
-        NVCA_LAUNCH(k_ccl_emit, dim3(128), dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, (const int *)roots, roots_cap, w * h, out, cap);
+        NVCA_LAUNCH(k_ccl_emit, dim3(128), dim3(256), 0, st, slots, (const int *)labels, (const CompAcc *)acc, (const int *)roots, roots_cap, w * h, out, cap, batch);
         return;
     }
     NVCA_LAUNCH(k_ccl_tile<false>, dim3(tile_blocks), dim3(256), 0, st, slots, labels, (CompAcc *)acc, roots, roots_cap, w, h, (const uint8_t *)flags, (int)gt.x, batch, tiles, tick);
