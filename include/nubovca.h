@@ -324,7 +324,8 @@ int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *stre
  * is submit(k + 1), collect(k).  A stream may appear in both outstanding calls (not in a synchronous nvca_part_batch_process /
  * nvca_part_stream_process while a ticket of its is outstanding: refused).  A collect that fails rolls its streams back as a
  * failed nvca_part_batch_process does and abandons a newer outstanding ticket with it (rolled back first); a ticket that is never
- * collected is rolled back when the context is destroyed. */
+ * collected is rolled back when the context is destroyed -- or when one of its streams is (nvca_part_stream_destroy gives up every
+ * outstanding call of the context first: their tickets become unknown). */
 int  nvca_part_batch_submit(nvca_ctx *ctx, int n, nvca_part_stream *const *streams, const nvca_frame *frames, int *ticket);
 int  nvca_part_batch_collect(nvca_ctx *ctx, int ticket, nvca_rect *out_a, int cap_a, int *n_a, nvca_rect *out_b, int cap_b, int *n_b);
 

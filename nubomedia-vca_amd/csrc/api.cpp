@@ -953,7 +953,7 @@ nvca_ctx::~nvca_ctx()
     nvca::free_scale_tables(this);
     if (ws) ws->release_all();
     trk.release_all();
-    for (void *&c : part_calls) if (c && part_call_free) { part_call_free(c); c = nullptr; }      // submitted, never collected: rolled back, drained
+    if (part_calls_abandon) part_calls_abandon(this);          // submitted, never collected: rolled back (newest first), drained
     for (nvca::PartWorkspace &w : part_sets) w.release_all();
     if (identity_lut) (void)hipFree(identity_lut);
     bounce.release();

@@ -325,7 +325,7 @@ struct nvca_ctx {
     nvca::PartWorkspace part_sets[2]; int part_set = 0;
     nvca::PartWorkspace &pw() { return part_sets[part_set]; }
     void *part_calls[2] = {nullptr, nullptr};  // submitted, not yet collected part-detector calls (parts.cpp: PartCall), by ticket parity
-    void (*part_call_free)(void *) = nullptr;
+    void (*part_calls_abandon)(nvca_ctx *) = nullptr;      // gives up whatever is outstanding (newest first: rolled back, drained, deleted)
     int part_seq = 0;                         // the next ticket
     nvca::Switches sw;                // this context's switches: the process defaults (environment), nvca_ctx_set_option overrides
     int lds_grant[2] = {0, 0};        // dynamic LDS already granted to k_tile / k_band through this context (hipFuncSetAttribute)

@@ -71,6 +71,8 @@ struct PartWork {
     ImageRef small, part_ref;
     std::vector<RoiJob> rois;                // per face, in face order (EYE: right then left; EAR: side 0 then side 1)
     size_t n_side0 = 0;                      // EAR: how many of `rois` belong to side 0
+    RectV faces;                             // a stream without a face pass of its own (detect-event): the faces its gate took for THIS frame -- the stream's own
+                                             // list may belong to the next frame by the time the back half runs (two calls in flight)
     ~PartWork() { for (RoiJob &r : rois) detect_job_free(r.job); }
 };
 
@@ -145,6 +147,8 @@ void find_ears_end(nvca_part_stream *s, const PartWork &w, size_t first, size_t 
 }
 } // namespace
 
+static void part_calls_abandon_for(nvca_ctx *ctx, const nvca_part_stream *s);
+
 extern "C" {
 
 void nvca_part_params_default(nvca_part_params *p, int kind)
@@ -170,6 +174,12 @@ void nvca_part_stream_destroy(nvca_part_stream *s)
 try {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
+    {
+        // a submitted, not yet collected batch holds this stream (its gates' snapshot, its jobs): such calls are abandoned first --
+        // the newer one before the older one, each rolled back and drained -- and their tickets become unknown
+        std::lock_guard<std::recursive_mutex> lk(s->ctx->mu);
+        part_calls_abandon_for(s->ctx, s);
+    }
     (void)hipStreamSynchronize(s->ctx->stream);
     delete s;
 }
@@ -371,6 +381,7 @@ int part_front(nvca_ctx *ctx, PartCall &c, int n, nvca_part_stream *const *strea
             FacePass &fp = passes[w.pass];
             if (std::find(fp.members.begin(), fp.members.end(), w.small.k) == fp.members.end()) fp.members.push_back(w.small.k);
         }
+        if (w.pass < 0 && kind != NVCA_PART_EAR) w.faces = s->faces;
     }
     // ---- phase 1b: every image the call needs, in a handful of launches
     {
@@ -517,7 +528,8 @@ int part_back(nvca_ctx *ctx, PartCall &c, nvca_rect *out_a, int cap_a, int *n_a,
         } else {
             if (w.pass >= 0) { const std::vector<nvca_rect> &fv = pass_result(w, false); s->faces.assign(fv.begin(), fv.begin() + std::min<size_t>(fv.size(), 256)); }
             const double scale_f2x = w.scale_f2x;
-            for (const nvca_rect &r : s->faces) {
+            const RectV &faces_now = w.pass >= 0 ? s->faces : w.faces;
+            for (const nvca_rect &r : faces_now) {
                 if (kind == NVCA_PART_EYE) {
                     nvca_rect ra, fr, fl;
                     ra.x = (int)(r.x * scale_f2x); ra.y = (int)(r.y * scale_f2x); ra.w = (int)(r.w * scale_f2x); ra.h = (int)(r.h * scale_f2x);
@@ -624,7 +636,22 @@ int part_back(nvca_ctx *ctx, PartCall &c, nvca_rect *out_a, int cap_a, int *n_a,
     return NVCA_OK;
 }
 
-void part_call_free(void *p) { delete (PartCall *)p; }
+} // namespace
+// outstanding calls that hold stream s (nullptr: any) are given up: rolled back (newest first), drained, deleted
+static void part_calls_abandon_for(nvca_ctx *ctx, const nvca_part_stream *s)
+{
+    bool hit = false;
+    for (void *o : ctx->part_calls)
+        if (o) { const PartCall *c = (const PartCall *)o; if (!s || std::find(c->streams.begin(), c->streams.end(), s) != c->streams.end()) hit = true; }
+    if (!hit) return;
+    // (both go: the newer call's gates were taken on top of the older one's)
+    PartCall *a = (PartCall *)ctx->part_calls[0], *b = (PartCall *)ctx->part_calls[1];
+    if (a && b && a->seq > b->seq) std::swap(a, b);          // a: older, b: newer
+    ctx->part_calls[0] = ctx->part_calls[1] = nullptr;
+    delete b;
+    delete a;
+}
+namespace {
 // the slot of the next call, or -1 when two are in flight
 int part_call_slot(nvca_ctx *ctx)
 {
@@ -674,7 +701,7 @@ try {
     call->parity = slot; call->seq = ctx->part_seq;
     const int rc = part_front(ctx, *call, n, streams, frames);
     if (rc) return rc;                                   // (~PartCall rolls the gates back)
-    ctx->part_call_free = part_call_free;
+    ctx->part_calls_abandon = [](nvca_ctx *c) { part_calls_abandon_for(c, nullptr); };
     ctx->part_calls[slot] = call.release();
     *ticket = ctx->part_seq++;
     return NVCA_OK;

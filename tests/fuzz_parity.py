@@ -65,7 +65,9 @@ while time.time() < t_end:
             vid.append(int(rng.randint(nv))); evt.append(bool(pr.get("detect_event")))
         sfc = int(H * rng.uniform(0.35, 0.6))
         keep = []
-        for t in range(int(rng.randint(2, 5))):
+        inflight = rng.rand() < 0.5            # nvca_part_batch_submit / _collect with two calls outstanding instead of one call per tick
+
+        def make_tick():
             fset, handed = [], []
             for v in range(nv):
                 faces = [(int(rng.randint(0, max(1, W - sfc))), int(rng.randint(0, max(1, H - sfc))), sfc)] if rng.rand() < 0.8 else []
@@ -77,15 +79,35 @@ while time.time() < t_end:
                 else:
                     handed.append(capi.make_frame(f))
             torch.cuda.synchronize()
+            pushes = []
             for i in range(ns):
                 if evt[i] and rng.rand() < 0.8:
-                    boxes = [(x, y, s_, s_) for (x, y, s_) in fset[vid[i]][1]]
-                    gps[i].push_faces(boxes); ops[i].push_faces(boxes)
-            res = capi.part_batch_process(ctx, gps, [handed[vid[i]] for i in range(ns)])
+                    pushes.append((i, [(x, y, s_, s_) for (x, y, s_) in fset[vid[i]][1]]))
+            return fset, handed, pushes
+
+        def check(t, fset, pushes, res):
+            for i, boxes in pushes:
+                ops[i].push_faces(boxes)
             for i in range(ns):
                 ea, eb = ops[i].process(fset[vid[i]][0])
                 if not (np.array_equal(res[i][0], ea) and np.array_equal(res[i][1], eb)):
-                    print("MISMATCH part batch", W, H, "generic" if generic else "stumps", "stream", i, "tick", t, res[i], ea, eb); sys.exit(1)
+                    print("MISMATCH part batch", "in flight" if inflight else "", W, H, "generic" if generic else "stumps", "stream", i, "tick", t, res[i], ea, eb); sys.exit(1)
+        nt = int(rng.randint(2, 5))
+        pending = []                           # (tick, frame set, pushes, ticket)
+        for t in range(nt):
+            fset, handed, pushes = make_tick()
+            for i, boxes in pushes:
+                gps[i].push_faces(boxes)
+            if inflight:
+                pending.append((t, fset, pushes, capi.part_batch_submit(ctx, gps, [handed[vid[i]] for i in range(ns)])))
+                if len(pending) == 2:
+                    t0, f0, p0, tk0 = pending.pop(0)
+                    check(t0, f0, p0, capi.part_batch_collect(ctx, tk0))
+            else:
+                check(t, fset, pushes, capi.part_batch_process(ctx, gps, [handed[vid[i]] for i in range(ns)]))
+        for t0, f0, p0, tk0 in pending:
+            check(t0, f0, p0, capi.part_batch_collect(ctx, tk0))
+        if inflight: rounds["part_inflight"] = rounds.get("part_inflight", 0) + 1
         for g_ in gps: g_.close()
         rounds["part_batch"] += 1
     elif u < 0.16:

@@ -183,6 +183,16 @@ def test_roi_chain_submit_collect_two_ticks_in_flight(env):
     for j in range(4):
         ea, eb = pairs[0][j][1].process(scenes[0][0])
         assert np.array_equal(res[j][0], ea) and np.array_equal(res[j][1], eb)
+    # a stream of an outstanding call is destroyed: the call is abandoned -- rolled back, drained -- and its ticket unknown; the other
+    # streams are as they were before the submit (their oracle twins never saw the abandoned frame)
+    tk = capi.part_batch_submit(ctx, streams[:4], [scenes[1][0]] * 4)
+    pairs[0][0][0].close()
+    with pytest.raises(capi.NvcaError):
+        capi.part_batch_collect(ctx, tk)
+    res = capi.part_batch_process(ctx, streams[1:4], [scenes[2][0]] * 3)
+    for j in range(1, 4):
+        ea, eb = pairs[0][j][1].process(scenes[2][0])
+        assert np.array_equal(res[j - 1][0], ea) and np.array_equal(res[j - 1][1], eb)
 
 
 @pytest.mark.parametrize("opts", [{"host_threads": 0}, {"roi": 0}, {"roi": 0, "host_threads": 0}])
