@@ -219,6 +219,7 @@ static Switches read_switches()
     w.host_threads = num("NVCA_HOST_THREADS", -1);
     w.two_lanes = num("NVCA_TWO_LANES", 1) != 0;
     w.roi = num("NVCA_ROI", 1) != 0;
+    w.fb_dense = num("NVCA_FB_DENSE", 1) != 0;
     w.pre_cus = num("NVCA_PRE_CUS", 0);
     w.quiet = set("NVCA_QUIET");
     w.stamps_out = getenv("NVCA_STAMPS_OUT");
@@ -1049,6 +1050,7 @@ try {
     else if (n == "trk_fold") w.trk_fold = value != 0;
     else if (n == "quiet") w.quiet = value != 0;
     else if (n == "roi") w.roi = value != 0;
+    else if (n == "fb_dense") w.fb_dense = value != 0;
     else if (n == "two_lanes") w.two_lanes = value != 0;
     else if (n == "host_threads") { w.host_threads = value; work_pool_destroy(ctx->pool); ctx->pool = nullptr; ctx->pool_tried = false; }
     else if (n == "pre_cus") w.pre_cus = value > 0 ? value : 0;
@@ -1090,6 +1092,7 @@ try {
     else if (n == "trk_fold") *value = w.trk_fold;
     else if (n == "quiet") *value = w.quiet;
     else if (n == "roi") *value = w.roi;
+    else if (n == "fb_dense") *value = w.fb_dense;
     else if (n == "two_lanes") *value = w.two_lanes;
     else if (n == "host_threads") *value = w.host_threads;
     else if (n == "pre_cus") *value = w.pre_cus;
@@ -1697,7 +1700,23 @@ struct DetectJob {
     bool fused = false;                              // the queued set went into the round's k_roi launch
     std::vector<RoiStepInfo> rinfo;
     std::vector<unsigned> rkeys[kJobImages];         // per image: step << 26 | iy << 13 | ix, ascending (= OpenCV's serial order)
+    // FIND_BIGGEST on the small-image path, dense first launch (Switches::fb_dense): per step of the queued launch where its stage-0 reject bits
+    // lie in the launch's bitmap (word offset, words per grid row, grid size); per LADDER step what came back -- every window that passes the whole
+    // cascade, visited by the serial walk or not (iy << 13 | ix, ascending), and the reject bits of the step's full grid
+    struct RejInfo { int off, wpr, nx, ny; };
+    bool dense = false;                              // the queued launch was a dense one
+    std::vector<RejInfo> rej_info;                   // [step of the launch]
+    std::vector<std::vector<unsigned>> dense_hits;   // [ladder step]
+    std::vector<const unsigned long long *> rej_bits; std::vector<int> rej_wpr, rej_rows;      // [ladder step]: into the launch's page-locked bitmap (valid until the next launch of its buffer set: the job is advanced before)
 };
+// was window ix of a grid row visited by the serial walk that started at column `start`?  (visited iff the run of stage-0 rejects
+// immediately left of it, not reaching below `start`, has even length: the walk steps by 2 behind a stage-0 reject, by 1 otherwise)
+static inline bool fb_visited(const unsigned long long *row, int start, int ix)
+{
+    int run = 0;
+    for (int x = ix - 1; x >= start && ((row[x >> 6] >> (x & 63)) & 1ull); x--) run++;
+    return !(run & 1);
+}
 
 static bool fb_make_spec(const DetectJob &j, int spitch, const FbStep &st, int startX, int endX, int startY, int endY, ScaleSpec &sp)
 {   // scan grid of one ladder step; false: nothing to scan there
@@ -1984,7 +2003,22 @@ static int fb_replay(nvca_ctx *ctx, DetectJob &j)
                 ScaleSpec sp;
                 const int sx0 = cv_round(j.scanROI.x / sk.ystep), sx1 = cv_round((j.scanROI.x + j.scanROI.w - sk.winw) / sk.ystep);
                 const int sy0 = cv_round(j.scanROI.y / sk.ystep), sy1 = cv_round((j.scanROI.y + j.scanROI.h - sk.winh) / sk.ystep);
-                if (j.small) {                    // small-image path: no plan, the narrowed grids go into the next round's launch as they are
+                if (j.small && j.dense && k < j.dense_hits.size() && j.rej_wpr[k] > 0) {
+                    // dense first launch: the narrowed walk of this step is replayed here -- its windows are grid points of the full grid, the
+                    // launch reported every one of them that passes the cascade, and which of them the walk from column sx0 visits follows
+                    // from the stage-0 reject bits (no second launch, no second wait).  A step the first launch did not hold (below the call's
+                    // minSize: the narrowed search lowers it to 0.4 / 0.6 of the object found) still takes the second launch, below.
+                    RoiStep tmp;
+                    if (roi_grid(cols, rows, sk.ystep, sk.winw, sk.winh, sx0, sx1, sy0, sy1, tmp)) {
+                        const int wpr = j.rej_wpr[k];
+                        for (unsigned key : j.dense_hits[k]) {            // ascending (iy, ix): the serial order
+                            const int iy = (int)(key >> 13), ix = (int)(key & 8191);
+                            if (iy < tmp.startY || iy >= tmp.endY || ix < tmp.startX || ix >= tmp.endX) continue;
+                            if (iy >= j.rej_rows[k] || !fb_visited(j.rej_bits[k] + (size_t)iy * wpr, tmp.startX, ix)) continue;
+                            j.hits[k].push_back(nvca_rect{cv_round(ix * sk.ystep), cv_round(iy * sk.ystep), sk.winw, sk.winh});
+                        }
+                    }
+                } else if (j.small) {             // small-image path: no plan, the narrowed grids go into the next round's launch as they are
                     RoiStep tmp;
                     if (roi_grid(cols, rows, sk.ystep, sk.winw, sk.winh, sx0, sx1, sy0, sy1, tmp)) { j.ladder_of.push_back((int)k); j.have[k] = 0; }
                 } else if (fb_make_spec(j, spitch, sk, sx0, sx1, sy0, sy1, sp)) {
@@ -2039,12 +2073,13 @@ struct RoiBatch {
     std::vector<RoiJobDev> jobs; std::vector<RoiStep> steps; std::vector<unsigned char> tabs; std::vector<DetectJob *> owners; std::vector<int> owner_img;
     std::vector<ScaleTable *> held;                 // stump tables of the launch: kept from eviction until it has been collected
     int plane_words = 0, lev_bytes = 0, lane = 0; unsigned cap = 0; size_t first = 0;
+    size_t rej_words = 0;                           // stage-0 reject bitmaps of the launch's dense steps (u64 words)
     void release() { for (ScaleTable *t : held) if (t->refs > 0) t->refs--; held.clear(); }
     ~RoiBatch() { release(); }
     RoiBatch() = default;
     RoiBatch(const RoiBatch &) = delete; RoiBatch &operator=(const RoiBatch &) = delete;
     // (a round object is reused from round to round: what the previous round held is released first)
-    void reset() { release(); jobs.clear(); steps.clear(); tabs.clear(); owners.clear(); owner_img.clear(); plane_words = 0; lev_bytes = 0; lane = 0; cap = 0; first = 0; }
+    void reset() { release(); jobs.clear(); steps.clear(); tabs.clear(); owners.clear(); owner_img.clear(); plane_words = 0; lev_bytes = 0; lane = 0; cap = 0; first = 0; rej_words = 0; }
 };
 static bool roi_eligible(const nvca_ctx *ctx, const DetectJob &j, int njobs_in_round)
 {
@@ -2103,6 +2138,8 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
     std::vector<RoiStep> steps; std::vector<DetectJob::RoiStepInfo> info; std::vector<unsigned char> tabs;
     const size_t tab0 = rb.tabs.size();
     int lev_bytes = 0;
+    const bool dense = j.kind == 2 && j.phase == 0 && ctx->sw.fb_dense && j.nimg == 1;
+    std::vector<DetectJob::RejInfo> rej; size_t rej_local = 0;
     if (j.phase == 0) for (int k = 0; k < kJobImages; k++) j.out[k].clear();
     if (j.kind == 1) {
         // the pyramid levels of si_plan, each with its cv::resize tables
@@ -2160,6 +2197,11 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
                 if (!t) return NVCA_ERR_NOMEM;
                 RoiStep st; roi_step_common(st, *t);
                 if (!roi_grid(cols, rows, fs.ystep, fs.winw, fs.winh, 0, cv_round((cols - fs.winw) / fs.ystep), 0, cv_round((rows - fs.winh) / fs.ystep), st)) continue;
+                if (dense) {                     // every stage-0 passer of the full grid + the grid's reject bits: a narrowed re-scan is replayed on the host
+                    st.adaptive = 2; st.rej_wpr = (st.endX + 63) / 64; st.rej_off = (int)(rb.rej_words + rej_local);
+                    rej.push_back(DetectJob::RejInfo{st.rej_off, st.rej_wpr, st.endX, st.endY});
+                    rej_local += (size_t)st.rej_wpr * st.endY;
+                }
                 steps.push_back(st); info.push_back(DetectJob::RoiStepInfo{fs.ystep, 0., fs.winw, fs.winh, (int)i}); j.ladder_of.push_back((int)i);
             }
             j.phase = 1;
@@ -2203,6 +2245,8 @@ static int roi_add_job(nvca_ctx *ctx, RoiBatch &rb, DetectJob &j)
     if (!fits && j.roi_prev_phase == 2) { ctx->set_error("internal: a narrowed search outgrew the small-image path"); return NVCA_ERR_INTERNAL; }   // (its full grids fitted)
     if (!fits) { j.phase = j.roi_prev_phase; return NVCA_OK; }       // this one takes the large-image path
     j.fused = true; j.rinfo.swap(info); j.dp = nullptr;
+    j.dense = dense && !rej.empty(); j.rej_info.swap(rej);
+    if (j.dense) rb.rej_words += rej_local;
     for (int k = 0; k < kJobImages; k++) j.rkeys[k].clear();
     if (steps.empty()) return NVCA_OK;                               // nothing to scan: the job completes with what it has
     rb.tabs.insert(rb.tabs.end(), tabs.begin(), tabs.end());
@@ -2238,7 +2282,8 @@ static int roi_launch(nvca_ctx *ctx, RoiBatch &rb, bool full_cap)
     rb.cap = (unsigned)std::min<long long>(want, full_cap ? (1ll << 26) : (1ll << 18));
     const size_t first = std::min<size_t>(rb.cap, std::max<size_t>(8192, ctx->roi_first_hint));
     rb.first = first;
-    if (ctx->rbuf().tables.ensure(total) || ctx->rbuf().h_tables.ensure(total) || ctx->rbuf().hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->rbuf().h_hits.ensure(((size_t)rb.cap + 1) * 8)) {
+    if (ctx->rbuf().tables.ensure(total) || ctx->rbuf().h_tables.ensure(total) || ctx->rbuf().hits.ensure(((size_t)rb.cap + 1) * 8) || ctx->rbuf().h_hits.ensure(((size_t)rb.cap + 1) * 8) ||
+        ctx->rbuf().rej.ensure((rb.rej_words + 1) * 8) || ctx->rbuf().h_rej.ensure((rb.rej_words + 1) * 8)) {
         ctx->set_error("allocation failed (small-image detector)"); return NVCA_ERR_NOMEM;
     }
     unsigned char *h = ctx->rbuf().h_tables.as<unsigned char>();
@@ -2250,7 +2295,9 @@ static int roi_launch(nvca_ctx *ctx, RoiBatch &rb, bool full_cap)
     if (const int e = roi_grant_lds(lds)) { ctx->set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)e)); return NVCA_ERR_HIP; }
     const unsigned char *d = ctx->rbuf().tables.as<unsigned char>();
     { TimedLaunch t(ctx, NVCA_K_ROI);
-      launch_roi(ctx->cs(), (const RoiJobDev *)d, (int)rb.steps.size(), (const RoiStep *)(d + o_steps), d + o_tabs, ctx->rbuf().hits.as<unsigned long long>(), rb.cap, rb.plane_words, lds); }
+      launch_roi(ctx->cs(), (const RoiJobDev *)d, (int)rb.steps.size(), (const RoiStep *)(d + o_steps), d + o_tabs, ctx->rbuf().hits.as<unsigned long long>(), rb.cap, rb.plane_words, lds,
+                 ctx->rbuf().rej.as<unsigned long long>()); }
+    if (rb.rej_words) NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->rbuf().h_rej.p, ctx->rbuf().rej.p, rb.rej_words * 8, hipMemcpyDeviceToHost, ctx->cs()));
     NVCA_LAUNCH_CHECK(ctx);
     NVCA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->rbuf().h_hits.p, ctx->rbuf().hits.p, (first + 1) * 8, hipMemcpyDeviceToHost, ctx->cs()));
     return NVCA_OK;
@@ -2274,6 +2321,18 @@ static int roi_collect(nvca_ctx *ctx, RoiBatch &rb)
     if (total > first) {
         NVCA_HIP_CHECK(ctx, hipMemcpyAsync(hh + 1 + first, ctx->rbuf().hits.as<unsigned long long>() + 1 + first, (total - first) * 8, hipMemcpyDeviceToHost, ctx->cs()));
         NVCA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->cs()));
+    }
+    // the dense jobs' reject bits: per ladder step of the job (api.cpp, fb_replay)
+    for (DetectJob *o : rb.owners) {
+        if (!o->dense) continue;
+        const unsigned long long *hr = ctx->rbuf().h_rej.as<unsigned long long>();
+        o->rej_bits.assign(o->ladder.size(), nullptr); o->rej_wpr.assign(o->ladder.size(), 0); o->rej_rows.assign(o->ladder.size(), 0); o->dense_hits.assign(o->ladder.size(), {});
+        for (size_t k = 0; k < o->rej_info.size() && k < o->rinfo.size(); k++) {
+            const DetectJob::RejInfo &ri = o->rej_info[k];
+            const int li = o->rinfo[k].ladder;
+            if (li < 0 || (size_t)li >= o->ladder.size() || (size_t)ri.off + (size_t)ri.wpr * ri.ny > rb.rej_words) { ctx->set_error("internal: reject bitmap of an unknown ladder step"); return NVCA_ERR_INTERNAL; }
+            o->rej_bits[li] = hr + ri.off; o->rej_wpr[li] = ri.wpr; o->rej_rows[li] = ri.ny;
+        }
     }
     // (the list is in the order the workgroups appended: every job sorts its own keys into the serial order when it advances)
     for (unsigned long long i = 0; i < total; i++) {
@@ -2320,6 +2379,15 @@ static int detect_job_advance(nvca_ctx *ctx, DetectJob &j)
             for (unsigned key : j.rkeys[k]) {
                 const DetectJob::RoiStepInfo &ri = j.rinfo[key >> 26];
                 const int iy = (key >> 13) & 8191, ix = key & 8191;
+                if (j.dense && k == 0) {
+                    // a dense launch reports every window that passes the cascade; the serial walk of the FULL grid (start column 0) visits only some
+                    const size_t li = (size_t)ri.ladder;
+                    if (li >= j.rej_bits.size() || j.rej_wpr[li] <= 0 || iy >= j.rej_rows[li] || ix >= j.rej_wpr[li] * 64) {
+                        ctx->set_error("internal: dense candidate outside its reject bitmap (device result rejected)"); j.phase = 3; return NVCA_ERR_INTERNAL;
+                    }
+                    j.dense_hits[li].push_back((unsigned)(iy << 13 | ix));
+                    if (!fb_visited(j.rej_bits[li] + (size_t)iy * j.rej_wpr[li], 0, ix)) continue;
+                }
                 if (ri.out_factor != 0) raw[k].push_back(nvca_rect{cv_round(ix * ri.out_factor), cv_round(iy * ri.out_factor), ri.winw, ri.winh});
                 else raw[k].push_back(nvca_rect{cv_round(ix * ri.ystep), cv_round(iy * ri.ystep), ri.winw, ri.winh});
                 sc[k].push_back(ri.ladder);

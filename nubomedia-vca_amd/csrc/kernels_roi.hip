@@ -157,7 +157,7 @@ static constexpr int kRoiPairWin = 384;        // windows up to which a stage ru
 struct RoiLds { lds_i32 *s; lds_u32 *q; double *vnf; unsigned short *qa, *qb; int *cnt; lds_u8 *lev; };
 template <class Pos>
 __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const RoiStep &st, int li, int nx, int gy0, int gy1, int P, const RoiLds &L, Pos pos,
-                                                 unsigned long long *__restrict__ hits, unsigned hit_cap ROI_STAMP_ARGS)
+                                                 unsigned long long *__restrict__ hits, unsigned hit_cap, unsigned long long *__restrict__ rejbuf ROI_STAMP_ARGS)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nst = job.nstages;
@@ -182,8 +182,9 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
                 pass0 = roi_run_stages(L.s, off, P, vnf, st.trecs, job.stages, 0, 1, job.pair_policy) == 1;
             }
             const unsigned long long rej = __ballot(in && !pass0);            // rejected by stage 0: the serial walk steps by 2 behind it
+            if (st.adaptive == 2 && lane == 0) rejbuf[(size_t)st.rej_off + (size_t)(st.startY + gy) * st.rej_wpr + ((st.startX + c0) >> 6)] = rej;
             bool visited = in;
-            if (in && st.adaptive) {
+            if (in && st.adaptive == 1) {
                 // window gx is visited iff the run of stage-0 rejects immediately to its left has even length
                 const unsigned long long below = lane ? (rej << (64 - lane)) : 0ull;       // bit 63 = lane - 1
                 int ones = lane ? __clzll((long long)~below) : 0;
@@ -316,11 +317,11 @@ __device__ __forceinline__ void roi_band_windows(const RoiJobDev &job, const Roi
 // a step's grid in bands of whole rows that fit the queues (the adaptive x step works row by row: bands are independent)
 template <class Pos>
 __device__ __forceinline__ void roi_step_windows(const RoiJobDev &job, const RoiStep &st, int li, int nx, int ny, int P, const RoiLds &L, Pos pos,
-                                                 unsigned long long *__restrict__ hits, unsigned hit_cap ROI_STAMP_ARGS)
+                                                 unsigned long long *__restrict__ hits, unsigned hit_cap, unsigned long long *__restrict__ rejbuf ROI_STAMP_ARGS)
 {
     if (nx <= 0 || ny <= 0) return;
     const int rows_per = nx >= kRoiMaxWin ? 1 : kRoiMaxWin / nx;
-    for (int gy0 = 0; gy0 < ny; gy0 += rows_per) roi_band_windows(job, st, li, nx, gy0, gy0 + rows_per < ny ? gy0 + rows_per : ny, P, L, pos, hits, hit_cap ROI_STAMP_PASS);
+    for (int gy0 = 0; gy0 < ny; gy0 += rows_per) roi_band_windows(job, st, li, nx, gy0, gy0 + rows_per < ny ? gy0 + rows_per : ny, P, L, pos, hits, hit_cap, rejbuf ROI_STAMP_PASS);
 }
 
 // One workgroup per (job, step): the steps of a job are independent of one another once the image is there, so each takes the
@@ -328,7 +329,7 @@ __device__ __forceinline__ void roi_step_windows(const RoiJobDev &job, const Roi
 // long chain per job.  Dynamic LDS: sum plane | squared plane | per-window normalisers | two queues | counters | (scale-image)
 // the level's gray image.
 __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict__ jobs, const RoiStep *__restrict__ steps, const unsigned char *__restrict__ tabs,
-                                                     unsigned long long *__restrict__ hits, unsigned hit_cap, int plane_words)
+                                                     unsigned long long *__restrict__ hits, unsigned hit_cap, int plane_words, unsigned long long *__restrict__ rejbuf)
 {
     extern __shared__ __align__(16) unsigned char roi_lds[];
     const RoiStep st = steps[blockIdx.x];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict
         roi_integral([&](int x, int y) { return L.lev[y * szw + x]; }, szw, szh, L.s, L.q, P);
         const int nx = (st.endX - st.startX + st.step - 1) / st.step, ny = (st.endY - st.startY + st.step - 1) / st.step;   // origins 0, step, 2 step, ...
         ROI_STAMP(0);
-        roi_step_windows(job, st, li, nx, ny, P, L, [&](int gx, int gy, int &x, int &y) { x = st.startX + gx * st.step; y = st.startY + gy * st.step; }, hits, hit_cap ROI_STAMP_PASS);
+        roi_step_windows(job, st, li, nx, ny, P, L, [&](int gx, int gy, int &x, int &y) { x = st.startX + gx * st.step; y = st.startY + gy * st.step; }, hits, hit_cap, rejbuf ROI_STAMP_PASS);
         return;
     }
     // scale-cascade scan, one ladder step: the image's integral pair, the features scaled by the step's factor, stride max(2, factor), adaptive x step
@@ -369,13 +370,13 @@ __global__ __launch_bounds__(kRoiThreads) void k_roi(const RoiJobDev *__restrict
     roi_integral([&](int x, int y) { return img[(size_t)y * job.stride + x]; }, job.w, job.h, L.s, L.q, P);
     ROI_STAMP(0);
     roi_step_windows(job, st, li, st.endX - st.startX, st.endY - st.startY, P, L,
-                     [&](int gx, int gy, int &x, int &y) { x = roi_cvround((st.startX + gx) * st.ystep); y = roi_cvround((st.startY + gy) * st.ystep); }, hits, hit_cap ROI_STAMP_PASS);
+                     [&](int gx, int gy, int &x, int &y) { x = roi_cvround((st.startX + gx) * st.ystep); y = roi_cvround((st.startY + gy) * st.ystep); }, hits, hit_cap, rejbuf ROI_STAMP_PASS);
 }
 
 void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep *steps, const unsigned char *tabs, unsigned long long *hits,
-                unsigned hit_cap, int plane_words, int lds_bytes)
+                unsigned hit_cap, int plane_words, int lds_bytes, unsigned long long *rej)
 {
-    NVCA_LAUNCH(k_roi, dim3(nsteps), dim3(kRoiThreads), (size_t)lds_bytes, st, jobs, steps, tabs, hits, hit_cap, plane_words);
+    NVCA_LAUNCH(k_roi, dim3(nsteps), dim3(kRoiThreads), (size_t)lds_bytes, st, jobs, steps, tabs, hits, hit_cap, plane_words, rej);
 }
 #ifdef NVCA_STAMPS
 void roi_stamps_dump(const char *path)

@@ -191,6 +191,7 @@ struct Switches {
     int  trk_order = -1;             // NVCA_TRK_ORDER: visiting order of k_ccl_reduce (-1: decided per frame on the device)
     int  host_threads = -1;          // NVCA_HOST_THREADS=n: helper threads for per-job host work (-1: min(8, cores / 2) - 1; 0: none)
     bool two_lanes = true;           // NVCA_TWO_LANES=0: both submitted face batches on the context's stream (one after the other)
+    bool fb_dense = true;            // NVCA_FB_DENSE=0: a FIND_BIGGEST search on the small-image path re-scans its narrowed grids in a second launch instead of replaying them on the host from the first launch's dense candidates + stage-0 reject bits
     bool roi = true;                 // NVCA_ROI=0: small images take the large-image path too (plan + four launches per job)
     bool stage_order = false;        // NVCA_STAGE_ORDER=1 (0, the default: the cascade's own order on every tile -- the cheapest one for a cascade whose stages each reject about half, as trained ones do; a round then may take two stages at once): the tile kernels walk the early stages 1 .. 5 in the cascade's order on every tile (1: in the order the previous tile of the band found cheapest -- cost per window killed; the set of survivors is the same.  A cascade whose stages each reject about half, as trained ones do, keeps its own order either way)
     int  pair_max = 32;              // NVCA_PAIR_MAX=n (<= 32): windows up to which a round of the tile kernels runs lane = (window, stump) instead of a window per lane
@@ -335,7 +336,7 @@ struct nvca_ctx {
     std::map<uint64_t, nvca::DevBuf *> roi_stage_recs;
     // (three sets: [0] the synchronous callers', [1] / [2] the part-detector calls in flight by ticket parity -- a round of theirs stays
     // queued between submit and collect)
-    struct RoiBuffers { nvca::DevBuf tables, hits; nvca::PinnedBuf h_tables, h_hits; } roi_bufs[3]; int roi_set = 0;
+    struct RoiBuffers { nvca::DevBuf tables, hits, rej; nvca::PinnedBuf h_tables, h_hits, h_rej; } roi_bufs[3]; int roi_set = 0;
     RoiBuffers &rbuf() { return roi_bufs[roi_set]; }
     size_t roi_first_hint = 0;              // candidates of the recent small-image rounds (+ a quarter): what the launch copies back with itself
     nvca::WorkPool *pool = nullptr; bool pool_tried = false;
@@ -640,6 +641,10 @@ struct RoiStep {                  // one ladder step (scale-cascade scan) or one
     int szw, szh;                 // level size
     int mode, xmax, xofs_off, yofs_off, ialpha_off, ibeta_off;      // the level's cv::resize tables (byte offsets into the launch's table blob)
     double inv_area, ystep;
+    // adaptive == 2 ("dense", FIND_BIGGEST searches): every window that passes stage 0 goes on, visited by the serial walk or not, and the
+    // stage-0 reject bits of the step's grid are written out -- row r's chunk c at rej[rej_off + r * rej_wpr + c] (64 windows a word) -- so
+    // that the host can replay the walk from ANY start column: a narrowed re-scan needs no second launch (api.cpp, fb_replay)
+    int rej_off, rej_wpr;
 };
 struct RoiJobDev {
     const uint8_t *img; int w, h, stride;
@@ -649,7 +654,7 @@ struct RoiJobDev {
 };
 static constexpr int kRoiMaxWin = 2048;           // windows of one ladder step / pyramid level of a small-image job
 void launch_roi(hipStream_t st, const RoiJobDev *jobs, int nsteps, const RoiStep *steps, const unsigned char *tabs, unsigned long long *hits,
-                unsigned hit_cap, int plane_words, int lds_bytes);
+                unsigned hit_cap, int plane_words, int lds_bytes, unsigned long long *rej);
 #ifdef NVCA_STAMPS
 void roi_stamps_dump(const char *path);     // diagnostic build: k_roi's phase sums as text
 #endif
