@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.join(ROOT, "nubomedia-vca_amd"))
 import numpy as np, torch
 from nubovca import capi, synth
 V, ticks, reps = 8, 4, 6
-base = [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
+base = [(150, 200, 560), (1100, 260, 620)] if os.environ.get("BIG") else [(200, 150, 300), (900, 400, 180), (1400, 100, 120), (1500, 700, 240)]
 ctx = capi.Context(0)
 xml_face = synth.calibrated_cascade_xml()
 casc = ctx.load_cascade_xml(xml_face)
 names = ("righteye", "lefteye", "nose", "mouth", "leftear", "rightear")
 kinds = [(0, "righteye", "lefteye"), (1, "nose", None), (2, "mouth", None), (3, "leftear", "rightear")]
-pcs = {nm: ctx.load_cascade_xml(synth.synthetic_part_cascade_xml(nm)) for nm in names}
+pcs = {nm: ctx.load_cascade_xml((synth.calibrated_part_cascade_xml if os.environ.get("BIG") else synth.synthetic_part_cascade_xml)(nm)) for nm in names}
 keep = [[torch.from_numpy(synth.make_bgr(1920, 1080, 40 + 5 * t + v, "natural", [(x + 8 * t + 6 * v, y + 3 * v, sz + 4 * ((t + v) % 3)) for x, y, sz in base])).cuda() for v in range(V)] for t in range(ticks)]
 torch.cuda.synchronize()
 frs = [[capi.make_frame(x.data_ptr(), 1920, 1080, 1920 * 3, capi.MEM_DEVICE) for x in row] for row in keep]
