@@ -321,7 +321,8 @@ int  nvca_part_batch_process(nvca_ctx *ctx, int n, nvca_part_stream *const *stre
  * queued -- nothing is waited for -- and *ticket names the call; the frames must stay valid until the ticket is collected.
  * collect: the face passes' results, the part searches, the merging heuristics; outputs as nvca_part_batch_process.  Tickets are
  * collected in submit order (the streams' state machines advance in that order); at most two are outstanding, so the usual loop
- * is submit(k + 1), collect(k).  A stream may appear in both outstanding calls (not in a synchronous nvca_part_batch_process /
+ * is submit(k + 1), collect(k) on ONE serving thread (a synchronous nvca_part_batch_process takes one of the two slots while it runs: it is
+ * refused while two tickets are outstanding).  A stream may appear in both outstanding calls (not in a synchronous nvca_part_batch_process /
  * nvca_part_stream_process while a ticket of its is outstanding: refused).  A collect that fails rolls its streams back as a
  * failed nvca_part_batch_process does and abandons a newer outstanding ticket with it (rolled back first); a ticket that is never
  * collected is rolled back when the context is destroyed -- or when one of its streams is (nvca_part_stream_destroy gives up every
